@@ -1,0 +1,585 @@
+/*
+ * tfhe_oracle.c -- TEST INFRASTRUCTURE, NOT PRODUCT CODE (see tfhe_oracle.h).
+ *
+ * Plain-C exact-integer restatement of TFHE gate bootstrapping as used by
+ * lab-incert/peba1 through bootsAND/OR/XOR/XNOR/MUX/NOT/COPY/CONSTANT
+ * (/root/reference/src/Math.cpp:27-417).  "parity unpinned" at ciphertext
+ * level -- the arithmetic is in tfhe/tfhe (un-vendored, un-pinned; linked at
+ * /root/reference/CMakeLists.txt:9-15); the algorithm follows SURVEY.md
+ * Appendix A.  Each function names the upstream routine it restates.
+ *
+ * The negacyclic product is exact mod 2^32.  Two interchangeable evaluators:
+ *   - schoolbook in wrapping 32-bit arithmetic (the definition), and
+ *   - a 64-bit Goldilocks (p = 2^64-2^32+1) NTT, exact because
+ *     |sum| < (k+1) l N (Bg/2) 2^31 <= 2^52 < p/2  (SURVEY.md Appendix A.5).
+ * The GPU path uses neither (two 27-bit primes + CRT), so agreement of all
+ * three is a meaningful check.
+ */
+#include "tfhe_oracle.h"
+
+#include <math.h>
+#include <pthread.h>
+#include <stdlib.h>
+#include <string.h>
+
+/* ------------------------------------------------------------------ */
+/* parameters (tfhe: new_default_gate_bootstrapping_parameters)        */
+/* ------------------------------------------------------------------ */
+int orc_params_default(OrcParams *o, int32_t lambda) {
+    if (lambda <= 0 || lambda > 128) return -1;
+    o->N = 1024; o->k = 1; o->ks_t = 8; o->ks_basebit = 2; o->max_stdev = 0.012467;
+    if (lambda > 80) {            /* v1.1 128-bit set */
+        o->n = 630; o->l = 3; o->Bgbit = 7;
+        o->ks_stdev = 1.0 / 32768.0;          /* 2^-15 */
+        o->bk_stdev = 1.0 / 33554432.0;       /* 2^-25 */
+    } else {                      /* 80-bit set */
+        o->n = 500; o->l = 2; o->Bgbit = 10;
+        o->ks_stdev = 2.44e-5; o->bk_stdev = 7.18e-9;
+    }
+    return 0;
+}
+
+int orc_params_p2048(OrcParams *o) {
+    o->N = 2048; o->k = 1; o->n = 1024; o->l = 3; o->Bgbit = 6;
+    o->ks_t = 8; o->ks_basebit = 2;
+    o->ks_stdev = 1.0 / 32768.0;
+    o->bk_stdev = 1.0 / 33554432.0;
+    o->max_stdev = 0.012467;
+    return 0;
+}
+
+size_t orc_bk_words(const OrcParams *p) {
+    return (size_t)p->n * (size_t)((p->k + 1) * p->l) * (size_t)(p->k + 1) * (size_t)p->N;
+}
+size_t orc_ksk_words(const OrcParams *p) {
+    return (size_t)p->k * p->N * (size_t)p->ks_t * (size_t)(1 << p->ks_basebit) * (size_t)(p->n + 1);
+}
+
+/* ------------------------------------------------------------------ */
+/* PRNG: xoshiro256** seeded by splitmix64.  The product implements the */
+/* same generator from this specification ("key derivation") */
+/* ------------------------------------------------------------------ */
+static inline uint64_t rotl64(uint64_t x, int k) { return (x << k) | (x >> (64 - k)); }
+
+void orc_rng_seed(OrcRng *r, uint64_t seed) {
+    uint64_t z = seed;
+    for (int i = 0; i < 4; ++i) {
+        z += 0x9E3779B97F4A7C15ULL;
+        uint64_t t = z;
+        t = (t ^ (t >> 30)) * 0xBF58476D1CE4E5B9ULL;
+        t = (t ^ (t >> 27)) * 0x94D049BB133111EBULL;
+        r->s[i] = t ^ (t >> 31);
+    }
+}
+
+uint64_t orc_rng_next(OrcRng *r) {
+    uint64_t *s = r->s;
+    const uint64_t result = rotl64(s[1] * 5, 7) * 9;
+    const uint64_t t = s[1] << 17;
+    s[2] ^= s[0]; s[3] ^= s[1]; s[1] ^= s[2]; s[0] ^= s[3];
+    s[2] ^= t;
+    s[3] = rotl64(s[3], 45);
+    return result;
+}
+
+Torus32 orc_rng_torus(OrcRng *r) { return (Torus32)(uint32_t)(orc_rng_next(r) >> 32); }
+
+/* tfhe dtot32: double in R/Z -> Torus32 */
+Torus32 orc_dtot32(double d) {
+    return (Torus32)(int64_t)((d - (double)(int64_t)d) * 4294967296.0);
+}
+
+/* Box-Muller, one normal per two draws (tfhe uses std::normal_distribution;
+ * the sampler is a keygen detail, bootstrapping itself draws nothing).       */
+double orc_rng_gauss(OrcRng *r, double sigma) {
+    const double u1 = ((double)(orc_rng_next(r) >> 11) + 1.0) * (1.0 / 9007199254740992.0);
+    const double u2 = (double)(orc_rng_next(r) >> 11) * (1.0 / 9007199254740992.0);
+    return sigma * sqrt(-2.0 * log(u1)) * cos(6.283185307179586476925286766559 * u2);
+}
+
+/* ------------------------------------------------------------------ */
+/* modulus switch (tfhe: modSwitchFromTorus32 / modSwitchToTorus32)    */
+/* ------------------------------------------------------------------ */
+int32_t orc_modswitch(Torus32 x, int32_t Msize) {
+    const uint64_t interv = ((UINT64_C(1) << 63) / (uint64_t)Msize) * 2;
+    const uint64_t half = interv / 2;
+    const uint64_t phase64 = ((uint64_t)(uint32_t)x << 32) + half;
+    return (int32_t)(phase64 / interv);
+}
+
+Torus32 orc_modswitch_to_torus(int32_t mu, int32_t Msize) {
+    const uint64_t interv = ((UINT64_C(1) << 63) / (uint64_t)Msize) * 2;
+    const uint64_t phase64 = (uint64_t)(int64_t)mu * interv;
+    return (Torus32)(phase64 >> 32);
+}
+
+/* ------------------------------------------------------------------ */
+/* exact negacyclic product, schoolbook (tfhe: torusPolynomialMultNaive */
+/* semantics, mod X^N+1, wrapping Torus32)                              */
+/* ------------------------------------------------------------------ */
+void orc_negacyclic_schoolbook(Torus32 *res, const int32_t *ip, const Torus32 *tp, int32_t N) {
+    uint32_t *r = (uint32_t *)res;
+    for (int32_t i = 0; i < N; ++i) r[i] = 0;
+    for (int32_t i = 0; i < N; ++i) {
+        const uint32_t a = (uint32_t)ip[i];
+        if (a == 0) continue;
+        for (int32_t j = 0; j < N - i; ++j) r[i + j] += a * (uint32_t)tp[j];
+        for (int32_t j = N - i; j < N; ++j) r[i + j - N] -= a * (uint32_t)tp[j];
+    }
+}
+
+/* ------------------------------------------------------------------ */
+/* Goldilocks field and negacyclic NTT                                  */
+/* ------------------------------------------------------------------ */
+#define GL_P UINT64_C(0xFFFFFFFF00000001)
+#define GL_EPS UINT64_C(0xFFFFFFFF)
+
+static inline uint64_t gl_reduce128(unsigned __int128 x) {
+    const uint64_t lo = (uint64_t)x, hi = (uint64_t)(x >> 64);
+    const uint64_t hh = hi >> 32, hl = hi & GL_EPS;
+    uint64_t t = lo - hh;               /* 2^96 = -1 */
+    if (lo < hh) t -= GL_EPS;           /* wrapped: +2^64 too much, 2^64 = p + eps */
+    const uint64_t t2 = (hl << 32) - hl; /* hl * (2^32-1), 2^64 = eps */
+    uint64_t r = t + t2;
+    if (r < t2) r += GL_EPS;
+    if (r >= GL_P) r -= GL_P;
+    return r;
+}
+static inline uint64_t gl_mul(uint64_t a, uint64_t b) { return gl_reduce128((unsigned __int128)a * b); }
+static inline uint64_t gl_add(uint64_t a, uint64_t b) {
+    uint64_t r = a + b;
+    if (r < a || r >= GL_P) r -= GL_P;
+    return r;
+}
+static inline uint64_t gl_sub(uint64_t a, uint64_t b) { return a >= b ? a - b : a - b + GL_P; }
+static uint64_t gl_pow(uint64_t a, uint64_t e) {
+    uint64_t r = 1;
+    while (e) { if (e & 1) r = gl_mul(r, a); a = gl_mul(a, a); e >>= 1; }
+    return r;
+}
+
+typedef struct NttTab { int32_t N; uint64_t *psi_br; uint64_t *ipsi_br; uint64_t ninv; } NttTab;
+static NttTab g_tabs[4];
+static int g_ntabs = 0;
+static pthread_mutex_t g_tab_mtx = PTHREAD_MUTEX_INITIALIZER;
+
+static uint32_t bitrev(uint32_t x, int bits) {
+    uint32_t r = 0;
+    for (int i = 0; i < bits; ++i) { r = (r << 1) | (x & 1); x >>= 1; }
+    return r;
+}
+
+static const NttTab *ntt_tab(int32_t N) {
+    pthread_mutex_lock(&g_tab_mtx);
+    for (int i = 0; i < g_ntabs; ++i)
+        if (g_tabs[i].N == N) { pthread_mutex_unlock(&g_tab_mtx); return &g_tabs[i]; }
+    NttTab *t = &g_tabs[g_ntabs];
+    int logn = 0; while ((1 << logn) < N) ++logn;
+    /* 7 generates the multiplicative group; psi = primitive 2N-th root */
+    const uint64_t psi = gl_pow(7, (GL_P - 1) / (uint64_t)(2 * N));
+    const uint64_t ipsi = gl_pow(psi, GL_P - 2);
+    t->N = N;
+    t->psi_br = (uint64_t *)malloc(sizeof(uint64_t) * N);
+    t->ipsi_br = (uint64_t *)malloc(sizeof(uint64_t) * N);
+    uint64_t a = 1, b = 1;
+    for (int32_t i = 0; i < N; ++i) {
+        const uint32_t j = bitrev((uint32_t)i, logn);
+        t->psi_br[j] = a; t->ipsi_br[j] = b;
+        a = gl_mul(a, psi); b = gl_mul(b, ipsi);
+    }
+    t->ninv = gl_pow((uint64_t)N, GL_P - 2);
+    ++g_ntabs;
+    pthread_mutex_unlock(&g_tab_mtx);
+    return t;
+}
+
+/* forward: natural order in, bit-reversed out (merged psi twist) */
+static void gl_ntt_fwd(uint64_t *a, const NttTab *t) {
+    const int32_t N = t->N;
+    int32_t len = N / 2, m = 1;
+    for (; m < N; m <<= 1, len >>= 1) {
+        for (int32_t i = 0; i < m; ++i) {
+            const uint64_t w = t->psi_br[m + i];
+            uint64_t *x = a + 2 * i * len, *y = x + len;
+            for (int32_t j = 0; j < len; ++j) {
+                const uint64_t u = x[j], v = gl_mul(y[j], w);
+                x[j] = gl_add(u, v); y[j] = gl_sub(u, v);
+            }
+        }
+    }
+}
+/* inverse: bit-reversed in, natural out, scaled by 1/N */
+static void gl_ntt_inv(uint64_t *a, const NttTab *t) {
+    const int32_t N = t->N;
+    int32_t len = 1, m = N / 2;
+    for (; m >= 1; m >>= 1, len <<= 1) {
+        for (int32_t i = 0; i < m; ++i) {
+            const uint64_t w = t->ipsi_br[m + i];
+            uint64_t *x = a + 2 * i * len, *y = x + len;
+            for (int32_t j = 0; j < len; ++j) {
+                const uint64_t u = x[j], v = y[j];
+                x[j] = gl_add(u, v); y[j] = gl_mul(gl_sub(u, v), w);
+            }
+        }
+    }
+    for (int32_t j = 0; j < N; ++j) a[j] = gl_mul(a[j], t->ninv);
+}
+static inline uint64_t gl_from_i32(int32_t v) { return v >= 0 ? (uint64_t)v : GL_P - (uint64_t)(-(int64_t)v); }
+/* centred lift then reduction mod 2^32 */
+static inline Torus32 gl_to_torus(uint64_t v) {
+    return v > GL_P / 2 ? (Torus32)(uint32_t)(0u - (uint32_t)(GL_P - v)) : (Torus32)(uint32_t)v;
+}
+
+void orc_negacyclic_ntt(Torus32 *res, const int32_t *ip, const Torus32 *tp, int32_t N) {
+    const NttTab *t = ntt_tab(N);
+    uint64_t *a = (uint64_t *)malloc(sizeof(uint64_t) * 2 * N), *b = a + N;
+    for (int32_t i = 0; i < N; ++i) { a[i] = gl_from_i32(ip[i]); b[i] = gl_from_i32(tp[i]); }
+    gl_ntt_fwd(a, t); gl_ntt_fwd(b, t);
+    for (int32_t i = 0; i < N; ++i) a[i] = gl_mul(a[i], b[i]);
+    gl_ntt_inv(a, t);
+    for (int32_t i = 0; i < N; ++i) res[i] = gl_to_torus(a[i]);
+    free(a);
+}
+
+/* ------------------------------------------------------------------ */
+/* key generation (tfhe: new_random_gate_bootstrapping_secret_keyset,   */
+/* tGswSymEncryptInt, lweCreateKeySwitchKey) with this repo's PRNG.     */
+/* Draw order is part of the shared specification:                      */
+/*   lwe_key bits, tlwe_key bits, then BK rows in memory order (mask     */
+/*   polys uniform, then N gaussians for the body), then KSK rows in     */
+/*   memory order skipping digit value 0 (mask uniform, one gaussian).   */
+/* ------------------------------------------------------------------ */
+static void negacyclic_mul_bits_add(Torus32 *res, const Torus32 *a, const int32_t *bits, int32_t N) {
+    uint32_t *r = (uint32_t *)res;
+    for (int32_t i = 0; i < N; ++i) {
+        if (!bits[i]) continue;
+        for (int32_t j = 0; j < N - i; ++j) r[i + j] += (uint32_t)a[j];
+        for (int32_t j = N - i; j < N; ++j) r[i + j - N] -= (uint32_t)a[j];
+    }
+}
+
+OrcKeySet *orc_keygen(const OrcParams *p, uint64_t seed) {
+    OrcKeySet *ks = (OrcKeySet *)calloc(1, sizeof(OrcKeySet));
+    ks->p = *p;
+    const int32_t n = p->n, N = p->N, k = p->k, l = p->l, kpl = (k + 1) * l;
+    const int32_t t = p->ks_t, base = 1 << p->ks_basebit;
+    OrcRng rng; orc_rng_seed(&rng, seed);
+
+    ks->lwe_key = (int32_t *)malloc(sizeof(int32_t) * n);
+    for (int32_t i = 0; i < n; ++i) ks->lwe_key[i] = (int32_t)(orc_rng_next(&rng) >> 63);
+    ks->tlwe_key = (int32_t *)malloc(sizeof(int32_t) * k * N);
+    for (int32_t i = 0; i < k * N; ++i) ks->tlwe_key[i] = (int32_t)(orc_rng_next(&rng) >> 63);
+
+    /* BK_i = TGSW(lwe_key[i]): (k+1)l TLWE zero-encryptions + mu * gadget */
+    ks->bk = (Torus32 *)malloc(sizeof(Torus32) * orc_bk_words(p));
+    for (int32_t i = 0; i < n; ++i) {
+        for (int32_t row = 0; row < kpl; ++row) {
+            Torus32 *smp = ks->bk + ((size_t)i * kpl + row) * (size_t)(k + 1) * N;
+            Torus32 *body = smp + (size_t)k * N;
+            for (int32_t u = 0; u < k; ++u)
+                for (int32_t j = 0; j < N; ++j) smp[(size_t)u * N + j] = orc_rng_torus(&rng);
+            for (int32_t j = 0; j < N; ++j) body[j] = orc_dtot32(orc_rng_gauss(&rng, p->bk_stdev));
+            for (int32_t u = 0; u < k; ++u)
+                negacyclic_mul_bits_add(body, smp + (size_t)u * N, ks->tlwe_key + (size_t)u * N, N);
+            /* tGswAddMuIntH: row (bloc,j) adds mu*2^{32-(j+1)Bgbit} to coef 0 of poly bloc */
+            const int32_t bloc = row / l, jj = row % l;
+            const uint32_t h = 1u << (32 - (jj + 1) * p->Bgbit);
+            smp[(size_t)bloc * N] = (Torus32)((uint32_t)smp[(size_t)bloc * N] + (uint32_t)ks->lwe_key[i] * h);
+        }
+    }
+
+    /* KSK[i][j][v] = LWE_s(v * s'_i * 2^{32-(j+1)basebit}); v = 0 rows stay zero */
+    ks->ksk = (Torus32 *)calloc(orc_ksk_words(p), sizeof(Torus32));
+    for (int32_t i = 0; i < k * N; ++i)
+        for (int32_t j = 0; j < t; ++j)
+            for (int32_t v = 1; v < base; ++v) {
+                Torus32 *row = ks->ksk + (((size_t)i * t + j) * base + v) * (size_t)(n + 1);
+                const uint32_t mess = (uint32_t)(ks->tlwe_key[i] * v) << (32 - (j + 1) * p->ks_basebit);
+                uint32_t b = 0;
+                for (int32_t q = 0; q < n; ++q) {
+                    row[q] = orc_rng_torus(&rng);
+                    b += (uint32_t)row[q] * (uint32_t)ks->lwe_key[q];
+                }
+                b += mess + (uint32_t)orc_dtot32(orc_rng_gauss(&rng, p->ks_stdev));
+                row[n] = (Torus32)b;
+            }
+
+    /* evaluation-domain image of BK (tfhe: LweBootstrappingKeyFFT) */
+    const NttTab *tab = ntt_tab(N);
+    const size_t npoly = (size_t)n * kpl * (k + 1);
+    ks->bk_ntt = (uint64_t *)malloc(sizeof(uint64_t) * npoly * N);
+    for (size_t q = 0; q < npoly; ++q) {
+        uint64_t *dst = ks->bk_ntt + q * N;
+        const Torus32 *src = ks->bk + q * N;
+        for (int32_t j = 0; j < N; ++j) dst[j] = gl_from_i32(src[j]);
+        gl_ntt_fwd(dst, tab);
+    }
+    return ks;
+}
+
+void orc_keyset_free(OrcKeySet *ks) {
+    if (!ks) return;
+    free(ks->lwe_key); free(ks->tlwe_key); free(ks->bk); free(ks->ksk); free(ks->bk_ntt);
+    free(ks);
+}
+
+/* ------------------------------------------------------------------ */
+/* encrypt / decrypt (tfhe: bootsSymEncrypt, lwePhase, bootsSymDecrypt) */
+/* draw order: one gaussian for the body, then n uniform mask words     */
+/* ------------------------------------------------------------------ */
+void orc_encrypt_bit(const OrcKeySet *ks, OrcRng *rng, int32_t message, Torus32 *ct) {
+    const int32_t n = ks->p.n;
+    const Torus32 mu = message ? (Torus32)(1 << 29) : (Torus32)(-(1 << 29));
+    uint32_t b = (uint32_t)mu + (uint32_t)orc_dtot32(orc_rng_gauss(rng, ks->p.ks_stdev));
+    for (int32_t i = 0; i < n; ++i) {
+        ct[i] = orc_rng_torus(rng);
+        b += (uint32_t)ct[i] * (uint32_t)ks->lwe_key[i];
+    }
+    ct[n] = (Torus32)b;
+}
+
+Torus32 orc_phase(const OrcKeySet *ks, const Torus32 *ct) {
+    const int32_t n = ks->p.n;
+    uint32_t ph = (uint32_t)ct[n];
+    for (int32_t i = 0; i < n; ++i) ph -= (uint32_t)ct[i] * (uint32_t)ks->lwe_key[i];
+    return (Torus32)ph;
+}
+
+int32_t orc_decrypt_bit(const OrcKeySet *ks, const Torus32 *ct) { return orc_phase(ks, ct) > 0 ? 1 : 0; }
+
+/* ------------------------------------------------------------------ */
+/* gadget decomposition (tfhe: tGswTorus32PolynomialDecompH)            */
+/* ------------------------------------------------------------------ */
+void orc_decompose(int32_t *digits, const Torus32 *poly, const OrcParams *p) {
+    const int32_t N = p->N, l = p->l, Bgbit = p->Bgbit;
+    const uint32_t mask = (1u << Bgbit) - 1u;
+    const int32_t halfBg = 1 << (Bgbit - 1);
+    uint32_t offset = 0;
+    for (int32_t j = 1; j <= l; ++j) offset += (uint32_t)halfBg << (32 - j * Bgbit);
+    for (int32_t q = 0; q < l; ++q) {
+        const int32_t decal = 32 - (q + 1) * Bgbit;
+        for (int32_t j = 0; j < N; ++j)
+            digits[(size_t)q * N + j] = (int32_t)((((uint32_t)poly[j] + offset) >> decal) & mask) - halfBg;
+    }
+}
+
+/* (X^a - 1) * src, a in [0,2N)  (tfhe: torusPolynomialMulByXaiMinusOne) */
+static void mul_xai_minus_one(Torus32 *out, int32_t a, const Torus32 *in, int32_t N) {
+    const uint32_t *s = (const uint32_t *)in; uint32_t *o = (uint32_t *)out;
+    if (a < N) {
+        for (int32_t i = 0; i < a; ++i) o[i] = 0u - s[i - a + N] - s[i];
+        for (int32_t i = a; i < N; ++i) o[i] = s[i - a] - s[i];
+    } else {
+        const int32_t aa = a - N;
+        for (int32_t i = 0; i < aa; ++i) o[i] = s[i - aa + N] - s[i];
+        for (int32_t i = aa; i < N; ++i) o[i] = 0u - s[i - aa] - s[i];
+    }
+}
+/* X^a * src (tfhe: torusPolynomialMulByXai) */
+static void mul_xai(Torus32 *out, int32_t a, const Torus32 *in, int32_t N) {
+    const uint32_t *s = (const uint32_t *)in; uint32_t *o = (uint32_t *)out;
+    if (a < N) {
+        for (int32_t i = 0; i < a; ++i) o[i] = 0u - s[i - a + N];
+        for (int32_t i = a; i < N; ++i) o[i] = s[i - a];
+    } else {
+        const int32_t aa = a - N;
+        for (int32_t i = 0; i < aa; ++i) o[i] = s[i - aa + N];
+        for (int32_t i = aa; i < N; ++i) o[i] = 0u - s[i - aa];
+    }
+}
+
+/* one blind-rotate step (tfhe: tfhe_MuxRotate_FFT + tGswFFTExternMulToTLwe,
+ * with the product exact):  acc += BK_i (.) ((X^barai - 1) acc)            */
+void orc_cmux_rotate(const OrcKeySet *ks, int32_t i, int32_t barai, Torus32 *acc, int use_ntt) {
+    const OrcParams *p = &ks->p;
+    const int32_t N = p->N, k = p->k, l = p->l, kpl = (k + 1) * l;
+    Torus32 *d = (Torus32 *)malloc(sizeof(Torus32) * (size_t)(k + 1) * N);
+    int32_t *dig = (int32_t *)malloc(sizeof(int32_t) * (size_t)kpl * N);
+    for (int32_t u = 0; u <= k; ++u) {
+        mul_xai_minus_one(d + (size_t)u * N, barai, acc + (size_t)u * N, N);
+        orc_decompose(dig + (size_t)u * l * N, d + (size_t)u * N, p);
+    }
+    if (use_ntt) {
+        const NttTab *tab = ntt_tab(N);
+        uint64_t *dn = (uint64_t *)malloc(sizeof(uint64_t) * (size_t)(kpl + k + 1) * N);
+        uint64_t *sum = dn + (size_t)kpl * N;
+        for (int32_t q = 0; q < kpl; ++q) {
+            uint64_t *x = dn + (size_t)q * N;
+            for (int32_t j = 0; j < N; ++j) x[j] = gl_from_i32(dig[(size_t)q * N + j]);
+            gl_ntt_fwd(x, tab);
+        }
+        for (int32_t w = 0; w <= k; ++w) {
+            uint64_t *s = sum + (size_t)w * N;
+            for (int32_t j = 0; j < N; ++j) s[j] = 0;
+            for (int32_t q = 0; q < kpl; ++q) {
+                const uint64_t *bkq = ks->bk_ntt + (((size_t)i * kpl + q) * (k + 1) + w) * N;
+                const uint64_t *x = dn + (size_t)q * N;
+                for (int32_t j = 0; j < N; ++j) s[j] = gl_add(s[j], gl_mul(x[j], bkq[j]));
+            }
+            gl_ntt_inv(s, tab);
+            uint32_t *a = (uint32_t *)(acc + (size_t)w * N);
+            for (int32_t j = 0; j < N; ++j) a[j] += (uint32_t)gl_to_torus(s[j]);
+        }
+        free(dn);
+    } else {
+        Torus32 *prod = (Torus32 *)malloc(sizeof(Torus32) * N);
+        for (int32_t w = 0; w <= k; ++w) {
+            uint32_t *a = (uint32_t *)(acc + (size_t)w * N);
+            for (int32_t q = 0; q < kpl; ++q) {
+                const Torus32 *bkq = ks->bk + (((size_t)i * kpl + q) * (k + 1) + w) * N;
+                orc_negacyclic_schoolbook(prod, dig + (size_t)q * N, bkq, N);
+                for (int32_t j = 0; j < N; ++j) a[j] += (uint32_t)prod[j];
+            }
+        }
+        free(prod);
+    }
+    free(d); free(dig);
+}
+
+/* tfhe: tfhe_blindRotateAndExtract_FFT up to (not including) the extract */
+void orc_blind_rotate(const OrcKeySet *ks, const int32_t *bara, int32_t barb,
+                      Torus32 mu, Torus32 *acc, int use_ntt) {
+    const OrcParams *p = &ks->p;
+    const int32_t N = p->N, k = p->k, n = p->n;
+    Torus32 *tv = (Torus32 *)malloc(sizeof(Torus32) * N);
+    for (int32_t j = 0; j < N; ++j) tv[j] = mu;
+    memset(acc, 0, sizeof(Torus32) * (size_t)k * N);
+    if (barb != 0) mul_xai(acc + (size_t)k * N, 2 * N - barb, tv, N);
+    else memcpy(acc + (size_t)k * N, tv, sizeof(Torus32) * N);
+    for (int32_t i = 0; i < n; ++i) {
+        if (bara[i] == 0) continue;
+        orc_cmux_rotate(ks, i, bara[i], acc, use_ntt);
+    }
+    free(tv);
+}
+
+/* tfhe: tLweExtractLweSampleIndex(index 0) */
+void orc_sample_extract(const OrcParams *p, const Torus32 *acc, Torus32 *u) {
+    const int32_t N = p->N, k = p->k;
+    for (int32_t i = 0; i < k; ++i) {
+        const uint32_t *a = (const uint32_t *)(acc + (size_t)i * N);
+        u[(size_t)i * N] = (Torus32)a[0];
+        for (int32_t j = 1; j < N; ++j) u[(size_t)i * N + j] = (Torus32)(0u - a[N - j]);
+    }
+    u[(size_t)k * N] = acc[(size_t)k * N];
+}
+
+/* tfhe: lweKeySwitch / lweKeySwitchTranslate_fromArray */
+void orc_keyswitch(const OrcKeySet *ks, const Torus32 *u, Torus32 *ct) {
+    const OrcParams *p = &ks->p;
+    const int32_t n = p->n, nin = p->k * p->N, t = p->ks_t, basebit = p->ks_basebit;
+    const int32_t base = 1 << basebit;
+    const uint32_t prec_offset = 1u << (32 - (1 + basebit * t));
+    const uint32_t mask = (uint32_t)base - 1u;
+    uint32_t *r = (uint32_t *)ct;
+    for (int32_t q = 0; q < n; ++q) r[q] = 0;
+    r[n] = (uint32_t)u[nin];
+    for (int32_t i = 0; i < nin; ++i) {
+        const uint32_t aibar = (uint32_t)u[i] + prec_offset;
+        for (int32_t j = 0; j < t; ++j) {
+            const uint32_t aij = (aibar >> (32 - (j + 1) * basebit)) & mask;
+            if (aij == 0) continue;
+            const uint32_t *row = (const uint32_t *)(ks->ksk + (((size_t)i * t + j) * base + aij) * (size_t)(n + 1));
+            for (int32_t q = 0; q <= n; ++q) r[q] -= row[q];
+        }
+    }
+}
+
+/* tfhe: tfhe_bootstrap_woKS_FFT */
+void orc_bootstrap_woks(const OrcKeySet *ks, const Torus32 *lin, Torus32 mu, Torus32 *u, int use_ntt) {
+    const OrcParams *p = &ks->p;
+    const int32_t n = p->n, N = p->N, k = p->k;
+    int32_t *bara = (int32_t *)malloc(sizeof(int32_t) * n);
+    Torus32 *acc = (Torus32 *)malloc(sizeof(Torus32) * (size_t)(k + 1) * N);
+    const int32_t barb = orc_modswitch(lin[n], 2 * N);
+    for (int32_t i = 0; i < n; ++i) bara[i] = orc_modswitch(lin[i], 2 * N);
+    orc_blind_rotate(ks, bara, barb, mu, acc, use_ntt);
+    orc_sample_extract(p, acc, u);
+    free(bara); free(acc);
+}
+
+/* ------------------------------------------------------------------ */
+/* gates (tfhe: boot-gates.cpp)                                         */
+/* ------------------------------------------------------------------ */
+static const struct { int32_t c8; int32_t sa, sb; } GATE_TAB[ORC_NGATES2] = {
+    /* NAND  */ { 1, -1, -1}, /* OR    */ { 1,  1,  1}, /* AND   */ {-1,  1,  1},
+    /* NOR   */ {-1, -1, -1}, /* XOR   */ { 2,  2,  2}, /* XNOR  */ {-2, -2, -2},
+    /* ANDNY */ {-1, -1,  1}, /* ANDYN */ {-1,  1, -1}, /* ORNY  */ { 1, -1,  1},
+    /* ORYN  */ { 1,  1, -1},
+};
+
+void orc_gate_prelude(const OrcParams *p, int gate, const Torus32 *ca, const Torus32 *cb, Torus32 *t) {
+    const int32_t n = p->n;
+    const uint32_t sa = (uint32_t)GATE_TAB[gate].sa, sb = (uint32_t)GATE_TAB[gate].sb;
+    for (int32_t i = 0; i <= n; ++i) t[i] = (Torus32)(sa * (uint32_t)ca[i] + sb * (uint32_t)cb[i]);
+    t[n] = (Torus32)((uint32_t)t[n] + (uint32_t)orc_modswitch_to_torus(GATE_TAB[gate].c8, 8));
+}
+
+void orc_gate2(const OrcKeySet *ks, int gate, Torus32 *out, const Torus32 *ca, const Torus32 *cb, int use_ntt) {
+    const OrcParams *p = &ks->p;
+    Torus32 *t = (Torus32 *)malloc(sizeof(Torus32) * (size_t)(p->n + 1));
+    Torus32 *u = (Torus32 *)malloc(sizeof(Torus32) * (size_t)(p->k * p->N + 1));
+    orc_gate_prelude(p, gate, ca, cb, t);
+    orc_bootstrap_woks(ks, t, orc_modswitch_to_torus(1, 8), u, use_ntt);
+    orc_keyswitch(ks, u, out);
+    free(t); free(u);
+}
+
+void orc_mux(const OrcKeySet *ks, Torus32 *out, const Torus32 *a, const Torus32 *b, const Torus32 *c, int use_ntt) {
+    const OrcParams *p = &ks->p;
+    const int32_t n = p->n, nin = p->k * p->N;
+    const Torus32 mu = orc_modswitch_to_torus(1, 8);
+    Torus32 *t = (Torus32 *)malloc(sizeof(Torus32) * (size_t)(n + 1));
+    Torus32 *u1 = (Torus32 *)malloc(sizeof(Torus32) * (size_t)(nin + 1) * 2), *u2 = u1 + nin + 1;
+    orc_gate_prelude(p, ORC_AND, a, b, t);      /* (0,-1/8) + a + b */
+    orc_bootstrap_woks(ks, t, mu, u1, use_ntt);
+    orc_gate_prelude(p, ORC_ANDNY, a, c, t);    /* (0,-1/8) - a + c */
+    orc_bootstrap_woks(ks, t, mu, u2, use_ntt);
+    for (int32_t i = 0; i <= nin; ++i) u1[i] = (Torus32)((uint32_t)u1[i] + (uint32_t)u2[i]);
+    u1[nin] = (Torus32)((uint32_t)u1[nin] + (uint32_t)mu);
+    orc_keyswitch(ks, u1, out);
+    free(t); free(u1);
+}
+
+void orc_not(const OrcParams *p, Torus32 *out, const Torus32 *a) {
+    for (int32_t i = 0; i <= p->n; ++i) out[i] = (Torus32)(0u - (uint32_t)a[i]);
+}
+
+void orc_constant(const OrcParams *p, Torus32 *out, int32_t value) {
+    for (int32_t i = 0; i < p->n; ++i) out[i] = 0;
+    const Torus32 mu = orc_modswitch_to_torus(1, 8);
+    out[p->n] = value ? mu : (Torus32)(0u - (uint32_t)mu);
+}
+
+/* ------------------------------------------------------------------ */
+/* threaded batch for the cpu_baseline leg                              */
+/* ------------------------------------------------------------------ */
+typedef struct BatchJob {
+    const OrcKeySet *ks; int gate; Torus32 *out; const Torus32 *ca, *cb;
+    int32_t begin, end;
+} BatchJob;
+
+static void *batch_worker(void *arg) {
+    BatchJob *j = (BatchJob *)arg;
+    const size_t w = (size_t)j->ks->p.n + 1;
+    for (int32_t g = j->begin; g < j->end; ++g)
+        orc_gate2(j->ks, j->gate, j->out + g * w, j->ca + g * w, j->cb + g * w, 1);
+    return NULL;
+}
+
+void orc_gate2_batch(const OrcKeySet *ks, int gate, Torus32 *out, const Torus32 *ca, const Torus32 *cb,
+                     int32_t count, int32_t nthreads) {
+    if (nthreads < 1) nthreads = 1;
+    if (nthreads > count) nthreads = count > 0 ? count : 1;
+    (void)ntt_tab(ks->p.N);
+    pthread_t *th = (pthread_t *)malloc(sizeof(pthread_t) * nthreads);
+    BatchJob *jobs = (BatchJob *)malloc(sizeof(BatchJob) * nthreads);
+    for (int32_t t = 0; t < nthreads; ++t) {
+        jobs[t] = (BatchJob){ks, gate, out, ca, cb,
+                             (int32_t)((int64_t)count * t / nthreads),
+                             (int32_t)((int64_t)count * (t + 1) / nthreads)};
+        pthread_create(&th[t], NULL, batch_worker, &jobs[t]);
+    }
+    for (int32_t t = 0; t < nthreads; ++t) pthread_join(th[t], NULL);
+    free(th); free(jobs);
+}
