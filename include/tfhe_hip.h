@@ -1,0 +1,119 @@
+/*
+ * tfhe_hip.h -- extensions of libtfhe-hip beyond the upstream tfhe C API.
+ *
+ * Everything here is plain C ABI (pointers and sizes, no C++/torch types).  The
+ * upstream-compatible surface is in tfhe/tfhe_gate_bootstrapping_functions.h;
+ * this header adds what a one-gate-per-call API cannot express: seeded keys,
+ * deferred (batched, levelised) execution, array-wide gates, raw ciphertext
+ * words, statistics, and kernel-level entry points used by the parity tests.
+ */
+#ifndef TFHE_HIP_H
+#define TFHE_HIP_H
+
+#include "tfhe/tfhe_core.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* gate codes for tfhe_hip_gate_batch (2-input gates share one kernel and differ
+ * only in the linear prelude) */
+enum TfheHipGate {
+    TFHE_HIP_NAND = 0, TFHE_HIP_OR, TFHE_HIP_AND, TFHE_HIP_NOR, TFHE_HIP_XOR, TFHE_HIP_XNOR,
+    TFHE_HIP_ANDNY, TFHE_HIP_ANDYN, TFHE_HIP_ORNY, TFHE_HIP_ORYN
+};
+
+/* ---- error channel: the upstream API returns void everywhere;
+ * failures are reported here and fatal ones also abort, like upstream ---- */
+const char *tfhe_hip_last_error(void);
+void tfhe_hip_clear_error(void);
+
+/* ---- device selection (call before the first keyset is created) ---- */
+int tfhe_hip_set_device(int device);
+int tfhe_hip_get_device(void);
+
+/* ---- parameters ---- */
+TFheGateBootstrappingParameterSet *tfhe_hip_new_parameters(
+    int32_t n, int32_t N, int32_t k, int32_t l, int32_t Bgbit, int32_t ks_t, int32_t ks_basebit,
+    double ks_stdev, double bk_stdev, double max_stdev);
+/* BASELINE.json configs[4]: N=2048, Bg=2^6, l=3 (n=1024, ks 8x2 bit fixed by this repo) */
+TFheGateBootstrappingParameterSet *tfhe_hip_new_p2048_parameters(void);
+
+/* ---- deterministic key generation and encryption randomness ---- */
+TFheGateBootstrappingSecretKeySet *tfhe_hip_new_secret_keyset_seeded(
+    const TFheGateBootstrappingParameterSet *params, uint64_t seed);
+/* host-only keyset (no device upload): lets CPU-only tests check key derivation */
+TFheGateBootstrappingSecretKeySet *tfhe_hip_new_secret_keyset_seeded_host(
+    const TFheGateBootstrappingParameterSet *params, uint64_t seed);
+void tfhe_hip_set_encrypt_seed(uint64_t seed);
+
+/* read-only views of the key material (parity tests hash these) */
+const int32_t *tfhe_hip_key_lwe(const TFheGateBootstrappingSecretKeySet *key, int64_t *count);
+const int32_t *tfhe_hip_key_tlwe(const TFheGateBootstrappingSecretKeySet *key, int64_t *count);
+const Torus32 *tfhe_hip_key_bk(const TFheGateBootstrappingCloudKeySet *cloud, int64_t *count);
+const Torus32 *tfhe_hip_key_ksk(const TFheGateBootstrappingCloudKeySet *cloud, int64_t *count);
+
+/* ---- raw ciphertext words: n mask words then the body ---- */
+int32_t tfhe_hip_sample_words(const TFheGateBootstrappingParameterSet *params);
+/* samples[0..count) are consecutive elements of one array; words are packed
+ * [count][n+1] */
+int tfhe_hip_export_samples(const LweSample *samples, int32_t count,
+                            const TFheGateBootstrappingParameterSet *params, Torus32 *out_words);
+int tfhe_hip_import_samples(LweSample *samples, int32_t count,
+                            const TFheGateBootstrappingParameterSet *params, const Torus32 *in_words);
+/* same, to/from DEVICE memory (e.g. a torch tensor's data_ptr) for collectives */
+int tfhe_hip_export_samples_device(const LweSample *samples, int32_t count,
+                                   const TFheGateBootstrappingParameterSet *params, void *device_words);
+int tfhe_hip_import_samples_device(LweSample *samples, int32_t count,
+                                   const TFheGateBootstrappingParameterSet *params, const void *device_words);
+/* refresh the host mirror (a, b) of samples whose value lives on the device */
+int tfhe_hip_sync_samples(const LweSample *samples, int32_t count);
+
+/* ---- execution mode ----
+ * immediate (default): every boots* call is complete on return, as upstream.
+ * deferred: boots* calls are recorded (SSA-renamed, so overwritten and freed
+ * temporaries are safe), levelised by data dependence, and executed level by
+ * level as batched kernels at tfhe_hip_flush() or at the next decrypt/export. */
+void tfhe_hip_set_deferred(int on);
+int tfhe_hip_get_deferred(void);
+int tfhe_hip_flush(void);   /* returns the number of levels executed, <0 on error */
+
+/* result[i] = gate(a[i], b[i]) for i < count, one batched launch */
+int tfhe_hip_gate_batch(int gate, LweSample *result, const LweSample *a, const LweSample *b,
+                        int32_t count, const TFheGateBootstrappingCloudKeySet *bk);
+
+/* ---- statistics ---- */
+typedef struct TfheHipStats {
+    uint64_t blind_rotates;     /* K2 instances */
+    uint64_t keyswitches;       /* K3 instances */
+    uint64_t linear_ops;        /* NOT */
+    uint64_t levels;            /* batched levels executed */
+    uint64_t flushes;
+    uint64_t br_launches;       /* blind-rotate kernel launches */
+    double   ms_blind_rotate;   /* device time, HIP events on the engine stream */
+    double   ms_keyswitch;
+    double   ms_flush_wall;     /* host wall time inside flush */
+} TfheHipStats;
+void tfhe_hip_get_stats(TfheHipStats *out);
+void tfhe_hip_reset_stats(void);
+/* when on, every kernel launch is bracketed by HIP events (adds sync points) */
+void tfhe_hip_set_kernel_timing(int on);
+
+/* ---- kernel-level entry points (K2/K3 parity tests against the oracle) ---- */
+/* exact negacyclic products res[c] = ip[c] * tp[c] mod (X^N+1) mod 2^32 through
+ * the device NTT (two 27-bit primes + CRT); |ip| must be < 2^12 */
+int tfhe_hip_kernel_negacyclic(const TFheGateBootstrappingCloudKeySet *bk, const int32_t *ip,
+                               const Torus32 *tp, Torus32 *res, int32_t count);
+/* modswitch + blind rotate + extract of `count` linear combinations lin[c]
+ * (n+1 words each): u_out[c] (kN+1 words) and, if acc_out != NULL, the raw
+ * accumulator ((k+1)N words) */
+int tfhe_hip_kernel_bootstrap_woks(const TFheGateBootstrappingCloudKeySet *bk, const Torus32 *lin,
+                                   int32_t count, Torus32 *u_out, Torus32 *acc_out);
+/* key switch of `count` extracted samples u[c] (kN+1 words) -> out[c] (n+1 words) */
+int tfhe_hip_kernel_keyswitch(const TFheGateBootstrappingCloudKeySet *bk, const Torus32 *u,
+                              int32_t count, Torus32 *out);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

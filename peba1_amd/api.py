@@ -1,0 +1,182 @@
+"""Thin Python mirror of the tfhe gate API as served by libtfhe-hip.so.
+
+Names follow the reference's vocabulary (parameter set, secret/cloud keyset,
+LweSample arrays, boots* gates; /root/reference/src/Math.cpp, src/main.cpp).
+Everything here is plumbing over the C ABI; the arithmetic is in the HIP kernels.
+"""
+import ctypes as C
+
+import numpy as np
+
+from . import lib as _l
+
+GATE_CODES = {"NAND": 0, "OR": 1, "AND": 2, "NOR": 3, "XOR": 4, "XNOR": 5,
+              "ANDNY": 6, "ANDYN": 7, "ORNY": 8, "ORYN": 9}
+
+
+def _i32p(a):
+    assert a.dtype == np.int32 and a.flags["C_CONTIGUOUS"]
+    return a.ctypes.data_as(_l.I32P)
+
+
+def last_error():
+    return _l.load().tfhe_hip_last_error().decode()
+
+
+class ParameterSet:
+    """new_default_gate_bootstrapping_parameters (main.cpp:21) or an explicit tuple."""
+
+    def __init__(self, minimum_lambda=128, custom=None, p2048=False):
+        L = _l.load()
+        if custom is not None:
+            self.ptr = L.tfhe_hip_new_parameters(*custom)
+        elif p2048:
+            self.ptr = L.tfhe_hip_new_p2048_parameters()
+        else:
+            self.ptr = L.new_default_gate_bootstrapping_parameters(minimum_lambda)
+        if not self.ptr:
+            raise ValueError("parameter set rejected: " + last_error())
+        self.n = self.ptr.contents.in_out_params.contents.n
+        tg = self.ptr.contents.tgsw_params.contents
+        self.N = tg.tlwe_params.contents.N
+        self.k = tg.tlwe_params.contents.k
+        self.l, self.Bgbit = tg.l, tg.Bgbit
+        self.ks_t, self.ks_basebit = self.ptr.contents.ks_t, self.ptr.contents.ks_basebit
+        self.words = self.n + 1
+
+
+class SecretKeySet:
+    """new_random_gate_bootstrapping_secret_keyset (main.cpp:22) with an explicit seed."""
+
+    def __init__(self, params, seed, device=True):
+        L = _l.load()
+        self.params = params
+        f = L.tfhe_hip_new_secret_keyset_seeded if device else L.tfhe_hip_new_secret_keyset_seeded_host
+        self.ptr = f(params.ptr, seed)
+        if not self.ptr:
+            raise RuntimeError("keygen failed: " + last_error())
+        self.cloud = C.pointer(self.ptr.contents.cloud)   # &key->cloud, main.cpp:23
+
+    def close(self):
+        if self.ptr:
+            _l.load().delete_gate_bootstrapping_secret_keyset(self.ptr)
+            self.ptr = None
+
+    def _arr(self, f, owner):
+        cnt = C.c_int64()
+        p = f(owner, C.byref(cnt))
+        return np.ctypeslib.as_array(p, shape=(cnt.value,))
+
+    def lwe_key(self):
+        return self._arr(_l.load().tfhe_hip_key_lwe, self.ptr)
+
+    def tlwe_key(self):
+        return self._arr(_l.load().tfhe_hip_key_tlwe, self.ptr)
+
+    def bk(self):
+        return self._arr(_l.load().tfhe_hip_key_bk, self.cloud)
+
+    def ksk(self):
+        return self._arr(_l.load().tfhe_hip_key_ksk, self.cloud)
+
+
+class CiphertextArray:
+    """new_gate_bootstrapping_ciphertext_array / delete_... (Math.cpp:28-30,47-49)."""
+
+    def __init__(self, params, count):
+        self.params, self.count = params, count
+        self.ptr = _l.load().new_gate_bootstrapping_ciphertext_array(count, params.ptr)
+
+    def close(self):
+        if self.ptr:
+            _l.load().delete_gate_bootstrapping_ciphertext_array(self.count, self.ptr)
+            self.ptr = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def at(self, i):
+        return C.cast(C.addressof(self.ptr.contents) + i * C.sizeof(_l.LweSample), _l.LS)
+
+    def encrypt(self, bits, key):
+        L = _l.load()
+        for i, b in enumerate(bits):
+            L.bootsSymEncrypt(self.at(i), int(b), key.ptr)
+        return self
+
+    def decrypt(self, key):
+        L = _l.load()
+        return np.array([L.bootsSymDecrypt(self.at(i), key.ptr) for i in range(self.count)], dtype=np.int32)
+
+    def words(self):
+        out = np.zeros((self.count, self.params.words), dtype=np.int32)
+        rc = _l.load().tfhe_hip_export_samples(self.ptr, self.count, self.params.ptr, _i32p(out))
+        if rc != 0:
+            raise RuntimeError(last_error())
+        return out
+
+    def set_words(self, w):
+        w = np.ascontiguousarray(w, dtype=np.int32).reshape(self.count, self.params.words)
+        rc = _l.load().tfhe_hip_import_samples(self.ptr, self.count, self.params.ptr, _i32p(w))
+        if rc != 0:
+            raise RuntimeError(last_error())
+        return self
+
+
+def gate_batch(name, result, a, b, key):
+    rc = _l.load().tfhe_hip_gate_batch(GATE_CODES[name], result.ptr, a.ptr, b.ptr, result.count, key.cloud)
+    if rc != 0:
+        raise RuntimeError(last_error())
+
+
+def set_deferred(on):
+    _l.load().tfhe_hip_set_deferred(1 if on else 0)
+
+
+def flush():
+    return _l.load().tfhe_hip_flush()
+
+
+def stats():
+    s = _l.Stats()
+    _l.load().tfhe_hip_get_stats(C.byref(s))
+    return {f: getattr(s, f) for f, _ in s._fields_}
+
+
+def reset_stats():
+    _l.load().tfhe_hip_reset_stats()
+
+
+def kernel_negacyclic(key, ip, tp):
+    ip = np.ascontiguousarray(ip, dtype=np.int32)
+    tp = np.ascontiguousarray(tp, dtype=np.int32)
+    res = np.zeros_like(tp)
+    rc = _l.load().tfhe_hip_kernel_negacyclic(key.cloud, _i32p(ip), _i32p(tp), _i32p(res), ip.shape[0])
+    if rc != 0:
+        raise RuntimeError(last_error())
+    return res
+
+
+def kernel_bootstrap_woks(key, lin, want_acc=False):
+    p = key.params
+    lin = np.ascontiguousarray(lin, dtype=np.int32).reshape(-1, p.words)
+    u = np.zeros((lin.shape[0], p.k * p.N + 1), dtype=np.int32)
+    acc = np.zeros((lin.shape[0], (p.k + 1) * p.N), dtype=np.int32) if want_acc else None
+    rc = _l.load().tfhe_hip_kernel_bootstrap_woks(key.cloud, _i32p(lin), lin.shape[0], _i32p(u),
+                                                  _i32p(acc) if want_acc else None)
+    if rc != 0:
+        raise RuntimeError(last_error())
+    return (u, acc) if want_acc else u
+
+
+def kernel_keyswitch(key, u):
+    p = key.params
+    u = np.ascontiguousarray(u, dtype=np.int32).reshape(-1, p.k * p.N + 1)
+    out = np.zeros((u.shape[0], p.words), dtype=np.int32)
+    rc = _l.load().tfhe_hip_kernel_keyswitch(key.cloud, _i32p(u), u.shape[0], _i32p(out))
+    if rc != 0:
+        raise RuntimeError(last_error())
+    return out

@@ -1,0 +1,17 @@
+#!/bin/bash
+# Builds libtfhe-hip.so (HIP kernels + C ABI) for gfx950, in-tree.
+set -euo pipefail
+cd "$(dirname "$0")"
+OUT=../libtfhe-hip.so
+ROCM=${ROCM_PATH:-/opt/rocm}
+HIPCC=${HIPCC:-$ROCM/bin/hipcc}
+CXX=${HOSTCXX:-$ROCM/lib/llvm/bin/clang++}
+FLAGS="-O3 -std=c++17 -fPIC -ffp-contract=off -Wall -Wno-unused-result"
+HOSTFLAGS="$FLAGS -D__HIP_PLATFORM_AMD__ -I$ROCM/include"
+$HIPCC $FLAGS --offload-arch=gfx950 -c kernels.hip -o kernels.o &
+$CXX $HOSTFLAGS -c host_keys.cpp -o host_keys.o &
+$CXX $HOSTFLAGS -c engine.cpp -o engine.o &
+$CXX $HOSTFLAGS -c shim.cpp -o shim.o &
+wait -n; wait -n; wait -n; wait -n
+$HIPCC -shared -o $OUT kernels.o host_keys.o engine.o shim.o
+echo "built $(realpath $OUT)"

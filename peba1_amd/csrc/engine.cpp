@@ -1,0 +1,362 @@
+// engine.cpp -- device memory, key upload and batched level execution.
+#include "engine.hpp"
+
+#include <chrono>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <mutex>
+
+#include "ntt_field.hpp"
+
+namespace tfhe_hip {
+
+// ---- error channel ---------------------------------------------------------
+static std::string g_last_error;
+static std::mutex g_err_mtx;
+
+void set_error(const std::string &msg) {
+    std::lock_guard<std::mutex> g(g_err_mtx);
+    g_last_error = msg;
+}
+const std::string &last_error_ref() { return g_last_error; }
+
+[[noreturn]] void fatal(const std::string &msg) {
+    set_error(msg);
+    std::fprintf(stderr, "libtfhe-hip: fatal: %s\n", msg.c_str());
+    std::abort();
+}
+
+void hip_check(hipError_t e, const char *what) {
+    if (e != hipSuccess) fatal(std::string(what) + ": " + hipGetErrorString(e));
+}
+
+// ---- slot pool ---------------------------------------------------------------
+SlotPool::SlotPool(int ct_words, int ct_stride, size_t capacity) : words_(ct_words), stride_(ct_stride), cap_(capacity) {
+    hip_check(hipMalloc(reinterpret_cast<void **>(&data_), cap_ * (size_t)stride_ * sizeof(int32_t)), "hipMalloc(slot pool)");
+    ref_.assign(cap_, 0);
+    level.assign(cap_, 0);
+    free_.reserve(cap_);
+    for (size_t i = cap_; i-- > 0;) free_.push_back((int32_t)i);
+}
+SlotPool::~SlotPool() {
+    if (data_) (void)hipFree(data_);
+}
+int32_t SlotPool::alloc() {
+    if (free_.empty())
+        fatal("ciphertext slot pool exhausted (" + std::to_string(cap_) +
+              " slots); raise TFHE_HIP_POOL_SLOTS or call tfhe_hip_flush() more often");
+    const int32_t s = free_.back();
+    free_.pop_back();
+    ref_[s] = 1;
+    level[s] = 0;
+    return s;
+}
+void SlotPool::release(int32_t s) {
+    if (s < 0) return;
+    if (--ref_[s] == 0) free_.push_back(s);
+}
+
+// ---- engine ------------------------------------------------------------------
+Engine &Engine::get() {
+    static Engine e;
+    return e;
+}
+
+void Engine::set_device(int d) {
+    if (inited_ && d != device_) fatal("tfhe_hip_set_device after the engine was initialised");
+    device_ = d;
+}
+
+void Engine::ensure_init() {
+    if (inited_) return;
+    int count = 0;
+    if (hipGetDeviceCount(&count) != hipSuccess || count == 0)
+        fatal("no HIP device available: libtfhe-hip evaluates gates on the GPU only (there is no CPU fallback)");
+    if (const char *env = std::getenv("TFHE_HIP_DEVICE")) device_ = std::atoi(env);
+    hip_check(hipSetDevice(device_), "hipSetDevice");
+    hip_check(hipStreamCreateWithFlags(&stream_, hipStreamNonBlocking), "hipStreamCreate");
+    for (auto &e : ev_) hip_check(hipEventCreate(&e), "hipEventCreate");
+    inited_ = true;
+}
+
+void *Engine::scratch(size_t idx, size_t bytes) {
+    if (scratch_ptr_.size() <= idx) { scratch_ptr_.resize(idx + 1, nullptr); scratch_size_.resize(idx + 1, 0); }
+    if (scratch_size_[idx] < bytes) {
+        hip_check(hipStreamSynchronize(stream_), "sync before scratch realloc");
+        if (scratch_ptr_[idx]) (void)hipFree(scratch_ptr_[idx]);
+        size_t cap = bytes + bytes / 2 + 4096;
+        hip_check(hipMalloc(&scratch_ptr_[idx], cap), "hipMalloc(scratch)");
+        scratch_size_[idx] = cap;
+    }
+    return scratch_ptr_[idx];
+}
+
+static uint32_t bitrev32(uint32_t x, int bits) {
+    uint32_t r = 0;
+    for (int i = 0; i < bits; ++i) { r = (r << 1) | (x & 1); x >>= 1; }
+    return r;
+}
+
+// twiddles [prime][fwd,inv][N]: psi^{+-brv(i)} * R mod P
+static std::vector<uint32_t> make_twiddles(int N, uint32_t scale_out[2]) {
+    int logn = 0;
+    while ((1 << logn) < N) ++logn;
+    std::vector<uint32_t> tw((size_t)4 * N);
+    for (int q = 0; q < 2; ++q) {
+        const uint64_t P = NTT_P[q];
+        const uint64_t psi = powmod_c(NTT_GEN[q], (P - 1) / (uint64_t)(2 * N), P);
+        const uint64_t ipsi = powmod_c(psi, P - 2, P);
+        const uint64_t R = NTT_R[q];
+        uint64_t a = 1, b = 1;
+        for (int i = 0; i < N; ++i) {
+            const uint32_t j = bitrev32((uint32_t)i, logn);
+            tw[(size_t)(q * 2 + 0) * N + j] = (uint32_t)(a * R % P);
+            tw[(size_t)(q * 2 + 1) * N + j] = (uint32_t)(b * R % P);
+            a = a * psi % P;
+            b = b * ipsi % P;
+        }
+        // image scale: N^-1 (the inverse NTT is unscaled) times R (so that the
+        // Montgomery reduction of sum x*img leaves sum x*bk / N)
+        scale_out[q] = (uint32_t)(powmod_c((uint64_t)N, P - 2, P) * R % P);
+    }
+    return tw;
+}
+
+static DevParams make_dev_params(const Params &p) {
+    DevParams d;
+    d.n = p.n; d.N = p.N; d.k = p.k; d.l = p.l; d.Bgbit = p.Bgbit; d.ks_t = p.ks_t; d.ks_basebit = p.ks_basebit;
+    d.kpl = p.kpl(); d.ct_stride = p.ct_stride(); d.u_stride = p.u_stride();
+    d.decomp_offset = p.decomp_offset(); d.ks_prec_offset = p.ks_prec_offset();
+    d.mu = 1 << 29;
+    return d;
+}
+
+DeviceKeyImage *Engine::upload_key(const TfheHipCloudKey &ck) {
+    ensure_init();
+    const Params &p = ck.p;
+    if (p.N != NTT_N || p.k != 1)
+        fatal("this build's blind-rotate kernel is specialised for N=1024, k=1 (got N=" + std::to_string(p.N) +
+              ", k=" + std::to_string(p.k) + ")");
+    if (p.n > 1024) fatal("n > 1024 unsupported");
+    // exactness of the CRT range: (k+1) l N (Bg/2) 2^31 must stay below P0*P1/2
+    const double bound = (double)(p.k + 1) * p.l * p.N * (double)(1u << (p.Bgbit - 1)) * 2147483648.0;
+    if (bound >= (double)CRT_HALF) fatal("gadget parameters exceed the exact range of the two-prime NTT");
+    // forward NTT input digits must be < P in magnitude; pointwise sum must fit 64 bits
+    auto *img = new DeviceKeyImage();
+    img->dp = make_dev_params(p);
+    uint32_t scale[2];
+    const std::vector<uint32_t> tw = make_twiddles(p.N, scale);
+    hip_check(hipMalloc(reinterpret_cast<void **>(&img->tw), tw.size() * 4), "hipMalloc(tw)");
+    hip_check(hipMemcpy(img->tw, tw.data(), tw.size() * 4, hipMemcpyHostToDevice), "upload twiddles");
+
+    // BK: upload raw, transform on device
+    const size_t bk_words = p.bk_words();
+    int32_t *raw = nullptr;
+    hip_check(hipMalloc(reinterpret_cast<void **>(&raw), bk_words * 4), "hipMalloc(raw bk)");
+    hip_check(hipMemcpy(raw, ck.bk.data(), bk_words * 4, hipMemcpyHostToDevice), "upload bk");
+    hip_check(hipMalloc(reinterpret_cast<void **>(&img->bk_img), bk_words * 2 * 4), "hipMalloc(bk image)");
+    launch_bk_transform(stream_, img->dp, raw, img->bk_img, img->tw, p.n * p.kpl(), p.k + 1, scale);
+    hip_check(hipGetLastError(), "bk_transform launch");
+    hip_check(hipStreamSynchronize(stream_), "bk_transform");
+    (void)hipFree(raw);
+
+    // KSK: drop the all-zero digit-0 rows, pad rows to ct_stride
+    const int base = 1 << p.ks_basebit, stride = p.ct_stride();
+    const size_t rows = (size_t)p.k * p.N * p.ks_t;
+    std::vector<int32_t> compact(rows * (base - 1) * stride, 0);
+    for (size_t r = 0; r < rows; ++r)
+        for (int v = 1; v < base; ++v)
+            std::memcpy(&compact[(r * (base - 1) + (v - 1)) * stride], &ck.ksk[(r * base + v) * (size_t)(p.n + 1)],
+                        (size_t)(p.n + 1) * 4);
+    hip_check(hipMalloc(reinterpret_cast<void **>(&img->ksk), compact.size() * 4), "hipMalloc(ksk)");
+    hip_check(hipMemcpy(img->ksk, compact.data(), compact.size() * 4, hipMemcpyHostToDevice), "upload ksk");
+
+    img->key.bk_img = img->bk_img;
+    img->key.ksk = img->ksk;
+    img->key.tw = img->tw;
+    return img;
+}
+
+void Engine::free_key(DeviceKeyImage *img) {
+    if (!img) return;
+    if (inited_) hip_check(hipStreamSynchronize(stream_), "sync before key free");
+    if (img->bk_img) (void)hipFree(img->bk_img);
+    if (img->ksk) (void)hipFree(img->ksk);
+    if (img->tw) (void)hipFree(img->tw);
+    delete img;
+}
+
+SlotPool *Engine::pool_for(const Params &p) {
+    ensure_init();
+    for (SlotPool *pl : pools_)
+        if (pl->ct_stride() == p.ct_stride() && pl->ct_words() == p.ct_words()) return pl;
+    size_t cap = 1u << 19;   // 524,288 slots = 1.3 GB at n = 630; HBM is 288 GB
+    if (const char *env = std::getenv("TFHE_HIP_POOL_SLOTS")) cap = (size_t)std::atoll(env);
+    auto *pl = new SlotPool(p.ct_words(), p.ct_stride(), cap);
+    // shared read-only slots: trivial 0 (fresh samples), constants -1/8 and +1/8
+    std::vector<Torus32> z(p.n, 0);
+    pl->zero_slot = pl->alloc();
+    write_slot(pl, pl->zero_slot, z.data(), 0);
+    pl->const_slot[0] = pl->alloc();
+    write_slot(pl, pl->const_slot[0], z.data(), -(1 << 29));
+    pl->const_slot[1] = pl->alloc();
+    write_slot(pl, pl->const_slot[1], z.data(), 1 << 29);
+    pools_.push_back(pl);
+    return pl;
+}
+
+void Engine::write_slot(SlotPool *pool, int32_t slot, const Torus32 *a, Torus32 b) {
+    std::vector<int32_t> tmp(pool->ct_stride(), 0);
+    std::memcpy(tmp.data(), a, (size_t)(pool->ct_words() - 1) * 4);
+    tmp[pool->ct_words() - 1] = b;
+    hip_check(hipMemcpy(pool->data() + (size_t)slot * pool->ct_stride(), tmp.data(), tmp.size() * 4, hipMemcpyHostToDevice),
+              "write_slot");
+}
+
+void Engine::read_slot(SlotPool *pool, int32_t slot, Torus32 *a, Torus32 *b) {
+    std::vector<int32_t> tmp(pool->ct_stride());
+    hip_check(hipMemcpy(tmp.data(), pool->data() + (size_t)slot * pool->ct_stride(), tmp.size() * 4, hipMemcpyDeviceToHost),
+              "read_slot");
+    std::memcpy(a, tmp.data(), (size_t)(pool->ct_words() - 1) * 4);
+    *b = tmp[pool->ct_words() - 1];
+}
+
+void Engine::write_slots_packed(SlotPool *pool, const int32_t *slots, int count, const Torus32 *words, bool on_device) {
+    if (count <= 0) return;
+    const size_t wbytes = (size_t)count * pool->ct_words() * 4;
+    int32_t *dslots = static_cast<int32_t *>(scratch(3, (size_t)count * 4));
+    hip_check(hipMemcpyAsync(dslots, slots, (size_t)count * 4, hipMemcpyHostToDevice, stream_), "upload slot list");
+    const int32_t *src = words;
+    if (!on_device) {
+        int32_t *dw = static_cast<int32_t *>(scratch(4, wbytes));
+        hip_check(hipMemcpyAsync(dw, words, wbytes, hipMemcpyHostToDevice, stream_), "upload packed words");
+        src = dw;
+    }
+    launch_scatter_slots(stream_, pool->data(), pool->ct_stride(), pool->ct_words(), dslots, count, src);
+    hip_check(hipStreamSynchronize(stream_), "scatter slots");
+}
+
+void Engine::read_slots_packed(SlotPool *pool, const int32_t *slots, int count, Torus32 *words, bool on_device) {
+    if (count <= 0) return;
+    const size_t wbytes = (size_t)count * pool->ct_words() * 4;
+    int32_t *dslots = static_cast<int32_t *>(scratch(3, (size_t)count * 4));
+    hip_check(hipMemcpyAsync(dslots, slots, (size_t)count * 4, hipMemcpyHostToDevice, stream_), "upload slot list");
+    int32_t *dst = on_device ? words : static_cast<int32_t *>(scratch(4, wbytes));
+    launch_gather_slots(stream_, pool->data(), pool->ct_stride(), pool->ct_words(), dslots, count, dst);
+    if (!on_device) hip_check(hipMemcpyAsync(words, dst, wbytes, hipMemcpyDeviceToHost, stream_), "download packed words");
+    hip_check(hipStreamSynchronize(stream_), "gather slots");
+}
+
+void Engine::execute(const DeviceKeyImage *key, SlotPool *pool, const LevelPlan &plan) {
+    const auto t0 = std::chrono::steady_clock::now();
+    const int levels = (int)plan.rot_off.size() - 1;
+    RotDesc *drots = static_cast<RotDesc *>(scratch(0, plan.rots.size() * sizeof(RotDesc) + 16));
+    KsDesc *dks = static_cast<KsDesc *>(scratch(1, plan.kss.size() * sizeof(KsDesc) + 16));
+    NotDesc *dnots = static_cast<NotDesc *>(scratch(2, plan.nots.size() * sizeof(NotDesc) + 16));
+    int32_t *u_buf = static_cast<int32_t *>(scratch(5, (size_t)(plan.max_rots_per_level + 1) * key->dp.u_stride * 4));
+    if (!plan.rots.empty())
+        hip_check(hipMemcpyAsync(drots, plan.rots.data(), plan.rots.size() * sizeof(RotDesc), hipMemcpyHostToDevice, stream_), "upload rots");
+    if (!plan.kss.empty())
+        hip_check(hipMemcpyAsync(dks, plan.kss.data(), plan.kss.size() * sizeof(KsDesc), hipMemcpyHostToDevice, stream_), "upload ks");
+    if (!plan.nots.empty())
+        hip_check(hipMemcpyAsync(dnots, plan.nots.data(), plan.nots.size() * sizeof(NotDesc), hipMemcpyHostToDevice, stream_), "upload nots");
+
+    // nots of level 0 (inputs already materialised) come first: not_off[0..1]
+    launch_not(stream_, key->dp, dnots + plan.not_off[0], plan.not_off[1] - plan.not_off[0], pool->data());
+    for (int L = 0; L < levels; ++L) {
+        const int nrot = plan.rot_off[L + 1] - plan.rot_off[L];
+        const int nks = plan.ks_off[L + 1] - plan.ks_off[L];
+        const int nnot = plan.not_off[L + 2] - plan.not_off[L + 1];
+        if (kernel_timing) hip_check(hipEventRecord(ev_[0], stream_), "event");
+        launch_blind_rotate(stream_, key->dp, key->key, pool->data(), drots + plan.rot_off[L], nrot, u_buf, nullptr);
+        if (kernel_timing) hip_check(hipEventRecord(ev_[1], stream_), "event");
+        launch_keyswitch(stream_, key->dp, key->key, u_buf, dks + plan.ks_off[L], nks, pool->data());
+        if (kernel_timing) hip_check(hipEventRecord(ev_[2], stream_), "event");
+        launch_not(stream_, key->dp, dnots + plan.not_off[L + 1], nnot, pool->data());
+        if (kernel_timing) {
+            hip_check(hipEventSynchronize(ev_[2]), "event sync");
+            float ms_br = 0, ms_ks = 0;
+            hip_check(hipEventElapsedTime(&ms_br, ev_[0], ev_[1]), "elapsed");
+            hip_check(hipEventElapsedTime(&ms_ks, ev_[1], ev_[2]), "elapsed");
+            stats.ms_blind_rotate += ms_br;
+            stats.ms_keyswitch += ms_ks;
+        }
+        stats.blind_rotates += (uint64_t)nrot;
+        stats.keyswitches += (uint64_t)nks;
+        stats.linear_ops += (uint64_t)nnot;
+        if (nrot) ++stats.br_launches;
+    }
+    stats.linear_ops += (uint64_t)(plan.not_off[1] - plan.not_off[0]);
+    hip_check(hipGetLastError(), "kernel launch");
+    hip_check(hipStreamSynchronize(stream_), "level execution");
+    stats.levels += (uint64_t)levels;
+    ++stats.flushes;
+    stats.ms_flush_wall += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+}
+
+void Engine::run_bootstrap_woks(const DeviceKeyImage *key, const Torus32 *lin, int count, Torus32 *u_out, Torus32 *acc_out) {
+    const DevParams &dp = key->dp;
+    // temporary "pool": count slots holding lin
+    std::vector<int32_t> padded((size_t)count * dp.ct_stride, 0);
+    for (int c = 0; c < count; ++c)
+        std::memcpy(&padded[(size_t)c * dp.ct_stride], lin + (size_t)c * (dp.n + 1), (size_t)(dp.n + 1) * 4);
+    int32_t *dpool = static_cast<int32_t *>(scratch(6, padded.size() * 4));
+    hip_check(hipMemcpyAsync(dpool, padded.data(), padded.size() * 4, hipMemcpyHostToDevice, stream_), "upload lin");
+    std::vector<RotDesc> rots(count);
+    for (int c = 0; c < count; ++c) rots[c] = RotDesc{c, c, 1, 0, 0, c};
+    RotDesc *drots = static_cast<RotDesc *>(scratch(0, rots.size() * sizeof(RotDesc)));
+    hip_check(hipMemcpyAsync(drots, rots.data(), rots.size() * sizeof(RotDesc), hipMemcpyHostToDevice, stream_), "upload rots");
+    int32_t *u_buf = static_cast<int32_t *>(scratch(5, (size_t)count * dp.u_stride * 4));
+    int32_t *dacc = acc_out ? static_cast<int32_t *>(scratch(7, (size_t)count * 2 * dp.N * 4)) : nullptr;
+    launch_blind_rotate(stream_, dp, key->key, dpool, drots, count, u_buf, dacc);
+    hip_check(hipGetLastError(), "blind_rotate launch");
+    std::vector<int32_t> ubuf((size_t)count * dp.u_stride);
+    hip_check(hipMemcpyAsync(ubuf.data(), u_buf, ubuf.size() * 4, hipMemcpyDeviceToHost, stream_), "download u");
+    if (acc_out) hip_check(hipMemcpyAsync(acc_out, dacc, (size_t)count * 2 * dp.N * 4, hipMemcpyDeviceToHost, stream_), "download acc");
+    hip_check(hipStreamSynchronize(stream_), "bootstrap_woks");
+    for (int c = 0; c < count; ++c)
+        std::memcpy(u_out + (size_t)c * (dp.k * dp.N + 1), &ubuf[(size_t)c * dp.u_stride], (size_t)(dp.k * dp.N + 1) * 4);
+    stats.blind_rotates += (uint64_t)count;
+}
+
+void Engine::run_keyswitch(const DeviceKeyImage *key, const Torus32 *u, int count, Torus32 *out) {
+    const DevParams &dp = key->dp;
+    const int uw = dp.k * dp.N + 1;
+    std::vector<int32_t> padded((size_t)count * dp.u_stride, 0);
+    for (int c = 0; c < count; ++c) std::memcpy(&padded[(size_t)c * dp.u_stride], u + (size_t)c * uw, (size_t)uw * 4);
+    int32_t *u_buf = static_cast<int32_t *>(scratch(5, padded.size() * 4));
+    hip_check(hipMemcpyAsync(u_buf, padded.data(), padded.size() * 4, hipMemcpyHostToDevice, stream_), "upload u");
+    std::vector<KsDesc> ks(count);
+    for (int c = 0; c < count; ++c) ks[c] = KsDesc{c, -1, 0, c};
+    KsDesc *dks = static_cast<KsDesc *>(scratch(1, ks.size() * sizeof(KsDesc)));
+    hip_check(hipMemcpyAsync(dks, ks.data(), ks.size() * sizeof(KsDesc), hipMemcpyHostToDevice, stream_), "upload ks");
+    int32_t *dpool = static_cast<int32_t *>(scratch(6, (size_t)count * dp.ct_stride * 4));
+    launch_keyswitch(stream_, dp, key->key, u_buf, dks, count, dpool);
+    hip_check(hipGetLastError(), "keyswitch launch");
+    std::vector<int32_t> res((size_t)count * dp.ct_stride);
+    hip_check(hipMemcpyAsync(res.data(), dpool, res.size() * 4, hipMemcpyDeviceToHost, stream_), "download ks");
+    hip_check(hipStreamSynchronize(stream_), "keyswitch");
+    for (int c = 0; c < count; ++c) std::memcpy(out + (size_t)c * (dp.n + 1), &res[(size_t)c * dp.ct_stride], (size_t)(dp.n + 1) * 4);
+    stats.keyswitches += (uint64_t)count;
+}
+
+void Engine::run_negacyclic(const DeviceKeyImage *key, const int32_t *ip, const Torus32 *tp, Torus32 *res, int count) {
+    const DevParams &dp = key->dp;
+    const size_t words = (size_t)count * dp.N;
+    uint32_t scale[2];
+    (void)make_twiddles(dp.N, scale);
+    int32_t *dtp = static_cast<int32_t *>(scratch(6, words * 4));
+    int32_t *dip = static_cast<int32_t *>(scratch(7, words * 4));
+    uint32_t *dimg = static_cast<uint32_t *>(scratch(8, words * 2 * 4));
+    int32_t *dres = static_cast<int32_t *>(scratch(9, words * 4));
+    hip_check(hipMemcpyAsync(dtp, tp, words * 4, hipMemcpyHostToDevice, stream_), "upload tp");
+    hip_check(hipMemcpyAsync(dip, ip, words * 4, hipMemcpyHostToDevice, stream_), "upload ip");
+    launch_bk_transform(stream_, dp, dtp, dimg, key->tw, count, 1, scale);
+    launch_negacyclic(stream_, dp, key->tw, dip, dimg, dres, count);
+    hip_check(hipGetLastError(), "negacyclic launch");
+    hip_check(hipMemcpyAsync(res, dres, words * 4, hipMemcpyDeviceToHost, stream_), "download res");
+    hip_check(hipStreamSynchronize(stream_), "negacyclic");
+}
+
+}  // namespace tfhe_hip

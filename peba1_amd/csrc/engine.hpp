@@ -1,0 +1,103 @@
+// engine.hpp -- device side of libtfhe-hip: the resident evaluation key, the
+// ciphertext slot pool and batched level execution on one HIP stream.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <cstdint>
+#include <string>
+#include <vector>
+
+#include "host_keys.hpp"
+#include "kernels.hpp"
+#include "../../include/tfhe_hip.h"
+
+// Device image of one cloud key: NTT image of BK, compact KSK, twiddles.
+struct DeviceKeyImage {
+    tfhe_hip::DevParams dp;
+    tfhe_hip::DevKey key;
+    uint32_t *bk_img = nullptr;
+    int32_t *ksk = nullptr;
+    uint32_t *tw = nullptr;
+};
+
+namespace tfhe_hip {
+
+void set_error(const std::string &msg);
+const std::string &last_error_ref();
+[[noreturn]] void fatal(const std::string &msg);
+void hip_check(hipError_t e, const char *what);
+
+// Pool of device-resident ciphertext slots (ct_stride words each).  Slots are
+// immutable once written (the recorder renames every destination), reference
+// counted, and recycled through a free list.
+class SlotPool {
+public:
+    SlotPool(int ct_words, int ct_stride, size_t capacity);
+    ~SlotPool();
+    int32_t alloc();                 // refcount 1, level 0
+    void retain(int32_t s) { ++ref_[s]; }
+    void release(int32_t s);
+    int32_t *data() { return data_; }
+    int ct_stride() const { return stride_; }
+    int ct_words() const { return words_; }
+    size_t capacity() const { return cap_; }
+    size_t in_use() const { return cap_ - free_.size(); }
+    std::vector<int32_t> level;      // pending level of each slot's value, 0 = materialised
+    int32_t zero_slot = -1, const_slot[2] = {-1, -1};
+private:
+    int words_, stride_;
+    size_t cap_;
+    int32_t *data_ = nullptr;
+    std::vector<int32_t> ref_;
+    std::vector<int32_t> free_;
+};
+
+struct LevelPlan {
+    // descriptors of the whole flush, level-major; offsets index into them
+    std::vector<RotDesc> rots;
+    std::vector<KsDesc> kss;
+    std::vector<NotDesc> nots;
+    std::vector<int32_t> rot_off, ks_off, not_off;   // size levels+1 (nots: levels+2, level 0 first)
+    int max_rots_per_level = 0;
+};
+
+class Engine {
+public:
+    static Engine &get();
+    void ensure_init();
+    int device() const { return device_; }
+    void set_device(int d);
+    hipStream_t stream() const { return stream_; }
+
+    DeviceKeyImage *upload_key(const TfheHipCloudKey &ck);
+    void free_key(DeviceKeyImage *img);
+    SlotPool *pool_for(const Params &p);
+
+    void write_slot(SlotPool *pool, int32_t slot, const Torus32 *a, Torus32 b);       // host -> device
+    void read_slot(SlotPool *pool, int32_t slot, Torus32 *a, Torus32 *b);             // device -> host
+    void write_slots_packed(SlotPool *pool, const int32_t *slots, int count, const Torus32 *words, bool words_on_device);
+    void read_slots_packed(SlotPool *pool, const int32_t *slots, int count, Torus32 *words, bool words_on_device);
+
+    // run a levelised plan; synchronises the stream before returning
+    void execute(const DeviceKeyImage *key, SlotPool *pool, const LevelPlan &plan);
+    // raw test paths
+    void run_bootstrap_woks(const DeviceKeyImage *key, const Torus32 *lin, int count, Torus32 *u_out, Torus32 *acc_out);
+    void run_keyswitch(const DeviceKeyImage *key, const Torus32 *u, int count, Torus32 *out);
+    void run_negacyclic(const DeviceKeyImage *key, const int32_t *ip, const Torus32 *tp, Torus32 *res, int count);
+
+    TfheHipStats stats{};
+    bool kernel_timing = false;
+
+private:
+    Engine() = default;
+    void *scratch(size_t idx, size_t bytes);   // grow-only device scratch buffers
+    int device_ = 0;
+    bool inited_ = false;
+    hipStream_t stream_ = nullptr;
+    hipEvent_t ev_[4] = {nullptr, nullptr, nullptr, nullptr};
+    std::vector<SlotPool *> pools_;
+    std::vector<void *> scratch_ptr_;
+    std::vector<size_t> scratch_size_;
+};
+
+}  // namespace tfhe_hip

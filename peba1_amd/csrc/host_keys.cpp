@@ -1,0 +1,163 @@
+// host_keys.cpp -- parameters, PRNG, key generation, encrypt/decrypt on the host.
+//
+// Follows tfhe's new_default_gate_bootstrapping_parameters /
+// new_random_gate_bootstrapping_secret_keyset / bootsSymEncrypt /
+// bootsSymDecrypt as described in SURVEY.md Appendix A.1-A.2 (the library
+// itself is not in /root/reference; the reference calls these at
+// src/main.cpp:21-22,63-69,78-83).  Randomness comes from this repo's own
+// seeded generator; the draw order is specified in DESIGN.md and is what the
+// test oracle regenerates independently.
+#include "host_keys.hpp"
+
+#include <cmath>
+#include <cstring>
+
+namespace tfhe_hip {
+
+uint32_t Params::decomp_offset() const {
+    uint32_t off = 0;
+    const uint32_t half = 1u << (Bgbit - 1);
+    for (int j = 1; j <= l; ++j) off += half << (32 - j * Bgbit);
+    return off;
+}
+
+bool default_params(int32_t lambda, Params &o) {
+    if (lambda <= 0 || lambda > 128) return false;
+    o.N = 1024; o.k = 1; o.ks_t = 8; o.ks_basebit = 2; o.max_stdev = 0.012467;
+    if (lambda > 80) {
+        o.n = 630; o.l = 3; o.Bgbit = 7;
+        o.ks_stdev = std::ldexp(1.0, -15);
+        o.bk_stdev = std::ldexp(1.0, -25);
+    } else {
+        o.n = 500; o.l = 2; o.Bgbit = 10;
+        o.ks_stdev = 2.44e-5; o.bk_stdev = 7.18e-9;
+    }
+    return true;
+}
+
+Params p2048_params() {
+    Params o;
+    o.N = 2048; o.k = 1; o.n = 1024; o.l = 3; o.Bgbit = 6; o.ks_t = 8; o.ks_basebit = 2;
+    o.ks_stdev = std::ldexp(1.0, -15);
+    o.bk_stdev = std::ldexp(1.0, -25);
+    o.max_stdev = 0.012467;
+    return o;
+}
+
+ParamBundle *make_param_bundle(const Params &p) {
+    ParamBundle *b = new ParamBundle();
+    b->p = p;
+    b->lwe = LweParams{p.n, p.ks_stdev, p.max_stdev};
+    b->tlwe = TLweParams{p.N, p.k, p.bk_stdev, p.max_stdev};
+    b->tgsw.l = p.l; b->tgsw.Bgbit = p.Bgbit; b->tgsw.Bg = 1 << p.Bgbit; b->tgsw.halfBg = 1 << (p.Bgbit - 1);
+    b->tgsw.maskMod = (1u << p.Bgbit) - 1u;
+    b->tgsw.tlwe_params = &b->tlwe;
+    b->tgsw.kpl = p.kpl();
+    b->tgsw.offset = p.decomp_offset();
+    b->set.ks_t = p.ks_t; b->set.ks_basebit = p.ks_basebit;
+    b->set.in_out_params = &b->lwe;
+    b->set.tgsw_params = &b->tgsw;
+    return b;
+}
+
+const Params &params_of(const TFheGateBootstrappingParameterSet *set) {
+    // `set` is the first member of the bundle it was allocated in
+    return reinterpret_cast<const ParamBundle *>(set)->p;
+}
+
+static inline uint64_t rotl(uint64_t x, int k) { return (x << k) | (x >> (64 - k)); }
+
+void Rng::reseed(uint64_t seed) {
+    uint64_t z = seed;
+    for (auto &word : s_) {
+        z += 0x9E3779B97F4A7C15ULL;
+        uint64_t t = z;
+        t = (t ^ (t >> 30)) * 0xBF58476D1CE4E5B9ULL;
+        t = (t ^ (t >> 27)) * 0x94D049BB133111EBULL;
+        word = t ^ (t >> 31);
+    }
+}
+
+uint64_t Rng::next() {
+    const uint64_t result = rotl(s_[1] * 5, 7) * 9;
+    const uint64_t t = s_[1] << 17;
+    s_[2] ^= s_[0]; s_[3] ^= s_[1]; s_[1] ^= s_[2]; s_[0] ^= s_[3];
+    s_[2] ^= t;
+    s_[3] = rotl(s_[3], 45);
+    return result;
+}
+
+double Rng::gauss(double sigma) {
+    const double u1 = ((double)(next() >> 11) + 1.0) * (1.0 / 9007199254740992.0);
+    const double u2 = (double)(next() >> 11) * (1.0 / 9007199254740992.0);
+    return sigma * std::sqrt(-2.0 * std::log(u1)) * std::cos(6.283185307179586476925286766559 * u2);
+}
+
+Torus32 dtot32(double d) { return (Torus32)(int64_t)((d - (double)(int64_t)d) * 4294967296.0); }
+
+// body += mask * key  in Z[X]/(X^N+1), key binary
+static void add_mul_by_bits(uint32_t *body, const uint32_t *mask, const int32_t *bits, int N) {
+    for (int i = 0; i < N; ++i) {
+        if (!bits[i]) continue;
+        for (int j = 0; j < N - i; ++j) body[i + j] += mask[j];
+        for (int j = N - i; j < N; ++j) body[i + j - N] -= mask[j];
+    }
+}
+
+void generate_keys(const Params &p, uint64_t seed, TfheHipSecretKey &sk, TfheHipCloudKey &ck) {
+    Rng rng(seed);
+    const int n = p.n, N = p.N, k = p.k, l = p.l, kpl = p.kpl(), t = p.ks_t, base = 1 << p.ks_basebit;
+    sk.p = p; ck.p = p;
+    sk.lwe_key.resize(n);
+    for (auto &b : sk.lwe_key) b = rng.bit();
+    sk.tlwe_key.resize((size_t)k * N);
+    for (auto &b : sk.tlwe_key) b = rng.bit();
+
+    // bootstrapping key: BK_i = TGSW_{tlwe_key}(lwe_key[i])
+    ck.bk.assign(p.bk_words(), 0);
+    for (int i = 0; i < n; ++i)
+        for (int row = 0; row < kpl; ++row) {
+            uint32_t *smp = reinterpret_cast<uint32_t *>(ck.bk.data()) + ((size_t)i * kpl + row) * (size_t)(k + 1) * N;
+            uint32_t *body = smp + (size_t)k * N;
+            for (int u = 0; u < k; ++u)
+                for (int j = 0; j < N; ++j) smp[(size_t)u * N + j] = (uint32_t)rng.torus();
+            for (int j = 0; j < N; ++j) body[j] = (uint32_t)dtot32(rng.gauss(p.bk_stdev));
+            for (int u = 0; u < k; ++u) add_mul_by_bits(body, smp + (size_t)u * N, sk.tlwe_key.data() + (size_t)u * N, N);
+            const int bloc = row / l, jj = row % l;
+            smp[(size_t)bloc * N] += (uint32_t)sk.lwe_key[i] << (32 - (jj + 1) * p.Bgbit);
+        }
+
+    // key-switching key: extracted TLWE key (kN bits) -> LWE key
+    ck.ksk.assign(p.ksk_words(), 0);
+    for (int i = 0; i < k * N; ++i)
+        for (int j = 0; j < t; ++j)
+            for (int v = 1; v < base; ++v) {
+                uint32_t *row = reinterpret_cast<uint32_t *>(ck.ksk.data()) + (((size_t)i * t + j) * base + v) * (size_t)(n + 1);
+                uint32_t b = 0;
+                for (int q = 0; q < n; ++q) {
+                    row[q] = (uint32_t)rng.torus();
+                    b += row[q] * (uint32_t)sk.lwe_key[q];
+                }
+                b += (uint32_t)(sk.tlwe_key[i] * v) << (32 - (j + 1) * p.ks_basebit);
+                b += (uint32_t)dtot32(rng.gauss(p.ks_stdev));
+                row[n] = b;
+            }
+}
+
+void encrypt_bit(const TfheHipSecretKey &sk, Rng &rng, int32_t message, Torus32 *a, Torus32 *b) {
+    const uint32_t mu = message ? (1u << 29) : 0u - (1u << 29);
+    uint32_t body = mu + (uint32_t)dtot32(rng.gauss(sk.p.ks_stdev));
+    for (int i = 0; i < sk.p.n; ++i) {
+        a[i] = rng.torus();
+        body += (uint32_t)a[i] * (uint32_t)sk.lwe_key[i];
+    }
+    *b = (Torus32)body;
+}
+
+Torus32 phase_of(const TfheHipSecretKey &sk, const Torus32 *a, Torus32 b) {
+    uint32_t ph = (uint32_t)b;
+    for (int i = 0; i < sk.p.n; ++i) ph -= (uint32_t)a[i] * (uint32_t)sk.lwe_key[i];
+    return (Torus32)ph;
+}
+
+}  // namespace tfhe_hip

@@ -1,0 +1,75 @@
+// host_keys.hpp -- host-side key material, parameters and the deterministic
+// PRNG of libtfhe-hip.  Key generation, encryption and decryption run on the
+// CPU (they are off the timed path); only the
+// evaluation keys are uploaded to the device.
+#pragma once
+#include <cstddef>
+#include <cstdint>
+#include <vector>
+
+#include "../../include/tfhe/tfhe_core.h"
+
+namespace tfhe_hip {
+
+struct Params {
+    int32_t n, N, k, l, Bgbit, ks_t, ks_basebit;
+    double ks_stdev, bk_stdev, max_stdev;
+    int32_t kpl() const { return (k + 1) * l; }
+    int32_t ct_words() const { return n + 1; }
+    int32_t ct_stride() const { return (n + 1 + 3) & ~3; }
+    int32_t u_stride() const { return (k * N + 1 + 3) & ~3; }
+    uint32_t decomp_offset() const;
+    uint32_t ks_prec_offset() const { return 1u << (32 - (1 + ks_basebit * ks_t)); }
+    size_t bk_words() const { return (size_t)n * kpl() * (k + 1) * N; }
+    size_t ksk_words() const { return (size_t)k * N * ks_t * (size_t)(1 << ks_basebit) * (n + 1); }
+};
+
+// The C structs behind a TFheGateBootstrappingParameterSet allocated by this library.
+struct ParamBundle {
+    TFheGateBootstrappingParameterSet set;
+    LweParams lwe;
+    TLweParams tlwe;
+    TGswParams tgsw;
+    Params p;
+};
+ParamBundle *make_param_bundle(const Params &p);
+const Params &params_of(const TFheGateBootstrappingParameterSet *set);
+bool default_params(int32_t minimum_lambda, Params &out);
+Params p2048_params();
+
+// xoshiro256** seeded through splitmix64 (DESIGN.md "key derivation")
+class Rng {
+public:
+    explicit Rng(uint64_t seed = 0) { reseed(seed); }
+    void reseed(uint64_t seed);
+    uint64_t next();
+    Torus32 torus() { return (Torus32)(uint32_t)(next() >> 32); }
+    int32_t bit() { return (int32_t)(next() >> 63); }
+    double gauss(double sigma);
+private:
+    uint64_t s_[4];
+};
+Torus32 dtot32(double d);
+
+}  // namespace tfhe_hip
+
+struct DeviceKeyImage;   // engine.hpp
+
+// Secret and cloud key material (names match the opaque pointers in tfhe_core.h)
+struct TfheHipSecretKey {
+    tfhe_hip::Params p;
+    std::vector<int32_t> lwe_key;    // [n]
+    std::vector<int32_t> tlwe_key;   // [k][N]
+};
+struct TfheHipCloudKey {
+    tfhe_hip::Params p;
+    std::vector<Torus32> bk;         // [n][(k+1)l][k+1][N]
+    std::vector<Torus32> ksk;        // [kN][t][base][n+1]
+    DeviceKeyImage *dev = nullptr;   // null for host-only keysets
+};
+
+namespace tfhe_hip {
+void generate_keys(const Params &p, uint64_t seed, TfheHipSecretKey &sk, TfheHipCloudKey &ck);
+void encrypt_bit(const TfheHipSecretKey &sk, Rng &rng, int32_t message, Torus32 *a, Torus32 *b);
+Torus32 phase_of(const TfheHipSecretKey &sk, const Torus32 *a, Torus32 b);
+}  // namespace tfhe_hip

@@ -1,0 +1,375 @@
+// kernels.hip -- hand-written gfx950 kernels of the bootstrapped-gate path.
+//
+//   K6 bk_transform_kernel   Torus32 bootstrapping key -> NTT image (once per key)
+//   K1+K2 blind_rotate_kernel  gate prelude, modulus switch, blind rotate
+//                              (n external products), sample extract
+//   K3/K4 keyswitch_kernel   (u0 [+ u1] + const) -> LWE sample under the gate key
+//   K5 not_kernel            negation
+//
+// Restates (does not translate) tfhe's tfhe_bootstrap_woKS_FFT / tfhe_blindRotate_FFT
+// / tGswFFTExternMulToTLwe / lweKeySwitch as described in SURVEY.md Appendix A.3;
+// reference call sites: /root/reference/src/Math.cpp:34-43 (every bootsXOR/bootsAND).
+//
+// Mapping (N = 1024, k = 1): one workgroup of two wave64 per blind rotation, wave
+// q does all arithmetic modulo prime q.  The accumulator (2 x 1024 Torus32) lives
+// in LDS for the whole n-step loop; per step a wave reads the rotated
+// accumulator, extracts gadget digits, runs 6 forward NTTs (ntt_wave.hpp),
+// multiply-accumulates against the streamed key image in 64-bit
+// (v_mad_u64_u32), runs 2 inverse NTTs, swaps one residue polynomial with its
+// partner wave and CRT-recombines the polynomial it owns.  Two workgroup
+// barriers per step.  The key image is read with 16-byte-per-lane coalesced
+// loads (1 KiB per wave instruction), 48 KiB per wave per step.
+#include "kernels.hpp"
+#include "ntt_wave.hpp"
+
+namespace tfhe_hip {
+
+namespace {
+
+__device__ __forceinline__ PrimeCtx make_ctx(int q, const uint32_t *tw) {
+    PrimeCtx c;
+    c.P = q ? NTT_P1 : NTT_P0;
+    c.pinv = q ? NTT_PINV1 : NTT_PINV0;
+    c.P2 = 2u * c.P;
+    c.wf = tw + (size_t)(q * 2 + 0) * NTT_N;
+    c.wi = tw + (size_t)(q * 2 + 1) * NTT_N;
+    return c;
+}
+
+// acc64 (sum of <= 6 products x*bk, x < 21P, bk < P) -> canonical-range input of
+// the inverse NTT, the inverse NTT itself, and the final canonical residue
+__device__ __forceinline__ void finish_inverse(const uint64_t (&acc)[16], uint32_t (&y)[16],
+                                               const PrimeCtx &c, uint32_t *scr, int lane) {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        uint32_t t = mont_redc(acc[r], c.P, c.pinv);   // < 5P
+        t = csub(t, 2u * c.P2);                        // < 4P
+        y[r] = csub(t, c.P2);                          // < 2P
+    }
+    ntt_inv_1024(y, c, scr, lane);
+#pragma unroll
+    for (int r = 0; r < 16; ++r) y[r] = csub(y[r], c.P);
+}
+
+// ---------------------------------------------------------------------------
+// K6: Torus32 polynomials -> NTT image.  grid (npoly, 2 primes), one wave each.
+// raw layout [X][w][N]; image layout [X][q][w][N] with word (g*256 + lane*4 + e)
+// holding register 4g+e of `lane` in layout L2, i.e. exactly what a lane of the
+// blind-rotate kernel fetches with one 16-byte load.
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(64) void bk_transform_kernel(const int32_t *__restrict__ raw, uint32_t *__restrict__ img,
+                                                          const uint32_t *__restrict__ tw, int nw,
+                                                          uint32_t scale0, uint32_t scale1) {
+    __shared__ __align__(16) uint32_t scr[NTT_SCRATCH_WORDS];
+    const int lane = threadIdx.x;
+    const int q = blockIdx.y;
+    const int poly = blockIdx.x;          // X*nw + w
+    const int X = poly / nw, w = poly % nw;
+    const PrimeCtx c = make_ctx(q, tw);
+    const uint32_t scale = q ? scale1 : scale0;
+    const int32_t *src = raw + (size_t)poly * NTT_N;
+    uint32_t x[16];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        int32_t m = src[r * 64 + lane] % (int32_t)c.P;
+        if (m < 0) m += (int32_t)c.P;
+        x[r] = (uint32_t)m;
+    }
+    ntt_fwd_1024(x, c, scr, lane);
+    uint4 *dst = reinterpret_cast<uint4 *>(img + ((size_t)(X * 2 + q) * nw + w) * NTT_N) + lane;
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+        uint32_t v[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] = (uint32_t)((uint64_t)(x[4 * g + e] % c.P) * scale % c.P);
+        dst[g * 64] = make_uint4(v[0], v[1], v[2], v[3]);
+    }
+}
+
+// ---------------------------------------------------------------------------
+// test kernel: res = ip * tp (negacyclic, mod 2^32), tp given as image
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(128) void negacyclic_kernel(const int32_t *__restrict__ ip, const uint32_t *__restrict__ img,
+                                                         const uint32_t *__restrict__ tw, int32_t *__restrict__ res) {
+    __shared__ __align__(16) uint32_t lds_scr[2][NTT_SCRATCH_WORDS];
+    const int tid = threadIdx.x;
+    const int q = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int lane = tid & 63;
+    const PrimeCtx c = make_ctx(q, tw);
+    uint32_t *scr = lds_scr[q];
+    const int32_t *src = ip + (size_t)blockIdx.x * NTT_N;
+    uint32_t x[16];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const int32_t v = src[r * 64 + lane];
+        x[r] = v < 0 ? (uint32_t)(v + (int32_t)c.P) : (uint32_t)v;
+    }
+    ntt_fwd_1024(x, c, scr, lane);
+    const uint4 *bp = reinterpret_cast<const uint4 *>(img + (size_t)(blockIdx.x * 2 + q) * NTT_N) + lane;
+    uint64_t acc[16];
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+        const uint4 b = bp[g * 64];
+        acc[4 * g + 0] = (uint64_t)x[4 * g + 0] * b.x;
+        acc[4 * g + 1] = (uint64_t)x[4 * g + 1] * b.y;
+        acc[4 * g + 2] = (uint64_t)x[4 * g + 2] * b.z;
+        acc[4 * g + 3] = (uint64_t)x[4 * g + 3] * b.w;
+    }
+    uint32_t y[16];
+    finish_inverse(acc, y, c, scr, lane);
+#pragma unroll
+    for (int r = 0; r < 16; ++r) scr[r * 64 + lane] = y[r];
+    __syncthreads();
+    if (q == 0) {
+        const uint32_t *oscr = lds_scr[1];
+#pragma unroll
+        for (int r = 0; r < 16; ++r)
+            res[(size_t)blockIdx.x * NTT_N + r * 64 + lane] = (int32_t)crt_to_torus(y[r], oscr[r * 64 + lane]);
+    }
+}
+
+// ---------------------------------------------------------------------------
+// K1+K2: blind rotate.  grid = rotations, 128 threads.
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(128) void blind_rotate_kernel(DevParams p, DevKey key, const int32_t *__restrict__ pool,
+                                                           const RotDesc *__restrict__ rots,
+                                                           int32_t *__restrict__ u_buf, int32_t *__restrict__ acc_dbg) {
+    __shared__ __align__(16) uint32_t lds_acc[2][NTT_N];
+    __shared__ __align__(16) uint32_t lds_scr[2][NTT_SCRATCH_WORDS];
+    __shared__ uint16_t lds_bar[NTT_N + 8];
+
+    const int tid = threadIdx.x;
+    const int q = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int lane = tid & 63;
+    const PrimeCtx c = make_ctx(q, key.tw);
+    uint32_t *scr = lds_scr[q];
+    const RotDesc rd = rots[blockIdx.x];
+    const int n = p.n;
+
+    // K1: t = (0,c0) + sa*A + sb*B, modulus switch to Z_{2N} (tfhe modSwitchFromTorus32)
+    {
+        const int32_t *A = pool + (size_t)rd.slot_a * p.ct_stride;
+        const int32_t *B = pool + (size_t)rd.slot_b * p.ct_stride;
+        for (int i = tid; i <= n; i += 128) {
+            uint32_t t = (uint32_t)rd.sa * (uint32_t)A[i] + (uint32_t)rd.sb * (uint32_t)B[i];
+            if (i == n) t += (uint32_t)rd.c0;
+            lds_bar[i] = (uint16_t)((t + (1u << 20)) >> 21);     // round(t * 2N / 2^32) mod 2N, N = 1024
+        }
+    }
+    __syncthreads();
+    {   // ACC = (0, X^{-barb} * (mu + mu X + ... + mu X^{N-1}))
+        const int barb = lds_bar[n];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int j = r * 64 + lane;
+            const int idx = (j + barb) & (2 * NTT_N - 1);
+            lds_acc[q][j] = q == 0 ? 0u : ((idx & NTT_N) ? (uint32_t)(-p.mu) : (uint32_t)p.mu);
+        }
+    }
+    __syncthreads();
+
+    const uint32_t dmask = (1u << p.Bgbit) - 1u;
+    const uint32_t dbias = c.P - (1u << (p.Bgbit - 1));   // P - Bg/2
+    const int kpl = p.kpl;
+
+    for (int i = 0; i < n; ++i) {
+        const int abar = __builtin_amdgcn_readfirstlane((int)lds_bar[i]);
+        if (abar == 0) continue;                            // tfhe_blindRotate_FFT skips these too
+
+        uint64_t acc0[16], acc1[16];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { acc0[r] = 0; acc1[r] = 0; }
+
+#pragma unroll 1
+        for (int u = 0; u < 2; ++u) {
+            // D = (X^abar - 1) * ACC_u, with the decomposition offset pre-added
+            uint32_t D[16];
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int j = r * 64 + lane;
+                const int idx = (j - abar) & (2 * NTT_N - 1);
+                const uint32_t v = lds_acc[u][idx & (NTT_N - 1)];
+                D[r] = ((idx & NTT_N) ? 0u - v : v) - lds_acc[u][j] + p.decomp_offset;
+            }
+#pragma unroll 1
+            for (int jj = 0; jj < p.l; ++jj) {
+                const int prow = u * p.l + jj;
+                const uint4 *bp = reinterpret_cast<const uint4 *>(
+                                      key.bk_img + ((size_t)((size_t)i * kpl + prow) * 2 + q) * 2 * NTT_N) + lane;
+                uint4 b0[4], b1[4];
+#pragma unroll
+                for (int g = 0; g < 4; ++g) { b0[g] = bp[g * 64]; b1[g] = bp[256 + g * 64]; }
+
+                const int shift = 32 - (jj + 1) * p.Bgbit;
+                uint32_t x[16];
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const uint32_t xx = ((D[r] >> shift) & dmask) + dbias;   // digit + P
+                    x[r] = min(xx, xx - c.P);                               // digit mod P
+                }
+                ntt_fwd_1024(x, c, scr, lane);
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    acc0[4 * g + 0] += (uint64_t)x[4 * g + 0] * b0[g].x;
+                    acc0[4 * g + 1] += (uint64_t)x[4 * g + 1] * b0[g].y;
+                    acc0[4 * g + 2] += (uint64_t)x[4 * g + 2] * b0[g].z;
+                    acc0[4 * g + 3] += (uint64_t)x[4 * g + 3] * b0[g].w;
+                    acc1[4 * g + 0] += (uint64_t)x[4 * g + 0] * b1[g].x;
+                    acc1[4 * g + 1] += (uint64_t)x[4 * g + 1] * b1[g].y;
+                    acc1[4 * g + 2] += (uint64_t)x[4 * g + 2] * b1[g].z;
+                    acc1[4 * g + 3] += (uint64_t)x[4 * g + 3] * b1[g].w;
+                }
+            }
+        }
+
+        uint32_t y0[16], y1[16];
+        finish_inverse(acc0, y0, c, scr, lane);
+        finish_inverse(acc1, y1, c, scr, lane);
+
+        // wave q owns output polynomial q: send the other one's residues across
+#pragma unroll
+        for (int r = 0; r < 16; ++r) scr[r * 64 + lane] = q == 0 ? y1[r] : y0[r];
+        __syncthreads();
+        {
+            const uint32_t *oscr = lds_scr[1 - q];
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const uint32_t other = oscr[r * 64 + lane];
+                const uint32_t r0 = q == 0 ? y0[r] : other;
+                const uint32_t r1 = q == 0 ? other : y1[r];
+                lds_acc[q][r * 64 + lane] += crt_to_torus(r0, r1);
+            }
+        }
+        __syncthreads();
+    }
+
+    // sample extract at index 0 (tfhe tLweExtractLweSampleIndex)
+    int32_t *u = u_buf + (size_t)rd.u_index * p.u_stride;
+    for (int j = tid; j < NTT_N; j += 128)
+        u[j] = (int32_t)(j == 0 ? lds_acc[0][0] : 0u - lds_acc[0][NTT_N - j]);
+    if (tid == 0) u[NTT_N] = (int32_t)lds_acc[1][0];
+    if (acc_dbg) {
+        int32_t *d = acc_dbg + (size_t)blockIdx.x * 2 * NTT_N;
+        for (int j = tid; j < 2 * NTT_N; j += 128) d[j] = (int32_t)lds_acc[j >> 10][j & (NTT_N - 1)];
+    }
+}
+
+// ---------------------------------------------------------------------------
+// K3/K4: key switch (tfhe lweKeySwitchTranslate_fromArray).  grid = gates.
+// One workgroup per gate; thread t owns 4 consecutive output words and
+// subtracts the selected KSK rows with 16-byte loads.
+// ---------------------------------------------------------------------------
+constexpr int KS_THREADS = 192;
+
+__global__ __launch_bounds__(KS_THREADS) void keyswitch_kernel(DevParams p, DevKey key, const int32_t *__restrict__ u_buf,
+                                                               const KsDesc *__restrict__ descs,
+                                                               int32_t *__restrict__ pool) {
+    __shared__ uint32_t su[2048 + 8];
+    const int tid = threadIdx.x;
+    const KsDesc d = descs[blockIdx.x];
+    const int nin = p.k * p.N;
+    {
+        const int32_t *u0 = u_buf + (size_t)d.u0 * p.u_stride;
+        const int32_t *u1 = d.u1 >= 0 ? u_buf + (size_t)d.u1 * p.u_stride : nullptr;
+        for (int j = tid; j <= nin; j += KS_THREADS) {
+            uint32_t v = (uint32_t)u0[j];
+            if (u1) v += (uint32_t)u1[j];
+            if (j == nin) v += (uint32_t)d.add_b;
+            su[j] = v;
+        }
+    }
+    __syncthreads();
+    const int nvec = p.ct_stride >> 2;
+    if (tid >= nvec) return;
+    const int t = p.ks_t, bb = p.ks_basebit;
+    const uint32_t mask = (1u << bb) - 1u;
+    const size_t row_vecs = (size_t)nvec;
+    const uint4 *ksk = reinterpret_cast<const uint4 *>(key.ksk) + tid;
+    uint4 acc = make_uint4(0, 0, 0, 0);
+    for (int i = 0; i < nin; ++i) {
+        const uint32_t aibar = su[i] + p.ks_prec_offset;
+        for (int j = 0; j < t; ++j) {
+            const uint32_t aij = (aibar >> (32 - (j + 1) * bb)) & mask;
+            if (aij == 0) continue;
+            const uint4 row = ksk[((size_t)(i * t + j) * mask + (aij - 1)) * row_vecs];
+            acc.x -= row.x; acc.y -= row.y; acc.z -= row.z; acc.w -= row.w;
+        }
+    }
+    uint32_t o[4] = {acc.x, acc.y, acc.z, acc.w};
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        const int wi = 4 * tid + e;
+        if (wi == p.n) o[e] += su[nin];
+        if (wi > p.n) o[e] = 0;
+    }
+    reinterpret_cast<uint4 *>(pool + (size_t)d.dst_slot * p.ct_stride)[tid] = make_uint4(o[0], o[1], o[2], o[3]);
+}
+
+// K5: bootsNOT
+__global__ __launch_bounds__(256) void not_kernel(DevParams p, const NotDesc *__restrict__ descs, int32_t *__restrict__ pool) {
+    const NotDesc d = descs[blockIdx.x];
+    const int32_t *src = pool + (size_t)d.src_slot * p.ct_stride;
+    int32_t *dst = pool + (size_t)d.dst_slot * p.ct_stride;
+    for (int i = threadIdx.x; i < p.ct_stride; i += 256) dst[i] = (int32_t)(0u - (uint32_t)src[i]);
+}
+
+// packed words <-> pool slots (import/export of ciphertexts, collectives)
+__global__ __launch_bounds__(256) void gather_slots_kernel(const int32_t *__restrict__ pool, int stride, int words,
+                                                           const int32_t *__restrict__ slots, int32_t *__restrict__ packed) {
+    const int32_t *src = pool + (size_t)slots[blockIdx.x] * stride;
+    int32_t *dst = packed + (size_t)blockIdx.x * words;
+    for (int i = threadIdx.x; i < words; i += 256) dst[i] = src[i];
+}
+__global__ __launch_bounds__(256) void scatter_slots_kernel(int32_t *__restrict__ pool, int stride, int words,
+                                                            const int32_t *__restrict__ slots, const int32_t *__restrict__ packed) {
+    int32_t *dst = pool + (size_t)slots[blockIdx.x] * stride;
+    const int32_t *src = packed + (size_t)blockIdx.x * words;
+    for (int i = threadIdx.x; i < stride; i += 256) dst[i] = i < words ? src[i] : 0;
+}
+
+}  // namespace
+
+void launch_gather_slots(hipStream_t s, const int32_t *pool, int stride, int words, const int32_t *slots, int count,
+                         int32_t *packed) {
+    if (count <= 0) return;
+    hipLaunchKernelGGL(gather_slots_kernel, dim3(count), dim3(256), 0, s, pool, stride, words, slots, packed);
+}
+void launch_scatter_slots(hipStream_t s, int32_t *pool, int stride, int words, const int32_t *slots, int count,
+                          const int32_t *packed) {
+    if (count <= 0) return;
+    hipLaunchKernelGGL(scatter_slots_kernel, dim3(count), dim3(256), 0, s, pool, stride, words, slots, packed);
+}
+
+void launch_bk_transform(hipStream_t s, const DevParams &p, const int32_t *raw_polys, uint32_t *img,
+                         const uint32_t *tw, int npoly_per_w, int nw, const uint32_t scale[2]) {
+    (void)p;
+    if (npoly_per_w * nw <= 0) return;
+    hipLaunchKernelGGL(bk_transform_kernel, dim3(npoly_per_w * nw, 2), dim3(64), 0, s, raw_polys, img, tw, nw,
+                       scale[0], scale[1]);
+}
+
+void launch_blind_rotate(hipStream_t s, const DevParams &p, const DevKey &key, const int32_t *pool,
+                         const RotDesc *rots, int count, int32_t *u_buf, int32_t *acc_dbg) {
+    if (count <= 0) return;
+    hipLaunchKernelGGL(blind_rotate_kernel, dim3(count), dim3(128), 0, s, p, key, pool, rots, u_buf, acc_dbg);
+}
+
+void launch_keyswitch(hipStream_t s, const DevParams &p, const DevKey &key, const int32_t *u_buf,
+                      const KsDesc *descs, int count, int32_t *pool) {
+    if (count <= 0) return;
+    hipLaunchKernelGGL(keyswitch_kernel, dim3(count), dim3(KS_THREADS), 0, s, p, key, u_buf, descs, pool);
+}
+
+void launch_not(hipStream_t s, const DevParams &p, const NotDesc *descs, int count, int32_t *pool) {
+    if (count <= 0) return;
+    hipLaunchKernelGGL(not_kernel, dim3(count), dim3(256), 0, s, p, descs, pool);
+}
+
+void launch_negacyclic(hipStream_t s, const DevParams &p, const uint32_t *tw, const int32_t *ip,
+                       const uint32_t *img, int32_t *res, int count) {
+    (void)p;
+    if (count <= 0) return;
+    hipLaunchKernelGGL(negacyclic_kernel, dim3(count), dim3(128), 0, s, ip, img, tw, res);
+}
+
+}  // namespace tfhe_hip

@@ -1,0 +1,597 @@
+// shim.cpp -- the C ABI of libtfhe-hip: the tfhe boots* surface that
+// /root/reference/src/Math.cpp and src/main.cpp bind plus the
+// tfhe_hip_* extensions.  Host logic only: allocation, the SSA recorder,
+// levelisation and hand-off to the engine.  No gate arithmetic happens here.
+//
+// Recorder model.  Every ciphertext value lives in an immutable device slot.
+// A boots* call allocates a fresh destination slot, records an operation that
+// reads its operands' CURRENT slots, and re-points the destination handle to
+// the new slot (SSA renaming).  That makes the reference's patterns safe under
+// deferral: result aliasing an input (Math.cpp:272), a temporary overwritten
+// four times (Math.cpp:34-42), temporaries freed right after use
+// (Math.cpp:47-49).  The level of an operation is 1 + the maximum level of its
+// operand slots; a flush executes level 1, 2, ... as batched kernel launches.
+// bootsCOPY and bootsCONSTANT only re-point handles (no data moves).
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <mutex>
+#include <new>
+#include <string>
+#include <vector>
+
+#include "engine.hpp"
+#include "../../include/tfhe/tfhe.h"
+
+using namespace tfhe_hip;
+
+namespace tfhe_hip {
+const std::string &last_error_ref();
+}
+
+namespace {
+
+constexpr uint32_t ARRAY_MAGIC = 0x7F4E11A5u;
+constexpr int32_t SLOT_HOST = -1;   // value lives in the host mirror
+constexpr int32_t SLOT_ZERO = -2;   // fresh sample: trivial encryption of phase 0
+
+// Hidden header in front of every LweSample array handed to the caller.
+struct alignas(16) ArrayHeader {
+    uint32_t magic;
+    int32_t count;
+    int32_t n;
+    int32_t pad;
+    SlotPool *pool;     // set when the first element moves to the device
+    void *reserved;
+};
+
+ArrayHeader *header_of(LweSample *samples) {
+    auto *h = reinterpret_cast<ArrayHeader *>(reinterpret_cast<char *>(samples) - sizeof(ArrayHeader));
+    if (h->magic != ARRAY_MAGIC) fatal("LweSample array was not allocated by new_gate_bootstrapping_ciphertext_array");
+    return h;
+}
+
+struct PendingOp {
+    uint8_t kind;       // 0..9 two-input gate code, 16 MUX, 17 NOT
+    int32_t dst, a, b, c;
+    int32_t level;
+};
+constexpr uint8_t OP_MUX = 16, OP_NOT = 17;
+
+// prelude constants of the two-input gates: (c0 in eighths, sa, sb), tfhe boot-gates.cpp
+struct GateLin { int32_t c8, sa, sb; };
+const GateLin GATE_LIN[10] = {
+    {1, -1, -1}, {1, 1, 1}, {-1, 1, 1}, {-1, -1, -1}, {2, 2, 2}, {-2, -2, -2},
+    {-1, -1, 1}, {-1, 1, -1}, {1, -1, 1}, {1, 1, -1},
+};
+
+struct Recorder {
+    std::recursive_mutex mtx;
+    bool deferred = false;
+    const TFheGateBootstrappingCloudKeySet *key = nullptr;   // key of the pending operations
+    SlotPool *pool = nullptr;
+    std::vector<PendingOp> ops;
+    int32_t max_level = 0;
+    Rng enc_rng{0x5EBA1};
+    uint64_t keygen_counter = 0;
+};
+Recorder &rec() {
+    static Recorder r;
+    static bool init = [] {
+        if (const char *e = std::getenv("TFHE_HIP_DEFERRED")) r.deferred = std::atoi(e) != 0;
+        return true;
+    }();
+    (void)init;
+    return r;
+}
+
+SlotPool *pool_of_key(const TFheGateBootstrappingCloudKeySet *bk) {
+    if (!bk || !bk->bk) fatal("null cloud key");
+    if (!bk->bk->dev) fatal("this keyset is host-only (no device key image); gates need the GPU");
+    return Engine::get().pool_for(bk->bk->p);
+}
+
+int flush_locked();
+
+// make sure `s` has a device slot holding its current value; returns the slot
+int32_t ensure_slot(const LweSample *cs, SlotPool *pool) {
+    auto *s = const_cast<LweSample *>(cs);
+    if (s->slot >= 0) return s->slot;
+    if (s->slot == SLOT_ZERO) {
+        pool->retain(pool->zero_slot);
+        s->slot = pool->zero_slot;
+        return s->slot;
+    }
+    const int32_t slot = pool->alloc();
+    Engine::get().write_slot(pool, slot, s->a, s->b);
+    s->slot = slot;
+    return slot;
+}
+
+void drop_slot(LweSample *s, SlotPool *pool) {
+    if (s->slot >= 0 && pool) pool->release(s->slot);
+    s->slot = SLOT_HOST;
+}
+
+void begin_op(const TFheGateBootstrappingCloudKeySet *bk) {
+    Recorder &r = rec();
+    if (r.key && r.key != bk && !r.ops.empty()) flush_locked();
+    r.key = bk;
+    r.pool = pool_of_key(bk);
+}
+
+void sync_sample_locked(const LweSample *cs) {
+    Recorder &r = rec();
+    auto *s = const_cast<LweSample *>(cs);
+    if (s->slot < 0) {
+        if (s->slot == SLOT_ZERO) { /* host mirror already zero */ }
+        return;
+    }
+    if (!r.pool) fatal("device-resident sample without a pool");
+    if (r.pool->level[s->slot] > 0) flush_locked();
+    Engine::get().read_slot(r.pool, s->slot, s->a, &s->b);
+}
+
+void finish_op(LweSample *result) {
+    Recorder &r = rec();
+    if (!r.deferred) {
+        flush_locked();
+        sync_sample_locked(result);   // immediate mode: host mirror valid on return, as upstream
+    }
+}
+
+void record_gate2(int code, LweSample *result, const LweSample *ca, const LweSample *cb,
+                  const TFheGateBootstrappingCloudKeySet *bk) {
+    Recorder &r = rec();
+    std::lock_guard<std::recursive_mutex> g(r.mtx);
+    begin_op(bk);
+    SlotPool *pool = r.pool;
+    const int32_t sa = ensure_slot(ca, pool), sb = ensure_slot(cb, pool);
+    const int32_t dst = pool->alloc();
+    const int32_t level = 1 + std::max(pool->level[sa], pool->level[sb]);
+    pool->level[dst] = level;
+    pool->retain(sa); pool->retain(sb); pool->retain(dst);   // pending references
+    r.ops.push_back(PendingOp{(uint8_t)code, dst, sa, sb, -1, level});
+    r.max_level = std::max(r.max_level, level);
+    if (result->slot >= 0) pool->release(result->slot);
+    result->slot = dst;
+    finish_op(result);
+}
+
+}  // namespace
+
+// flush: levelise, build descriptors, execute, release pending references
+namespace {
+int flush_locked() {
+    Recorder &r = rec();
+    if (r.ops.empty()) return 0;
+    SlotPool *pool = r.pool;
+    const int levels = r.max_level;
+    LevelPlan plan;
+    // counting sort by level
+    std::vector<int32_t> nrot(levels + 2, 0), nks(levels + 2, 0), nnot(levels + 2, 0);
+    for (const PendingOp &op : r.ops) {
+        if (op.kind == OP_NOT) ++nnot[op.level];
+        else if (op.kind == OP_MUX) { nrot[op.level] += 2; ++nks[op.level]; }
+        else { ++nrot[op.level]; ++nks[op.level]; }
+    }
+    plan.rot_off.assign(levels + 1, 0);
+    plan.ks_off.assign(levels + 1, 0);
+    plan.not_off.assign(levels + 2, 0);
+    for (int L = 1; L <= levels; ++L) {
+        plan.rot_off[L] = plan.rot_off[L - 1] + nrot[L];
+        plan.ks_off[L] = plan.ks_off[L - 1] + nks[L];
+        plan.max_rots_per_level = std::max(plan.max_rots_per_level, nrot[L]);
+    }
+    for (int L = 0; L <= levels; ++L) plan.not_off[L + 1] = plan.not_off[L] + nnot[L];
+    plan.rots.resize(plan.rot_off[levels]);
+    plan.kss.resize(plan.ks_off[levels]);
+    plan.nots.resize(plan.not_off[levels + 1]);
+    std::vector<int32_t> rpos(plan.rot_off.begin(), plan.rot_off.end() - 1);   // cursor per level (index L-1)
+    std::vector<int32_t> kpos(plan.ks_off.begin(), plan.ks_off.end() - 1);
+    std::vector<int32_t> npos(plan.not_off.begin(), plan.not_off.end() - 1);   // index L
+    const int32_t mu = 1 << 29;
+    for (const PendingOp &op : r.ops) {
+        if (op.kind == OP_NOT) {
+            plan.nots[npos[op.level]++] = NotDesc{op.a, op.dst};
+            continue;
+        }
+        const int L = op.level - 1;
+        const int32_t base = plan.rot_off[L];
+        if (op.kind == OP_MUX) {
+            // tfhe bootsMUX: u1 = BR(-1/8 + a + b), u2 = BR(-1/8 - a + c), KS(u1 + u2 + 1/8)
+            const int32_t i0 = rpos[L]++, i1 = rpos[L]++;
+            plan.rots[i0] = RotDesc{op.a, op.b, 1, 1, -(mu), i0 - base};
+            plan.rots[i1] = RotDesc{op.a, op.c, -1, 1, -(mu), i1 - base};
+            plan.kss[kpos[L]++] = KsDesc{i0 - base, i1 - base, mu, op.dst};
+        } else {
+            const GateLin &gl = GATE_LIN[op.kind];
+            const int32_t i0 = rpos[L]++;
+            plan.rots[i0] = RotDesc{op.a, op.b, gl.sa, gl.sb, gl.c8 * mu, i0 - base};
+            plan.kss[kpos[L]++] = KsDesc{i0 - base, -1, 0, op.dst};
+        }
+    }
+    Engine::get().execute(r.key->bk->dev, pool, plan);
+    for (const PendingOp &op : r.ops) {
+        pool->level[op.dst] = 0;
+        pool->release(op.dst);
+        pool->release(op.a);
+        if (op.b >= 0) pool->release(op.b);
+        if (op.c >= 0) pool->release(op.c);
+    }
+    r.ops.clear();
+    r.max_level = 0;
+    return levels;
+}
+}  // namespace
+
+// ===========================================================================
+// upstream-compatible C ABI
+// ===========================================================================
+extern "C" {
+
+int32_t modSwitchFromTorus32(Torus32 phase, int32_t Msize) {
+    const uint64_t interv = ((UINT64_C(1) << 63) / (uint64_t)Msize) * 2;
+    const uint64_t phase64 = ((uint64_t)(uint32_t)phase << 32) + interv / 2;
+    return (int32_t)(phase64 / interv);
+}
+Torus32 modSwitchToTorus32(int32_t mu, int32_t Msize) {
+    const uint64_t interv = ((UINT64_C(1) << 63) / (uint64_t)Msize) * 2;
+    return (Torus32)(((uint64_t)(int64_t)mu * interv) >> 32);
+}
+
+TFheGateBootstrappingParameterSet *new_default_gate_bootstrapping_parameters(int32_t minimum_lambda) {
+    Params p;
+    if (!default_params(minimum_lambda, p)) {
+        std::fprintf(stderr, "Sorry, for now, the parameters are only implemented for 80bit and 128bit of security!\n");
+        set_error("unsupported minimum_lambda");
+        return nullptr;
+    }
+    return &make_param_bundle(p)->set;
+}
+
+void delete_gate_bootstrapping_parameters(TFheGateBootstrappingParameterSet *params) {
+    delete reinterpret_cast<ParamBundle *>(params);
+}
+
+static TFheGateBootstrappingSecretKeySet *make_keyset(const TFheGateBootstrappingParameterSet *params, uint64_t seed,
+                                                      bool device) {
+    if (!params) { set_error("null params"); return nullptr; }
+    const Params &p = params_of(params);
+    auto *sk = new TfheHipSecretKey();
+    auto *ck = new TfheHipCloudKey();
+    generate_keys(p, seed, *sk, *ck);
+    if (device) ck->dev = Engine::get().upload_key(*ck);
+    auto *ks = new TFheGateBootstrappingSecretKeySet();
+    ks->params = params;
+    ks->lwe_key = sk;
+    ks->tgsw_key = sk;
+    ks->cloud.params = params;
+    ks->cloud.bk = ck;
+    ks->cloud.bkFFT = ck;
+    return ks;
+}
+
+TFheGateBootstrappingSecretKeySet *new_random_gate_bootstrapping_secret_keyset(const TFheGateBootstrappingParameterSet *params) {
+    // upstream draws from an unseeded global generator; here successive keysets use successive seeds
+    Recorder &r = rec();
+    std::lock_guard<std::recursive_mutex> g(r.mtx);
+    return make_keyset(params, 0x7F4E5EEDull + r.keygen_counter++, true);
+}
+
+void delete_gate_bootstrapping_secret_keyset(TFheGateBootstrappingSecretKeySet *keyset) {
+    if (!keyset) return;
+    Recorder &r = rec();
+    std::lock_guard<std::recursive_mutex> g(r.mtx);
+    if (r.key == &keyset->cloud) { flush_locked(); r.key = nullptr; }
+    if (keyset->cloud.bk) {
+        Engine::get().free_key(keyset->cloud.bk->dev);
+        delete keyset->cloud.bk;
+    }
+    delete keyset->lwe_key;
+    delete keyset;
+}
+
+void delete_gate_bootstrapping_cloud_keyset(TFheGateBootstrappingCloudKeySet *) {
+    // the cloud key is embedded in the secret keyset in this library (as at main.cpp:23); nothing to free
+}
+
+LweSample *new_gate_bootstrapping_ciphertext_array(int32_t nbelems, const TFheGateBootstrappingParameterSet *params) {
+    if (nbelems < 0 || !params) { set_error("bad arguments to new_gate_bootstrapping_ciphertext_array"); return nullptr; }
+    const int32_t n = params->in_out_params->n;
+    const size_t bytes = sizeof(ArrayHeader) + (size_t)nbelems * sizeof(LweSample) + (size_t)nbelems * n * sizeof(Torus32);
+    char *mem = static_cast<char *>(std::calloc(1, bytes ? bytes : 1));
+    if (!mem) fatal("out of host memory");
+    auto *h = reinterpret_cast<ArrayHeader *>(mem);
+    h->magic = ARRAY_MAGIC; h->count = nbelems; h->n = n; h->pool = nullptr;
+    auto *samples = reinterpret_cast<LweSample *>(mem + sizeof(ArrayHeader));
+    auto *words = reinterpret_cast<Torus32 *>(mem + sizeof(ArrayHeader) + (size_t)nbelems * sizeof(LweSample));
+    for (int32_t i = 0; i < nbelems; ++i) {
+        samples[i].a = words + (size_t)i * n;
+        samples[i].b = 0;
+        samples[i].slot = SLOT_ZERO;
+        samples[i].current_variance = 0.0;
+    }
+    return samples;
+}
+
+void delete_gate_bootstrapping_ciphertext_array(int32_t nbelems, LweSample *samples) {
+    if (!samples) return;
+    ArrayHeader *h = header_of(samples);
+    if (h->count != nbelems) set_error("delete_gate_bootstrapping_ciphertext_array: count differs from allocation");
+    Recorder &r = rec();
+    std::lock_guard<std::recursive_mutex> g(r.mtx);
+    for (int32_t i = 0; i < h->count; ++i)
+        if (samples[i].slot >= 0 && r.pool) r.pool->release(samples[i].slot);
+    h->magic = 0;
+    std::free(h);
+}
+
+LweSample *new_gate_bootstrapping_ciphertext(const TFheGateBootstrappingParameterSet *params) {
+    return new_gate_bootstrapping_ciphertext_array(1, params);
+}
+void delete_gate_bootstrapping_ciphertext(LweSample *sample) { delete_gate_bootstrapping_ciphertext_array(1, sample); }
+
+void bootsSymEncrypt(LweSample *result, int32_t message, const TFheGateBootstrappingSecretKeySet *key) {
+    Recorder &r = rec();
+    std::lock_guard<std::recursive_mutex> g(r.mtx);
+    drop_slot(result, r.pool);
+    encrypt_bit(*key->lwe_key, r.enc_rng, message, result->a, &result->b);
+}
+
+int32_t bootsSymDecrypt(const LweSample *sample, const TFheGateBootstrappingSecretKeySet *key) {
+    Recorder &r = rec();
+    std::lock_guard<std::recursive_mutex> g(r.mtx);
+    sync_sample_locked(sample);
+    return phase_of(*key->lwe_key, sample->a, sample->b) > 0 ? 1 : 0;
+}
+
+void bootsCONSTANT(LweSample *result, int32_t value, const TFheGateBootstrappingCloudKeySet *bk) {
+    Recorder &r = rec();
+    std::lock_guard<std::recursive_mutex> g(r.mtx);
+    begin_op(bk);
+    const int32_t s = r.pool->const_slot[value ? 1 : 0];
+    r.pool->retain(s);
+    if (result->slot >= 0) r.pool->release(result->slot);
+    result->slot = s;
+    if (!r.deferred) {   // keep the host mirror exact without a device round trip
+        std::memset(result->a, 0, (size_t)bk->params->in_out_params->n * sizeof(Torus32));
+        result->b = value ? (1 << 29) : -(1 << 29);
+    }
+}
+
+void bootsCOPY(LweSample *result, const LweSample *ca, const TFheGateBootstrappingCloudKeySet *bk) {
+    Recorder &r = rec();
+    std::lock_guard<std::recursive_mutex> g(r.mtx);
+    begin_op(bk);
+    if (result == ca) return;
+    const int32_t s = ensure_slot(ca, r.pool);
+    r.pool->retain(s);
+    if (result->slot >= 0) r.pool->release(result->slot);
+    result->slot = s;
+    if (!r.deferred) sync_sample_locked(result);
+}
+
+void bootsNOT(LweSample *result, const LweSample *ca, const TFheGateBootstrappingCloudKeySet *bk) {
+    Recorder &r = rec();
+    std::lock_guard<std::recursive_mutex> g(r.mtx);
+    begin_op(bk);
+    SlotPool *pool = r.pool;
+    const int32_t sa = ensure_slot(ca, pool);
+    const int32_t dst = pool->alloc();
+    const int32_t level = pool->level[sa];     // linear: rides on its operand's level
+    pool->level[dst] = level;
+    pool->retain(sa); pool->retain(dst);
+    r.ops.push_back(PendingOp{OP_NOT, dst, sa, -1, -1, level});
+    r.max_level = std::max(r.max_level, level);
+    if (result->slot >= 0) pool->release(result->slot);
+    result->slot = dst;
+    finish_op(result);
+}
+
+void bootsNAND(LweSample *r_, const LweSample *a, const LweSample *b, const TFheGateBootstrappingCloudKeySet *bk) { record_gate2(TFHE_HIP_NAND, r_, a, b, bk); }
+void bootsOR(LweSample *r_, const LweSample *a, const LweSample *b, const TFheGateBootstrappingCloudKeySet *bk) { record_gate2(TFHE_HIP_OR, r_, a, b, bk); }
+void bootsAND(LweSample *r_, const LweSample *a, const LweSample *b, const TFheGateBootstrappingCloudKeySet *bk) { record_gate2(TFHE_HIP_AND, r_, a, b, bk); }
+void bootsNOR(LweSample *r_, const LweSample *a, const LweSample *b, const TFheGateBootstrappingCloudKeySet *bk) { record_gate2(TFHE_HIP_NOR, r_, a, b, bk); }
+void bootsXOR(LweSample *r_, const LweSample *a, const LweSample *b, const TFheGateBootstrappingCloudKeySet *bk) { record_gate2(TFHE_HIP_XOR, r_, a, b, bk); }
+void bootsXNOR(LweSample *r_, const LweSample *a, const LweSample *b, const TFheGateBootstrappingCloudKeySet *bk) { record_gate2(TFHE_HIP_XNOR, r_, a, b, bk); }
+void bootsANDNY(LweSample *r_, const LweSample *a, const LweSample *b, const TFheGateBootstrappingCloudKeySet *bk) { record_gate2(TFHE_HIP_ANDNY, r_, a, b, bk); }
+void bootsANDYN(LweSample *r_, const LweSample *a, const LweSample *b, const TFheGateBootstrappingCloudKeySet *bk) { record_gate2(TFHE_HIP_ANDYN, r_, a, b, bk); }
+void bootsORNY(LweSample *r_, const LweSample *a, const LweSample *b, const TFheGateBootstrappingCloudKeySet *bk) { record_gate2(TFHE_HIP_ORNY, r_, a, b, bk); }
+void bootsORYN(LweSample *r_, const LweSample *a, const LweSample *b, const TFheGateBootstrappingCloudKeySet *bk) { record_gate2(TFHE_HIP_ORYN, r_, a, b, bk); }
+
+void bootsMUX(LweSample *result, const LweSample *a, const LweSample *b, const LweSample *c,
+              const TFheGateBootstrappingCloudKeySet *bk) {
+    Recorder &r = rec();
+    std::lock_guard<std::recursive_mutex> g(r.mtx);
+    begin_op(bk);
+    SlotPool *pool = r.pool;
+    const int32_t sa = ensure_slot(a, pool), sb = ensure_slot(b, pool), sc = ensure_slot(c, pool);
+    const int32_t dst = pool->alloc();
+    const int32_t level = 1 + std::max(pool->level[sa], std::max(pool->level[sb], pool->level[sc]));
+    pool->level[dst] = level;
+    pool->retain(sa); pool->retain(sb); pool->retain(sc); pool->retain(dst);
+    r.ops.push_back(PendingOp{OP_MUX, dst, sa, sb, sc, level});
+    r.max_level = std::max(r.max_level, level);
+    if (result->slot >= 0) pool->release(result->slot);
+    result->slot = dst;
+    finish_op(result);
+}
+
+// ===========================================================================
+// tfhe_hip_* extensions
+// ===========================================================================
+const char *tfhe_hip_last_error(void) { return last_error_ref().c_str(); }
+void tfhe_hip_clear_error(void) { set_error(""); }
+
+int tfhe_hip_set_device(int device) { Engine::get().set_device(device); return 0; }
+int tfhe_hip_get_device(void) { return Engine::get().device(); }
+
+TFheGateBootstrappingParameterSet *tfhe_hip_new_parameters(int32_t n, int32_t N, int32_t k, int32_t l, int32_t Bgbit,
+                                                           int32_t ks_t, int32_t ks_basebit, double ks_stdev,
+                                                           double bk_stdev, double max_stdev) {
+    if (n <= 0 || N <= 0 || (N & (N - 1)) || k < 1 || l < 1 || Bgbit < 1 || l * Bgbit > 32 || ks_t < 1 ||
+        ks_basebit < 1 || ks_t * ks_basebit > 31) {
+        set_error("tfhe_hip_new_parameters: invalid parameter tuple");
+        return nullptr;
+    }
+    Params p{n, N, k, l, Bgbit, ks_t, ks_basebit, ks_stdev, bk_stdev, max_stdev};
+    return &make_param_bundle(p)->set;
+}
+TFheGateBootstrappingParameterSet *tfhe_hip_new_p2048_parameters(void) { return &make_param_bundle(p2048_params())->set; }
+
+TFheGateBootstrappingSecretKeySet *tfhe_hip_new_secret_keyset_seeded(const TFheGateBootstrappingParameterSet *params, uint64_t seed) {
+    return make_keyset(params, seed, true);
+}
+TFheGateBootstrappingSecretKeySet *tfhe_hip_new_secret_keyset_seeded_host(const TFheGateBootstrappingParameterSet *params, uint64_t seed) {
+    return make_keyset(params, seed, false);
+}
+void tfhe_hip_set_encrypt_seed(uint64_t seed) {
+    Recorder &r = rec();
+    std::lock_guard<std::recursive_mutex> g(r.mtx);
+    r.enc_rng.reseed(seed);
+}
+
+const int32_t *tfhe_hip_key_lwe(const TFheGateBootstrappingSecretKeySet *key, int64_t *count) {
+    if (count) *count = (int64_t)key->lwe_key->lwe_key.size();
+    return key->lwe_key->lwe_key.data();
+}
+const int32_t *tfhe_hip_key_tlwe(const TFheGateBootstrappingSecretKeySet *key, int64_t *count) {
+    if (count) *count = (int64_t)key->lwe_key->tlwe_key.size();
+    return key->lwe_key->tlwe_key.data();
+}
+const Torus32 *tfhe_hip_key_bk(const TFheGateBootstrappingCloudKeySet *cloud, int64_t *count) {
+    if (count) *count = (int64_t)cloud->bk->bk.size();
+    return cloud->bk->bk.data();
+}
+const Torus32 *tfhe_hip_key_ksk(const TFheGateBootstrappingCloudKeySet *cloud, int64_t *count) {
+    if (count) *count = (int64_t)cloud->bk->ksk.size();
+    return cloud->bk->ksk.data();
+}
+
+int32_t tfhe_hip_sample_words(const TFheGateBootstrappingParameterSet *params) { return params->in_out_params->n + 1; }
+
+static int export_impl(const LweSample *samples, int32_t count, int32_t n, Torus32 *out, bool device_dst) {
+    Recorder &r = rec();
+    std::lock_guard<std::recursive_mutex> g(r.mtx);
+    if (count <= 0) return 0;
+    if (!device_dst) {
+        bool any_dev = false;
+        for (int32_t i = 0; i < count; ++i) any_dev |= samples[i].slot >= 0;
+        if (!any_dev) {
+            for (int32_t i = 0; i < count; ++i) {
+                std::memcpy(out + (size_t)i * (n + 1), samples[i].a, (size_t)n * 4);
+                out[(size_t)i * (n + 1) + n] = samples[i].b;
+            }
+            return 0;
+        }
+    }
+    if (!r.pool) { set_error("export to device before any key was created"); return -1; }
+    if (!r.ops.empty()) flush_locked();
+    std::vector<int32_t> slots(count);
+    for (int32_t i = 0; i < count; ++i) slots[i] = ensure_slot(&samples[i], r.pool);
+    Engine::get().read_slots_packed(r.pool, slots.data(), count, out, device_dst);
+    return 0;
+}
+
+static int import_impl(LweSample *samples, int32_t count, int32_t n, const Torus32 *in, bool device_src) {
+    Recorder &r = rec();
+    std::lock_guard<std::recursive_mutex> g(r.mtx);
+    if (count <= 0) return 0;
+    if (!r.pool) {
+        if (device_src) { set_error("import from device before any key was created"); return -1; }
+        for (int32_t i = 0; i < count; ++i) {
+            std::memcpy(samples[i].a, in + (size_t)i * (n + 1), (size_t)n * 4);
+            samples[i].b = in[(size_t)i * (n + 1) + n];
+            samples[i].slot = SLOT_HOST;
+        }
+        return 0;
+    }
+    std::vector<int32_t> slots(count);
+    for (int32_t i = 0; i < count; ++i) {
+        if (samples[i].slot >= 0) r.pool->release(samples[i].slot);
+        slots[i] = samples[i].slot = r.pool->alloc();
+        if (!device_src) {
+            std::memcpy(samples[i].a, in + (size_t)i * (n + 1), (size_t)n * 4);
+            samples[i].b = in[(size_t)i * (n + 1) + n];
+        }
+    }
+    Engine::get().write_slots_packed(r.pool, slots.data(), count, in, device_src);
+    return 0;
+}
+
+int tfhe_hip_export_samples(const LweSample *samples, int32_t count, const TFheGateBootstrappingParameterSet *params,
+                            Torus32 *out_words) {
+    return export_impl(samples, count, params->in_out_params->n, out_words, false);
+}
+int tfhe_hip_import_samples(LweSample *samples, int32_t count, const TFheGateBootstrappingParameterSet *params,
+                            const Torus32 *in_words) {
+    return import_impl(samples, count, params->in_out_params->n, in_words, false);
+}
+int tfhe_hip_export_samples_device(const LweSample *samples, int32_t count,
+                                   const TFheGateBootstrappingParameterSet *params, void *device_words) {
+    return export_impl(samples, count, params->in_out_params->n, static_cast<Torus32 *>(device_words), true);
+}
+int tfhe_hip_import_samples_device(LweSample *samples, int32_t count, const TFheGateBootstrappingParameterSet *params,
+                                   const void *device_words) {
+    return import_impl(samples, count, params->in_out_params->n, static_cast<const Torus32 *>(device_words), true);
+}
+
+int tfhe_hip_sync_samples(const LweSample *samples, int32_t count) {
+    Recorder &r = rec();
+    std::lock_guard<std::recursive_mutex> g(r.mtx);
+    if (!r.ops.empty()) flush_locked();
+    for (int32_t i = 0; i < count; ++i) sync_sample_locked(&samples[i]);
+    return 0;
+}
+
+void tfhe_hip_set_deferred(int on) {
+    Recorder &r = rec();
+    std::lock_guard<std::recursive_mutex> g(r.mtx);
+    if (!on && !r.ops.empty()) flush_locked();
+    r.deferred = on != 0;
+}
+int tfhe_hip_get_deferred(void) { return rec().deferred ? 1 : 0; }
+
+int tfhe_hip_flush(void) {
+    Recorder &r = rec();
+    std::lock_guard<std::recursive_mutex> g(r.mtx);
+    return flush_locked();
+}
+
+int tfhe_hip_gate_batch(int gate, LweSample *result, const LweSample *a, const LweSample *b, int32_t count,
+                        const TFheGateBootstrappingCloudKeySet *bk) {
+    if (gate < 0 || gate > TFHE_HIP_ORYN) { set_error("tfhe_hip_gate_batch: bad gate code"); return -1; }
+    Recorder &r = rec();
+    std::lock_guard<std::recursive_mutex> g(r.mtx);
+    const bool was = r.deferred;
+    r.deferred = true;
+    for (int32_t i = 0; i < count; ++i) record_gate2(gate, &result[i], &a[i], &b[i], bk);
+    r.deferred = was;
+    if (!was) flush_locked();
+    return 0;
+}
+
+void tfhe_hip_get_stats(TfheHipStats *out) { if (out) *out = Engine::get().stats; }
+void tfhe_hip_reset_stats(void) { Engine::get().stats = TfheHipStats{}; }
+void tfhe_hip_set_kernel_timing(int on) { Engine::get().kernel_timing = on != 0; }
+
+int tfhe_hip_kernel_negacyclic(const TFheGateBootstrappingCloudKeySet *bk, const int32_t *ip, const Torus32 *tp,
+                               Torus32 *res, int32_t count) {
+    if (!bk || !bk->bk || !bk->bk->dev) { set_error("negacyclic: keyset has no device image"); return -1; }
+    Engine::get().run_negacyclic(bk->bk->dev, ip, tp, res, count);
+    return 0;
+}
+int tfhe_hip_kernel_bootstrap_woks(const TFheGateBootstrappingCloudKeySet *bk, const Torus32 *lin, int32_t count,
+                                   Torus32 *u_out, Torus32 *acc_out) {
+    if (!bk || !bk->bk || !bk->bk->dev) { set_error("bootstrap_woks: keyset has no device image"); return -1; }
+    Engine::get().run_bootstrap_woks(bk->bk->dev, lin, count, u_out, acc_out);
+    return 0;
+}
+int tfhe_hip_kernel_keyswitch(const TFheGateBootstrappingCloudKeySet *bk, const Torus32 *u, int32_t count, Torus32 *out) {
+    if (!bk || !bk->bk || !bk->bk->dev) { set_error("keyswitch: keyset has no device image"); return -1; }
+    Engine::get().run_keyswitch(bk->bk->dev, u, count, out);
+    return 0;
+}
+
+}  // extern "C"

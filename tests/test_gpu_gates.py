@@ -1,0 +1,133 @@
+"""GPU parity of the boots* gates (a4-a9) against the CPU oracle: decrypted truth tables
+AND ciphertext words, through the upstream-compatible C ABI."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+TRUTH = {"AND": lambda a, b: a & b, "OR": lambda a, b: a | b, "XOR": lambda a, b: a ^ b,
+         "XNOR": lambda a, b: 1 - (a ^ b), "NAND": lambda a, b: 1 - (a & b), "NOR": lambda a, b: 1 - (a | b),
+         "ANDNY": lambda a, b: (1 - a) & b, "ANDYN": lambda a, b: a & (1 - b),
+         "ORNY": lambda a, b: (1 - a) | b, "ORYN": lambda a, b: a | (1 - b)}
+
+
+def test_two_input_gates_batched(p128_keys, oracle):
+    from peba1_amd import api, lib
+    pp, ks, oks = p128_keys
+    L = lib.load()
+    L.tfhe_hip_set_encrypt_seed(21)
+    abits = [0, 0, 1, 1]
+    bbits = [0, 1, 0, 1]
+    a = api.CiphertextArray(pp, 4).encrypt(abits, ks)
+    b = api.CiphertextArray(pp, 4).encrypt(bbits, ks)
+    wa, wb = a.words(), b.words()
+    for name, f in TRUTH.items():
+        res = api.CiphertextArray(pp, 4)
+        api.gate_batch(name, res, a, b, ks)
+        got = res.words()
+        for i in range(4):
+            assert (got[i] == oks.gate(name, wa[i], wb[i])).all(), (name, i)
+        assert list(res.decrypt(ks)) == [f(x, y) for x, y in zip(abits, bbits)], name
+
+
+def test_single_call_api_immediate_mode(p128_keys, oracle):
+    """The drop-in path: one boots* call per gate, result complete on return."""
+    from peba1_amd import api, lib
+    pp, ks, oks = p128_keys
+    L = lib.load()
+    assert L.tfhe_hip_get_deferred() == 0
+    L.tfhe_hip_set_encrypt_seed(5)
+    x = api.CiphertextArray(pp, 3).encrypt([1, 0, 1], ks)
+    wx = x.words()
+    r = api.CiphertextArray(pp, 4)
+    L.bootsXOR(r.at(0), x.at(0), x.at(1), ks.cloud)
+    L.bootsMUX(r.at(1), x.at(0), x.at(1), x.at(2), ks.cloud)
+    L.bootsNOT(r.at(2), x.at(0), ks.cloud)
+    L.bootsCONSTANT(r.at(3), 1, ks.cloud)
+    # host mirror is valid on return in immediate mode
+    n = pp.n
+    mirror = np.array([list(r.ptr[i].a[0:n]) + [r.ptr[i].b] for i in range(4)], dtype=np.int32)
+    assert (mirror[0] == oks.gate("XOR", wx[0], wx[1])).all()
+    assert (mirror[1] == oks.mux(wx[0], wx[1], wx[2])).all()
+    assert (mirror[2] == oks.gate_not(wx[0])).all()
+    assert (mirror[3] == oks.constant(1)).all()
+    assert list(r.decrypt(ks)) == [1, 0, 0, 1]
+    # result aliasing an input (reference: Math.cpp:272)
+    L.bootsAND(x.at(0), x.at(0), x.at(2), ks.cloud)
+    assert (x.words()[0] == oks.gate("AND", wx[0], wx[2])).all()
+
+
+def test_mux_truth_table_deferred(p128_keys, oracle):
+    from peba1_amd import api, lib
+    pp, ks, oks = p128_keys
+    L = lib.load()
+    L.tfhe_hip_set_encrypt_seed(8)
+    combos = [(a, b, c) for a in (0, 1) for b in (0, 1) for c in (0, 1)]
+    A = api.CiphertextArray(pp, 8).encrypt([t[0] for t in combos], ks)
+    B = api.CiphertextArray(pp, 8).encrypt([t[1] for t in combos], ks)
+    Cc = api.CiphertextArray(pp, 8).encrypt([t[2] for t in combos], ks)
+    wa, wb, wc = A.words(), B.words(), Cc.words()
+    R = api.CiphertextArray(pp, 8)
+    api.set_deferred(True)
+    try:
+        for i in range(8):
+            L.bootsMUX(R.at(i), A.at(i), B.at(i), Cc.at(i), ks.cloud)
+        assert api.flush() == 1          # eight independent MUXes: one level
+    finally:
+        api.set_deferred(False)
+    got = R.words()
+    for i, (a, b, c) in enumerate(combos):
+        assert (got[i] == oks.mux(wa[i], wb[i], wc[i])).all(), i
+    assert list(R.decrypt(ks)) == [b if a else c for a, b, c in combos]
+
+
+def test_deferred_chain_with_overwrite_and_free(p128_keys, oracle):
+    """A dependent chain recorded with the reference's habits: a temporary overwritten,
+    copied and freed before the flush (Math.cpp:34-49)."""
+    from peba1_amd import api, lib
+    pp, ks, oks = p128_keys
+    L = lib.load()
+    L.tfhe_hip_set_encrypt_seed(13)
+    x = api.CiphertextArray(pp, 3).encrypt([1, 1, 0], ks)
+    wx = x.words()
+    out = api.CiphertextArray(pp, 2)
+    api.set_deferred(True)
+    try:
+        tmp = api.CiphertextArray(pp, 1)
+        keep = api.CiphertextArray(pp, 1)
+        L.bootsXOR(tmp.at(0), x.at(0), x.at(1), ks.cloud)       # t1 = a ^ b
+        L.bootsXOR(out.at(0), tmp.at(0), x.at(2), ks.cloud)     # s  = t1 ^ c
+        L.bootsAND(tmp.at(0), x.at(0), x.at(1), ks.cloud)       # overwrite tmp
+        L.bootsCOPY(keep.at(0), tmp.at(0), ks.cloud)
+        L.bootsAND(tmp.at(0), x.at(0), x.at(2), ks.cloud)       # overwrite again
+        L.bootsXOR(out.at(1), keep.at(0), tmp.at(0), ks.cloud)
+        tmp.close()
+        keep.close()
+        assert api.flush() == 2
+    finally:
+        api.set_deferred(False)
+    t1 = oks.gate("XOR", wx[0], wx[1])
+    s = oks.gate("XOR", t1, wx[2])
+    t2 = oks.gate("AND", wx[0], wx[1])
+    t3 = oks.gate("AND", wx[0], wx[2])
+    c = oks.gate("XOR", t2, t3)
+    got = out.words()
+    assert (got[0] == s).all() and (got[1] == c).all()
+    assert list(out.decrypt(ks)) == [0, 1]
+
+
+def test_fresh_samples_are_trivial_zero(p128_keys, oracle):
+    """Function_f reads never-written samples; the shim defines them as phase 0."""
+    from peba1_amd import api, lib
+    pp, ks, oks = p128_keys
+    L = lib.load()
+    L.tfhe_hip_set_encrypt_seed(2)
+    one = api.CiphertextArray(pp, 1).encrypt([1], ks)
+    fresh = api.CiphertextArray(pp, 1)
+    r = api.CiphertextArray(pp, 1)
+    L.bootsXOR(r.at(0), one.at(0), fresh.at(0), ks.cloud)
+    zero = np.zeros(pp.words, dtype=np.int32)
+    assert (r.words()[0] == oks.gate("XOR", one.words()[0], zero)).all()
+    assert fresh.decrypt(ks)[0] == 0

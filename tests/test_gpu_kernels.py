@@ -1,0 +1,78 @@
+"""GPU parity of each HIP kernel against the CPU oracle, word for word (bit-exact:
+all arithmetic is integer / Torus32).  Call path: Python -> C ABI (include/tfhe_hip.h)
+-> HIP kernels.  Reference semantics: SURVEY.md Appendix A.3; reference call sites
+/root/reference/src/Math.cpp:34-43."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def test_key_material_identical(p128_keys):
+    _, ks, oks = p128_keys
+    assert (ks.lwe_key() == oks.lwe_key()).all()
+    assert (ks.tlwe_key() == oks.tlwe_key()).all()
+    assert (ks.bk() == oks.bk()).all()
+    assert (ks.ksk() == oks.ksk()).all()
+
+
+def test_negacyclic_ntt_exact(p128_keys, oracle):
+    """a15: negacyclic polynomial multiply through the two-prime device NTT == schoolbook mod 2^32."""
+    from peba1_amd import api
+    _, ks, _ = p128_keys
+    rng = np.random.default_rng(7)
+    count, N = 12, 1024
+    ip = rng.integers(-64, 64, (count, N), dtype=np.int64).astype(np.int32)
+    tp = rng.integers(-2**31, 2**31, (count, N), dtype=np.int64).astype(np.int32)
+    # edge cases: extreme digits against extreme torus values, zeros, a monomial
+    ip[0, :] = -64; tp[0, :] = -2**31
+    ip[1, :] = 63; tp[1, :] = 2**31 - 1
+    ip[2, :] = 0
+    ip[3, :] = 0; ip[3, 1023] = 1
+    got = api.kernel_negacyclic(ks, ip, tp)
+    for c in range(count):
+        want = oracle.negacyclic(ip[c], tp[c], ntt=False)
+        assert (got[c] == want).all(), f"poly {c}"
+
+
+def test_blind_rotate_matches_oracle(p128_keys, oracle):
+    """a11-a14, a16: modswitch + blind rotate + extract on real ciphertext combinations."""
+    from peba1_amd import api
+    _, ks, oks = p128_keys
+    r = oracle.Rng(11)
+    cts = oks.encrypt(r, [1, 1, 0, 1])
+    lins = np.stack([oks.prelude("AND", cts[0], cts[1]), oks.prelude("XOR", cts[2], cts[3])])
+    u, acc = api.kernel_bootstrap_woks(ks, lins, want_acc=True)
+    for c in range(2):
+        bar = oks.modswitch_ct(lins[c])
+        want_acc = oks.blind_rotate(bar[:-1], bar[-1])
+        assert (acc[c] == want_acc).all(), f"accumulator {c}"
+        assert (u[c] == oks.sample_extract(want_acc)).all(), f"extract {c}"
+
+
+def test_blind_rotate_edge_inputs(p128_keys, oracle):
+    """all-zero mask (every step skipped), barb = 0, and abar values at the wrap points."""
+    from peba1_amd import api
+    pp, ks, oks = p128_keys
+    lin = np.zeros((3, pp.words), dtype=np.int32)
+    lin[1, :] = np.int32(1 << 21)              # every abar = 1
+    lin[2, ::2] = np.int32(-(1 << 21))         # abar = 2N-1 on even positions
+    lin[2, 5] = np.int32(1 << 31 >> 0) if False else np.int32(-2**31)   # abar = N
+    u, acc = api.kernel_bootstrap_woks(ks, lin, want_acc=True)
+    for c in range(3):
+        bar = oks.modswitch_ct(lin[c])
+        want = oks.blind_rotate(bar[:-1], bar[-1])
+        assert (acc[c] == want).all(), f"case {c}"
+
+
+def test_keyswitch_matches_oracle(p128_keys, oracle):
+    """a17: key switch of arbitrary extracted samples."""
+    from peba1_amd import api
+    pp, ks, oks = p128_keys
+    rng = np.random.default_rng(3)
+    u = rng.integers(-2**31, 2**31, (5, pp.N + 1), dtype=np.int64).astype(np.int32)
+    u[0, :] = 0                      # all digits zero: nothing subtracted
+    u[1, :-1] = -1                   # all digits 3 after rounding offset wraps
+    got = api.kernel_keyswitch(ks, u)
+    for c in range(5):
+        assert (got[c] == oks.keyswitch(u[c])).all(), f"sample {c}"
