@@ -1,0 +1,196 @@
+#!/usr/bin/env python3
+"""bench.py -- bootstrapped gates/s of the PEBA1 match path on MI355X.
+
+A "step" is ONE encrypted match: Function_f (squared-Euclidean distance of a
+128-slot x 8-bit probe against a template, then the threshold comparator;
+/root/reference/src/Math.cpp:379-387) = 215,544 blind rotations + 215,496 key
+switches, TFHE default 128-bit parameters (n=630, N=1024, k=1, l=3, Bg=2^7).  Inputs
+(probe, template, threshold ciphertexts) and the evaluation keys are resident in HBM
+before the timed region.  With --gpus N every rank runs its own independent match
+against its own template (1-to-N identification, weak scaling); the only exchange is
+one RCCL gather of the N match-bit ciphertexts to rank 0 per step.
+
+    python bench.py --gpus 1 --steps 3 --warmup 1
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+Prints ONE JSON line on rank 0.  `value` counts blind rotations (a MUX is two).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBPS = 8000.0   # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E peak 8.0 TB/s (spec)
+
+
+def algorithmic_bytes(pp):
+    """bytes per blind rotate / key switch / ciphertext, no cross-gate reuse,
+    bootstrapping key counted at 8 B per coefficient (the density this engine stores: two
+    32-bit residues)."""
+    kpl = (pp.k + 1) * pp.l
+    a_br = pp.n * kpl * (pp.k + 1) * pp.N * 8
+    a_ks = pp.N * pp.k * pp.ks_t * (1.0 - 2.0 ** (-pp.ks_basebit)) * (pp.n + 1) * 4
+    ct = (pp.n + 1) * 4
+    return a_br, a_ks, ct
+
+
+def cpu_baseline(seed):
+    """The oracle (exact-integer C port, oracle/) timed on this box's host cores on a bounded
+    sample of the same work: independent bootsAND gates, all cores."""
+    from oracle import pyoracle as O
+    cores = os.cpu_count() or 1
+    count = min(48, 3 * cores)
+    oks = O.KeySet(O.params("P128"), seed)
+    r = O.Rng(77)
+    import numpy as np
+    a = oks.encrypt(r, np.arange(count) & 1)
+    b = oks.encrypt(r, (np.arange(count) >> 1) & 1)
+    oks.gate_batch("AND", a[:cores], b[:cores], nthreads=cores)      # warm caches / tables
+    t0 = time.perf_counter()
+    out = oks.gate_batch("AND", a, b, nthreads=cores)
+    dt = time.perf_counter() - t0
+    assert list(oks.decrypt(out)) == [int(x & y) for x, y in zip(np.arange(count) & 1, (np.arange(count) >> 1) & 1)]
+    t1 = time.perf_counter()
+    oks.gate_batch("AND", a[:2], b[:2], nthreads=1)
+    single = 2.0 / (time.perf_counter() - t1)
+    return {"value": count / dt, "unit": "bootstrapped gates/s", "cores": cores, "kind": "port",
+            "sample": f"{count} independent bootsAND (P128) on {cores} threads, oracle exact-integer NTT; "
+                      f"1 thread: {single:.2f} gates/s"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--slots", type=int, default=128)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("launch N>1 with torch.distributed.run (one process per GPU)")
+    dist = None
+    torch = None
+    if world > 1:
+        import torch
+        import torch.distributed as dist
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+
+    from peba1_amd import api, circuits, lib
+    L = lib.load()
+    L.tfhe_hip_set_device(local_rank)
+    seed = 0x5EBA2
+    pp = api.ParameterSet(128)
+    ks = api.SecretKeySet(pp, seed, device=True)           # same key on every rank (replicated evaluation keys)
+    nslots, bitsize = args.slots, 8
+    # synthetic inputs of SURVEY.md 8(d): probe = genuine sample; rank r matches it against template r
+    base = [(37 * i + 11) % 255 for i in range(nslots)]
+    probe_vals = [v + 1 for v in base]
+    tmpl_vals = base if rank == 0 else [(v + 29 * rank + 3 * i) % 256 for i, v in enumerate(base)]
+    dist2 = sum((a - b) ** 2 for a, b in zip(probe_vals, tmpl_vals))
+    threshold = 256
+    L.tfhe_hip_set_encrypt_seed(1000 + rank)
+    probe = circuits.EncryptedVector(pp, probe_vals, bitsize, ks).to_device()
+    tmpl = circuits.EncryptedVector(pp, tmpl_vals, bitsize, ks).to_device()
+    bound = circuits.encrypt_number(pp, threshold, 3 * bitsize, ks)
+    bound.set_words(bound.words())
+    L.tfhe_hip_set_kernel_timing(1)
+    api.set_deferred(True)
+
+    gather_buf = None
+    if world > 1:
+        mine = torch.empty(pp.words, dtype=torch.int32, device="cuda")
+        gather_buf = [torch.empty(pp.words, dtype=torch.int32, device="cuda") for _ in range(world)] if rank == 0 else None
+
+    def one_match():
+        rb = api.CiphertextArray(pp, 3 * bitsize)
+        circuits.function_f(rb, probe, tmpl, bound, bitsize, ks)   # records ~350k API calls
+        api.flush()                                                # levelised batched execution
+        if world > 1:   # the exchange step: match-bit ciphertexts to rank 0 over RCCL
+            L.tfhe_hip_export_samples_device(rb.ptr, 1, pp.ptr, mine.data_ptr())
+            dist.gather(mine, gather_buf, dst=0)
+        return rb
+
+    def sync():
+        if world > 1:
+            dist.barrier()
+            torch.cuda.synchronize()
+
+    last = None
+    for _ in range(args.warmup):
+        last = one_match()
+    sync()
+    api.reset_stats()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        last = one_match()
+    sync()
+    elapsed = time.perf_counter() - t0
+    st = api.stats()
+    if world > 1:
+        tt = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        elapsed = float(tt.item())
+
+    # correctness of what was timed: the decrypted match bit is (distance > threshold)
+    bit = int(last.decrypt(ks)[0])
+    assert bit == (1 if dist2 > threshold else 0), f"rank {rank}: match bit {bit}, distance {dist2}"
+    ok_all = True
+    if world > 1 and rank == 0:
+        tmp = api.CiphertextArray(pp, 1)
+        for r in range(world):
+            L.tfhe_hip_import_samples_device(tmp.ptr, 1, pp.ptr, gather_buf[r].data_ptr())
+            ok_all &= int(tmp.decrypt(ks)[0]) in (0, 1)
+
+    if rank == 0:
+        a_br, a_ks, ct = algorithmic_bytes(pp)
+        rot_per_match = st["blind_rotates"] / max(1, args.steps)
+        value = world * st["blind_rotates"] / elapsed
+        br_gbps = st["blind_rotates"] * a_br / (st["ms_blind_rotate"] * 1e-3) / 1e9 if st["ms_blind_rotate"] else 0.0
+        ks_gbps = st["keyswitches"] * a_ks / (st["ms_keyswitch"] * 1e-3) / 1e9 if st["ms_keyswitch"] else 0.0
+        traffic = None
+        pmc = os.path.join(ROOT, "profiles", "pmc_blind_rotate.json")
+        if os.path.exists(pmc):
+            with open(pmc) as f:
+                traffic = json.load(f).get("hbm_bytes_per_launch")
+        out = {
+            "metric": "bootstrapped gates/sec (blind rotations/s) over one PEBA1 match, and end-to-end match ms",
+            "value": value, "unit": "gates/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": elapsed * 1e3 / max(1, args.steps), "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "u32", "data": "synthetic",
+            "config": {"workload": f"Function_f: {nslots} slots x {bitsize} bit template match, TFHE P128 "
+                                   f"(n={pp.n}, N={pp.N}, k={pp.k}, l={pp.l}, Bg=2^{pp.Bgbit}), "
+                                   f"{int(rot_per_match)} blind rotations per match, bit-exact vs CPU oracle",
+                       "parallelism": f"1 match per GPU x {world}", "levels_per_match": int(st["levels"] / max(1, args.steps))},
+            "match_ms": elapsed * 1e3 / max(1, args.steps),
+            "roofline": {"bound": "hbm", "kernel": "blind_rotate_kernel", "achieved": br_gbps, "peak": HBM_PEAK_GBPS,
+                         "unit": "GB/s", "frac": br_gbps / HBM_PEAK_GBPS, "traffic": traffic,
+                         "launches": int(st["br_launches"]),
+                         "avg_launch_ms": st["ms_blind_rotate"] / max(1, st["br_launches"]),
+                         "algorithmic_bytes_per_blind_rotate": a_br,
+                         "keyswitch_GBps": ks_gbps, "algorithmic_bytes_per_keyswitch": a_ks},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            api.set_deferred(False)
+            out["cpu_baseline"] = cpu_baseline(seed)
+        else:
+            out["cpu_baseline"] = None
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+    ks.close()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,73 @@
+/*
+ * peba1_circuits.h -- C ABI of libpeba1-circuits: the encrypted integer circuits
+ * and the protocol function f of lab-incert/peba1, re-expressed over the boots*
+ * gate API so that they issue the reference's gate sequence gate for gate.
+ *
+ * Each entry cites the reference function it mirrors (/root/reference/src/Math.cpp
+ * and include/Math.h).  The reference passes templates as std::vector<LweSample*>;
+ * here they are pointer arrays plus a slot count.  The library only calls the
+ * public tfhe API, so it runs over libtfhe-hip (GPU) or any other provider of
+ * those symbols.  With tfhe_hip_set_deferred(1) a whole circuit is recorded and
+ * executed as levelised batches at the next flush/decrypt.
+ */
+#ifndef PEBA1_CIRCUITS_H
+#define PEBA1_CIRCUITS_H
+
+#include "tfhe/tfhe.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* Math.cpp:27-50   bootsADD1bit: full adder, 7 bootstraps, carry updated in place */
+void peba1_add_1bit(LweSample *result, LweSample *a, LweSample *b, LweSample *carry,
+                    const TFheGateBootstrappingCloudKeySet *ck);
+/* Math.cpp:54-67   bootsADDNbit: ripple-carry adder, carry-out in carry[0] */
+void peba1_add_nbit(LweSample *result, LweSample *a, LweSample *b, LweSample *carry, int bitsize,
+                    const TFheGateBootstrappingCloudKeySet *ck);
+/* Math.cpp:71-93   bootsTwoSComplement */
+void peba1_twos_complement(LweSample *result, LweSample *a, int bitsize, const TFheGateBootstrappingCloudKeySet *ck);
+/* Math.cpp:97-119  bootsABS */
+void peba1_abs(LweSample *result, LweSample *a, int bitsize, const TFheGateBootstrappingCloudKeySet *ck);
+/* Math.cpp:123-180 bootsSUBNbit: result (bitsize+1 samples) = |a - b| */
+void peba1_sub_nbit(LweSample *result, LweSample *a, LweSample *b, int bitsize,
+                    const TFheGateBootstrappingCloudKeySet *ck);
+/* Math.cpp:183-211 bootsShiftLeft / bootsShiftRight / bootsShiftLeftNR */
+void peba1_shift_left(LweSample *result, LweSample *a, int bitsize, int n, const TFheGateBootstrappingCloudKeySet *ck);
+void peba1_shift_right(LweSample *result, LweSample *a, int bitsize, int n, const TFheGateBootstrappingCloudKeySet *ck);
+void peba1_shift_left_inplace(LweSample *a, int bitsize, int n, const TFheGateBootstrappingCloudKeySet *ck);
+/* Math.cpp:214-250 bootsMultiply: shift-and-add, result is 23 samples (the
+ * reference hard-codes length 23) */
+void peba1_multiply(LweSample *result, LweSample *a, LweSample *b, int bitsize,
+                    const TFheGateBootstrappingCloudKeySet *ck);
+/* Math.cpp:259-262 compare_bit */
+void peba1_compare_bit(LweSample *result, const LweSample *a, const LweSample *b, const LweSample *lsb_carry,
+                       LweSample *tmp, const TFheGateBootstrappingCloudKeySet *ck);
+/* Math.cpp:265-286 minimum: result = min(a,b), bit[0] = (a > b) */
+void peba1_minimum(LweSample *result, LweSample *bit, const LweSample *a, const LweSample *b, int nb_bits,
+                   const TFheGateBootstrappingCloudKeySet *ck);
+/* Math.cpp:333-369 HE_EuclideanDistance: result (24 samples) += sum_i (b_i - a_i)^2 */
+void peba1_euclidean_distance(LweSample *result, LweSample *const *a, LweSample *const *b, int nslots, int bitsize,
+                              const TFheGateBootstrappingCloudKeySet *ck);
+/* Math.cpp:379-387 Function_f: result_b[0] = (distance > bound); result_b has 3*bitsize samples */
+void peba1_function_f(LweSample *result_b, LweSample *const *a, LweSample *const *b, int nslots,
+                      LweSample *bound_match, int bitsize, const TFheGateBootstrappingCloudKeySet *ck);
+/* Math.cpp:390-417 Function_g with the reference's heap overflow fixed:
+ * result (bitsize samples) = result_b ? r1 : r0, computed as (1-b)*r0 + b*r1 */
+void peba1_function_g(LweSample *result, LweSample *result_b, LweSample *r0, LweSample *r1, int bitsize,
+                      const TFheGateBootstrappingCloudKeySet *ck);
+
+/* Slot-sharded variant of the distance for multi-GPU runs: the
+ * partial sum of squares over slots [0, nslots) of this rank, 24 samples, with
+ * the accumulator explicitly zeroed first. */
+void peba1_partial_distance(LweSample *partial, LweSample *const *a, LweSample *const *b, int nslots, int bitsize,
+                            const TFheGateBootstrappingCloudKeySet *ck);
+/* rank-0 tail: distance = sum of `nparts` partial sums (each 24 samples, pairwise
+ * tree of 23-bit adders), then minimum against bound; result_b has 24 samples */
+void peba1_combine_and_compare(LweSample *result_b, LweSample *const *partials, int nparts, LweSample *bound_match,
+                               const TFheGateBootstrappingCloudKeySet *ck);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -14,9 +14,11 @@ extern "C" {
 #endif
 
 /* ---- used by Math.o (10) ---- */
-/* Math.cpp:28-30 and 33 more sites.  Extension over upstream: new samples are
- * zero-filled (trivial encryption of phase 0), which makes Function_f's
- * uninitialised accumulator (Math.cpp:381-383) well defined. */
+/* Math.cpp:28-30 and 33 more sites.  Defined behaviour where upstream has none:
+ * a new sample is the trivial encryption of bit 0, (a = 0, b = -1/8), exactly
+ * what bootsCONSTANT(.., 0) writes (upstream leaves a[] uninitialised).  That
+ * makes Function_f's never-initialised accumulator (Math.cpp:381-383)
+ * act as the number 0 instead of sitting on every gate's decision boundary. */
 LweSample *new_gate_bootstrapping_ciphertext_array(int32_t nbelems, const TFheGateBootstrappingParameterSet *params);
 /* Math.cpp:47-49 and 33 more sites */
 void delete_gate_bootstrapping_ciphertext_array(int32_t nbelems, LweSample *samples);

@@ -15,3 +15,7 @@ $CXX $HOSTFLAGS -c shim.cpp -o shim.o &
 wait -n; wait -n; wait -n; wait -n
 $HIPCC -shared -o $OUT kernels.o host_keys.o engine.o shim.o
 echo "built $(realpath $OUT)"
+# circuits: calls only the public tfhe API; symbols resolve at load time against
+# whichever provider is loaded first (libtfhe-hip.so, or the tests' plain mock)
+$CXX $FLAGS -I../../include -shared -o ../libpeba1-circuits.so circuits.cpp
+echo "built $(realpath ../libpeba1-circuits.so)"

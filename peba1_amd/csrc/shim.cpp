@@ -33,7 +33,7 @@ namespace {
 
 constexpr uint32_t ARRAY_MAGIC = 0x7F4E11A5u;
 constexpr int32_t SLOT_HOST = -1;   // value lives in the host mirror
-constexpr int32_t SLOT_ZERO = -2;   // fresh sample: trivial encryption of phase 0
+constexpr int32_t SLOT_ZERO = -2;   // fresh sample: trivial encryption of bit 0, (0, -1/8)
 
 // Hidden header in front of every LweSample array handed to the caller.
 struct alignas(16) ArrayHeader {
@@ -98,8 +98,8 @@ int32_t ensure_slot(const LweSample *cs, SlotPool *pool) {
     auto *s = const_cast<LweSample *>(cs);
     if (s->slot >= 0) return s->slot;
     if (s->slot == SLOT_ZERO) {
-        pool->retain(pool->zero_slot);
-        s->slot = pool->zero_slot;
+        pool->retain(pool->const_slot[0]);
+        s->slot = pool->const_slot[0];
         return s->slot;
     }
     const int32_t slot = pool->alloc();
@@ -308,7 +308,7 @@ LweSample *new_gate_bootstrapping_ciphertext_array(int32_t nbelems, const TFheGa
     auto *words = reinterpret_cast<Torus32 *>(mem + sizeof(ArrayHeader) + (size_t)nbelems * sizeof(LweSample));
     for (int32_t i = 0; i < nbelems; ++i) {
         samples[i].a = words + (size_t)i * n;
-        samples[i].b = 0;
+        samples[i].b = -(1 << 29);      // fresh = trivial encryption of 0, like bootsCONSTANT(.., 0)
         samples[i].slot = SLOT_ZERO;
         samples[i].current_variance = 0.0;
     }

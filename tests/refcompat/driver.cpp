@@ -1,0 +1,124 @@
+// driver.cpp -- TEST INFRASTRUCTURE.  Runs the known-answer scenarios of SURVEY.md 8c
+// over the plaintext-bit provider (tests/mock) and prints one JSON object.  Built twice:
+//   -DUSE_REFERENCE : against /root/reference/src/Math.cpp (compiled in a temp dir,
+//                     never copied), proving source compatibility of include/tfhe/*.h
+//   default         : against this repo's libpeba1-circuits
+// Equal output = same values, same gate counts, same gate sequence.
+#include <cstdint>
+#include <cstdio>
+#include <string>
+#include <vector>
+
+#ifdef USE_REFERENCE
+#include "Math.h"
+#else
+#include "peba1_circuits.h"
+#endif
+
+extern "C" {
+void mock_reset(void);
+void mock_counts(int64_t *out);
+uint64_t mock_trace_hash(void);
+int64_t mock_bootstraps(void);
+}
+
+static TFheGateBootstrappingParameterSet *params;
+static TFheGateBootstrappingSecretKeySet *key;
+static const TFheGateBootstrappingCloudKeySet *ck;
+
+static LweSample *enc(uint64_t v, int bits) {
+    LweSample *p = new_gate_bootstrapping_ciphertext_array(bits, params);
+    for (int i = 0; i < bits; ++i) bootsSymEncrypt(&p[i], (v >> i) & 1, key);
+    return p;
+}
+static uint64_t dec(LweSample *p, int bits) {
+    uint64_t v = 0;
+    for (int i = 0; i < bits; ++i) v |= (uint64_t)bootsSymDecrypt(&p[i], key) << i;
+    return v;
+}
+static void report(const char *name, uint64_t value, bool last = false) {
+    int64_t c[16];
+    mock_counts(c);
+    std::printf("  \"%s\": {\"value\": %llu, \"xor\": %lld, \"and\": %lld, \"or\": %lld, \"xnor\": %lld, \"mux\": %lld, "
+                "\"not\": %lld, \"copy\": %lld, \"const\": %lld, \"allocs\": %lld, \"uninit_reads\": %lld, "
+                "\"blind_rotates\": %lld, \"trace\": \"%016llx\"}%s\n",
+                name, (unsigned long long)value, (long long)c[0], (long long)c[1], (long long)c[2], (long long)c[3],
+                (long long)c[4], (long long)c[5], (long long)c[6], (long long)c[7], (long long)c[8], (long long)c[10],
+                (long long)mock_bootstraps(), (unsigned long long)mock_trace_hash(), last ? "" : ",");
+}
+
+#ifdef USE_REFERENCE
+#define ADDN(r, a, b, c, n) bootsADDNbit(r, a, b, c, n, ck)
+#define SUBN(r, a, b, n) bootsSUBNbit(r, a, b, n, ck)
+#define MULT(r, a, b, n) bootsMultiply(r, a, b, n, ck)
+#define TWOSC(r, a, n) bootsTwoSComplement(r, a, n, ck)
+#define EUCLID(r, a, b, n) HE_EuclideanDistance(r, a, b, n, ck)
+#define FUNC_F(r, a, b, bound, n) Function_f(r, a, b, bound, n, ck)
+#else
+#define ADDN(r, a, b, c, n) peba1_add_nbit(r, a, b, c, n, ck)
+#define SUBN(r, a, b, n) peba1_sub_nbit(r, a, b, n, ck)
+#define MULT(r, a, b, n) peba1_multiply(r, a, b, n, ck)
+#define TWOSC(r, a, n) peba1_twos_complement(r, a, n, ck)
+#define EUCLID(r, a, b, n) peba1_euclidean_distance(r, a.data(), b.data(), (int)a.size(), n, ck)
+#define FUNC_F(r, a, b, bound, n) peba1_function_f(r, a.data(), b.data(), (int)a.size(), bound, n, ck)
+#endif
+
+int main() {
+    params = new_default_gate_bootstrapping_parameters(128);
+    key = new_random_gate_bootstrapping_secret_keyset(params);
+    ck = &key->cloud;
+    const int nslots = 128, bits = 8;
+    std::vector<uint8_t> tmpl(nslots), genuine(nslots), impostor(nslots);
+    for (int i = 0; i < nslots; ++i) {
+        tmpl[i] = (uint8_t)((37 * i + 11) % 255);
+        genuine[i] = (uint8_t)(tmpl[i] + 1);
+        impostor[i] = (uint8_t)((91 * i + 5) % 256);
+    }
+    std::printf("{\n");
+    {
+        LweSample *a = enc(122, 8), *b = enc(204, 8), *r = new_gate_bootstrapping_ciphertext_array(8, params),
+                  *c = new_gate_bootstrapping_ciphertext_array(1, params);
+        mock_reset();
+        ADDN(r, a, b, c, 8);
+        report("addn8_122_204", dec(r, 8) | (dec(c, 1) << 8));
+    }
+    {
+        LweSample *a = enc(5, 8), *r = new_gate_bootstrapping_ciphertext_array(9, params);
+        mock_reset();
+        TWOSC(r, a, 8);
+        report("twosc8_5", dec(r, 8));
+    }
+    {
+        LweSample *a = enc(122, 8), *b = enc(204, 8), *r = new_gate_bootstrapping_ciphertext_array(9, params);
+        mock_reset();
+        SUBN(r, a, b, 8);
+        report("subn8_122_204", dec(r, 9));
+    }
+    {
+        LweSample *a = enc(122, 9), *b = enc(204, 9), *r = new_gate_bootstrapping_ciphertext_array(24, params);
+        mock_reset();
+        MULT(r, a, b, 8);
+        report("mult8_122_204", dec(r, 23));
+    }
+    std::vector<LweSample *> et(nslots), eg(nslots), ei(nslots);
+    for (int i = 0; i < nslots; ++i) { et[i] = enc(tmpl[i], 8); eg[i] = enc(genuine[i], 8); ei[i] = enc(impostor[i], 8); }
+    for (int which = 0; which < 2; ++which) {
+        LweSample *r = new_gate_bootstrapping_ciphertext_array(24, params);
+        for (int i = 0; i < 24; ++i) bootsCONSTANT(&r[i], 0, ck);     // main.cpp:498-500 zeroes it first
+        mock_reset();
+        if (which == 0) { EUCLID(r, eg, et, bits); } else { EUCLID(r, ei, et, bits); }
+        report(which == 0 ? "euclid128_genuine" : "euclid128_impostor", dec(r, 24));
+    }
+    const uint64_t bounds[2] = {0, 256};
+    for (int bi = 0; bi < 2; ++bi)
+        for (int which = 0; which < 2; ++which) {
+            LweSample *bound = enc(bounds[bi], 24), *rb = new_gate_bootstrapping_ciphertext_array(24, params);
+            mock_reset();
+            if (which == 0) { FUNC_F(rb, eg, et, bound, bits); } else { FUNC_F(rb, ei, et, bound, bits); }
+            const std::string name = std::string("function_f_") + (which == 0 ? "genuine" : "impostor") + "_bound" +
+                                     std::to_string(bounds[bi]);
+            report(name.c_str(), dec(rb, 24), bi == 1 && which == 1);
+        }
+    std::printf("}\n");
+    return 0;
+}

@@ -119,7 +119,8 @@ def test_deferred_chain_with_overwrite_and_free(p128_keys, oracle):
 
 
 def test_fresh_samples_are_trivial_zero(p128_keys, oracle):
-    """Function_f reads never-written samples; the shim defines them as phase 0."""
+    """Function_f reads never-written samples; the shim defines them as the
+    trivial encryption of bit 0, i.e. what bootsCONSTANT(.., 0) writes."""
     from peba1_amd import api, lib
     pp, ks, oks = p128_keys
     L = lib.load()
@@ -128,6 +129,6 @@ def test_fresh_samples_are_trivial_zero(p128_keys, oracle):
     fresh = api.CiphertextArray(pp, 1)
     r = api.CiphertextArray(pp, 1)
     L.bootsXOR(r.at(0), one.at(0), fresh.at(0), ks.cloud)
-    zero = np.zeros(pp.words, dtype=np.int32)
-    assert (r.words()[0] == oks.gate("XOR", one.words()[0], zero)).all()
-    assert fresh.decrypt(ks)[0] == 0
+    assert (fresh.words()[0] == oks.constant(0)).all()
+    assert (r.words()[0] == oks.gate("XOR", one.words()[0], oks.constant(0))).all()
+    assert fresh.decrypt(ks)[0] == 0 and r.decrypt(ks)[0] == 1
