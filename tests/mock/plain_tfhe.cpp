@@ -94,4 +94,15 @@ void bootsMUX(LweSample *r, const LweSample *a, const LweSample *b, const LweSam
     wr(r, va ? vb : vc);
 }
 
+// raw words of the plaintext "ciphertext": n = 1 mask word (always 0) then the bit
+int32_t tfhe_hip_sample_words(const TFheGateBootstrappingParameterSet *) { return 2; }
+int tfhe_hip_export_samples(const LweSample *s, int32_t count, const TFheGateBootstrappingParameterSet *, Torus32 *out) {
+    for (int32_t i = 0; i < count; ++i) { out[2 * i] = 0; out[2 * i + 1] = rd(&s[i]); }
+    return 0;
+}
+int tfhe_hip_import_samples(LweSample *s, int32_t count, const TFheGateBootstrappingParameterSet *, const Torus32 *in) {
+    for (int32_t i = 0; i < count; ++i) wr(&s[i], in[2 * i + 1]);
+    return 0;
+}
+
 }  // extern "C"

