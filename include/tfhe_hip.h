@@ -82,6 +82,12 @@ int tfhe_hip_flush(void);   /* returns the number of levels executed, <0 on erro
 int tfhe_hip_gate_batch(int gate, LweSample *result, const LweSample *a, const LweSample *b,
                         int32_t count, const TFheGateBootstrappingCloudKeySet *bk);
 
+/* ---- tuning (results never depend on these) ----
+ * "br4_max_rotations": launches of at most this many blind rotations use the
+ * 4-wave latency kernel instead of the 2-wave throughput kernel (default 512,
+ * env TFHE_HIP_BR4_MAX); 0 disables it.  Returns 0, or -1 for an unknown name. */
+int tfhe_hip_set_tuning(const char *name, int64_t value);
+
 /* ---- statistics ---- */
 typedef struct TfheHipStats {
     uint64_t blind_rotates;     /* K2 instances */

@@ -140,6 +140,11 @@ def flush():
     return _l.load().tfhe_hip_flush()
 
 
+def set_tuning(name, value):
+    if _l.load().tfhe_hip_set_tuning(name.encode(), int(value)) != 0:
+        raise ValueError(last_error())
+
+
 def stats():
     s = _l.Stats()
     _l.load().tfhe_hip_get_stats(C.byref(s))

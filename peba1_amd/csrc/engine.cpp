@@ -74,6 +74,7 @@ void Engine::ensure_init() {
     if (hipGetDeviceCount(&count) != hipSuccess || count == 0)
         fatal("no HIP device available: libtfhe-hip evaluates gates on the GPU only (there is no CPU fallback)");
     if (const char *env = std::getenv("TFHE_HIP_DEVICE")) device_ = std::atoi(env);
+    if (const char *env = std::getenv("TFHE_HIP_BR4_MAX")) br4_max_rotations = std::atoi(env);
     hip_check(hipSetDevice(device_), "hipSetDevice");
     hip_check(hipStreamCreateWithFlags(&stream_, hipStreamNonBlocking), "hipStreamCreate");
     for (auto &e : ev_) hip_check(hipEventCreate(&e), "hipEventCreate");
@@ -248,6 +249,12 @@ void Engine::read_slots_packed(SlotPool *pool, const int32_t *slots, int count, 
     hip_check(hipStreamSynchronize(stream_), "gather slots");
 }
 
+void Engine::launch_br(const DeviceKeyImage *key, const int32_t *pool, const RotDesc *rots, int count, int32_t *u_buf,
+                       int32_t *acc_dbg) {
+    if (count <= br4_max_rotations) launch_blind_rotate4(stream_, key->dp, key->key, pool, rots, count, u_buf, acc_dbg);
+    else launch_blind_rotate(stream_, key->dp, key->key, pool, rots, count, u_buf, acc_dbg);
+}
+
 void Engine::execute(const DeviceKeyImage *key, SlotPool *pool, const LevelPlan &plan) {
     const auto t0 = std::chrono::steady_clock::now();
     const int levels = (int)plan.rot_off.size() - 1;
@@ -269,7 +276,7 @@ void Engine::execute(const DeviceKeyImage *key, SlotPool *pool, const LevelPlan 
         const int nks = plan.ks_off[L + 1] - plan.ks_off[L];
         const int nnot = plan.not_off[L + 2] - plan.not_off[L + 1];
         if (kernel_timing) hip_check(hipEventRecord(ev_[0], stream_), "event");
-        launch_blind_rotate(stream_, key->dp, key->key, pool->data(), drots + plan.rot_off[L], nrot, u_buf, nullptr);
+        launch_br(key, pool->data(), drots + plan.rot_off[L], nrot, u_buf, nullptr);
         if (kernel_timing) hip_check(hipEventRecord(ev_[1], stream_), "event");
         launch_keyswitch(stream_, key->dp, key->key, u_buf, dks + plan.ks_off[L], nks, pool->data());
         if (kernel_timing) hip_check(hipEventRecord(ev_[2], stream_), "event");
@@ -309,7 +316,7 @@ void Engine::run_bootstrap_woks(const DeviceKeyImage *key, const Torus32 *lin, i
     hip_check(hipMemcpyAsync(drots, rots.data(), rots.size() * sizeof(RotDesc), hipMemcpyHostToDevice, stream_), "upload rots");
     int32_t *u_buf = static_cast<int32_t *>(scratch(5, (size_t)count * dp.u_stride * 4));
     int32_t *dacc = acc_out ? static_cast<int32_t *>(scratch(7, (size_t)count * 2 * dp.N * 4)) : nullptr;
-    launch_blind_rotate(stream_, dp, key->key, dpool, drots, count, u_buf, dacc);
+    launch_br(key, dpool, drots, count, u_buf, dacc);
     hip_check(hipGetLastError(), "blind_rotate launch");
     std::vector<int32_t> ubuf((size_t)count * dp.u_stride);
     hip_check(hipMemcpyAsync(ubuf.data(), u_buf, ubuf.size() * 4, hipMemcpyDeviceToHost, stream_), "download u");

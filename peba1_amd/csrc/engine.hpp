@@ -87,6 +87,10 @@ public:
 
     TfheHipStats stats{};
     bool kernel_timing = false;
+    // launches of at most this many rotations use the 4-wave latency kernel (2 workgroups per CU)
+    int br4_max_rotations = 512;
+    void launch_br(const DeviceKeyImage *key, const int32_t *pool, const RotDesc *rots, int count, int32_t *u_buf,
+                   int32_t *acc_dbg);
 
 private:
     Engine() = default;

@@ -30,25 +30,22 @@ __device__ __forceinline__ PrimeCtx make_ctx(int q, const uint32_t *tw) {
     PrimeCtx c;
     c.P = q ? NTT_P1 : NTT_P0;
     c.pinv = q ? NTT_PINV1 : NTT_PINV0;
-    c.P2 = 2u * c.P;
+    c.rmod = q ? NTT_R[1] : NTT_R[0];
     c.wf = tw + (size_t)(q * 2 + 0) * NTT_N;
     c.wi = tw + (size_t)(q * 2 + 1) * NTT_N;
     return c;
 }
 
-// acc64 (sum of <= 6 products x*bk, x < 21P, bk < P) -> canonical-range input of
-// the inverse NTT, the inverse NTT itself, and the final canonical residue
-__device__ __forceinline__ void finish_inverse(const uint64_t (&acc)[16], uint32_t (&y)[16],
+// acc64 (sum of <= 6 products x*bk, |x| < 10.1P, 0 <= bk < P, so |acc| < 2^60) ->
+// Montgomery reduction (|.| < 2.4P), inverse NTT, canonical residue in [0,P)
+__device__ __forceinline__ void finish_inverse(const int64_t (&acc)[16], uint32_t (&y)[16],
                                                const PrimeCtx &c, uint32_t *scr, int lane) {
+    int32_t t[16];
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
-        uint32_t t = mont_redc(acc[r], c.P, c.pinv);   // < 5P
-        t = csub(t, 2u * c.P2);                        // < 4P
-        y[r] = csub(t, c.P2);                          // < 2P
-    }
-    ntt_inv_1024(y, c, scr, lane);
+    for (int r = 0; r < 16; ++r) t[r] = mont_redc(acc[r], c.P, c.pinv);
+    ntt_inv_1024(t, c, scr, lane);
 #pragma unroll
-    for (int r = 0; r < 16; ++r) y[r] = csub(y[r], c.P);
+    for (int r = 0; r < 16; ++r) y[r] = canon(t[r], c.P);
 }
 
 // ---------------------------------------------------------------------------
@@ -68,20 +65,20 @@ __global__ __launch_bounds__(64) void bk_transform_kernel(const int32_t *__restr
     const PrimeCtx c = make_ctx(q, tw);
     const uint32_t scale = q ? scale1 : scale0;
     const int32_t *src = raw + (size_t)poly * NTT_N;
-    uint32_t x[16];
+    int32_t x[16];
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
-        int32_t m = src[r * 64 + lane] % (int32_t)c.P;
-        if (m < 0) m += (int32_t)c.P;
-        x[r] = (uint32_t)m;
-    }
-    ntt_fwd_1024(x, c, scr, lane);
+    for (int r = 0; r < 16; ++r) x[r] = src[r * 64 + lane] % (int32_t)c.P;     // |x| < P
+    ntt_fwd_1024(x, c, scr, lane);                                             // |x| < 11P
     uint4 *dst = reinterpret_cast<uint4 *>(img + ((size_t)(X * 2 + q) * nw + w) * NTT_N) + lane;
 #pragma unroll
     for (int g = 0; g < 4; ++g) {
         uint32_t v[4];
 #pragma unroll
-        for (int e = 0; e < 4; ++e) v[e] = (uint32_t)((uint64_t)(x[4 * g + e] % c.P) * scale % c.P);
+        for (int e = 0; e < 4; ++e) {
+            int32_t m = x[4 * g + e] % (int32_t)c.P;
+            if (m < 0) m += (int32_t)c.P;
+            v[e] = (uint32_t)((uint64_t)(uint32_t)m * scale % c.P);
+        }
         dst[g * 64] = make_uint4(v[0], v[1], v[2], v[3]);
     }
 }
@@ -98,22 +95,19 @@ __global__ __launch_bounds__(128) void negacyclic_kernel(const int32_t *__restri
     const PrimeCtx c = make_ctx(q, tw);
     uint32_t *scr = lds_scr[q];
     const int32_t *src = ip + (size_t)blockIdx.x * NTT_N;
-    uint32_t x[16];
+    int32_t x[16];
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
-        const int32_t v = src[r * 64 + lane];
-        x[r] = v < 0 ? (uint32_t)(v + (int32_t)c.P) : (uint32_t)v;
-    }
+    for (int r = 0; r < 16; ++r) x[r] = src[r * 64 + lane];
     ntt_fwd_1024(x, c, scr, lane);
     const uint4 *bp = reinterpret_cast<const uint4 *>(img + (size_t)(blockIdx.x * 2 + q) * NTT_N) + lane;
-    uint64_t acc[16];
+    int64_t acc[16];
 #pragma unroll
     for (int g = 0; g < 4; ++g) {
         const uint4 b = bp[g * 64];
-        acc[4 * g + 0] = (uint64_t)x[4 * g + 0] * b.x;
-        acc[4 * g + 1] = (uint64_t)x[4 * g + 1] * b.y;
-        acc[4 * g + 2] = (uint64_t)x[4 * g + 2] * b.z;
-        acc[4 * g + 3] = (uint64_t)x[4 * g + 3] * b.w;
+        acc[4 * g + 0] = (int64_t)x[4 * g + 0] * (int32_t)b.x;
+        acc[4 * g + 1] = (int64_t)x[4 * g + 1] * (int32_t)b.y;
+        acc[4 * g + 2] = (int64_t)x[4 * g + 2] * (int32_t)b.z;
+        acc[4 * g + 3] = (int64_t)x[4 * g + 3] * (int32_t)b.w;
     }
     uint32_t y[16];
     finish_inverse(acc, y, c, scr, lane);
@@ -129,7 +123,95 @@ __global__ __launch_bounds__(128) void negacyclic_kernel(const int32_t *__restri
 }
 
 // ---------------------------------------------------------------------------
-// K1+K2: blind rotate.  grid = rotations, 128 threads.
+// shared pieces of the blind-rotate kernels
+// ---------------------------------------------------------------------------
+struct StepConsts {
+    uint32_t dmask;      // Bg - 1
+    int32_t half;        // Bg/2
+};
+
+// K1: t = (0,c0) + sa*A + sb*B, modulus switch to Z_{2N} (tfhe modSwitchFromTorus32), N = 1024
+template <int THREADS>
+__device__ __forceinline__ void prelude_modswitch(const DevParams &p, const RotDesc &rd, const int32_t *__restrict__ pool,
+                                                  uint16_t *lds_bar, int tid) {
+    const int32_t *A = pool + (size_t)rd.slot_a * p.ct_stride;
+    const int32_t *B = pool + (size_t)rd.slot_b * p.ct_stride;
+    for (int i = tid; i <= p.n; i += THREADS) {
+        uint32_t t = (uint32_t)rd.sa * (uint32_t)A[i] + (uint32_t)rd.sb * (uint32_t)B[i];
+        if (i == p.n) t += (uint32_t)rd.c0;
+        lds_bar[i] = (uint16_t)((t + (1u << 20)) >> 21);     // round(t * 2N / 2^32) mod 2N
+    }
+}
+
+// body polynomial of ACC = (0, X^{-barb} * (mu + mu X + ... + mu X^{N-1})), coefficient j
+__device__ __forceinline__ uint32_t testvector_coef(int j, int barb, int32_t mu) {
+    const int idx = (j + barb) & (2 * NTT_N - 1);
+    return (idx & NTT_N) ? (uint32_t)(-mu) : (uint32_t)mu;
+}
+
+// One input polynomial u of one blind-rotate step, modulo the wave's prime:
+// D = (X^abar - 1) * ACC_u, its l gadget digits, forward NTT of each, and the
+// multiply-accumulate against key rows u*l+jj for both output polynomials
+// (acc0 <- output poly 0, acc1 <- output poly 1; exchanged when swap_outputs).
+__device__ __forceinline__ void forward_poly(const DevParams &p, const DevKey &key, const PrimeCtx &c,
+                                             const StepConsts &sc, const uint32_t *lds_acc_u, uint32_t *scr,
+                                             int lane, int q, int i, int u, int abar, bool swap_outputs,
+                                             int64_t (&acc0)[16], int64_t (&acc1)[16]) {
+    uint32_t D[16];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const int j = r * 64 + lane;
+        const int idx = (j - abar) & (2 * NTT_N - 1);
+        const uint32_t v = lds_acc_u[idx & (NTT_N - 1)];
+        D[r] = ((idx & NTT_N) ? 0u - v : v) - lds_acc_u[j] + p.decomp_offset;   // offset pre-added
+    }
+#pragma unroll 1
+    for (int jj = 0; jj < p.l; ++jj) {
+        const int prow = u * p.l + jj;
+        const uint4 *bp = reinterpret_cast<const uint4 *>(
+                              key.bk_img + ((size_t)((size_t)i * p.kpl + prow) * 2 + q) * 2 * NTT_N) + lane;
+        uint4 b0[4], b1[4];
+        const int o0 = swap_outputs ? 256 : 0, o1 = 256 - o0;      // uint4 offset of output poly 0 / 1
+#pragma unroll
+        for (int g = 0; g < 4; ++g) { b0[g] = bp[o0 + g * 64]; b1[g] = bp[o1 + g * 64]; }
+
+        const int shift = 32 - (jj + 1) * p.Bgbit;
+        int32_t x[16];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) x[r] = (int32_t)((D[r] >> shift) & sc.dmask) - sc.half;   // signed digit
+        ntt_fwd_1024(x, c, scr, lane);
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            acc0[4 * g + 0] += (int64_t)x[4 * g + 0] * (int32_t)b0[g].x;
+            acc0[4 * g + 1] += (int64_t)x[4 * g + 1] * (int32_t)b0[g].y;
+            acc0[4 * g + 2] += (int64_t)x[4 * g + 2] * (int32_t)b0[g].z;
+            acc0[4 * g + 3] += (int64_t)x[4 * g + 3] * (int32_t)b0[g].w;
+            acc1[4 * g + 0] += (int64_t)x[4 * g + 0] * (int32_t)b1[g].x;
+            acc1[4 * g + 1] += (int64_t)x[4 * g + 1] * (int32_t)b1[g].y;
+            acc1[4 * g + 2] += (int64_t)x[4 * g + 2] * (int32_t)b1[g].z;
+            acc1[4 * g + 3] += (int64_t)x[4 * g + 3] * (int32_t)b1[g].w;
+        }
+    }
+}
+
+// sample extract at index 0 (tfhe tLweExtractLweSampleIndex) + optional raw accumulator dump
+template <int THREADS>
+__device__ __forceinline__ void extract_sample(const DevParams &p, const RotDesc &rd, const uint32_t (*lds_acc)[NTT_N],
+                                               int32_t *__restrict__ u_buf, int32_t *__restrict__ acc_dbg, int tid) {
+    int32_t *u = u_buf + (size_t)rd.u_index * p.u_stride;
+    for (int j = tid; j < NTT_N; j += THREADS)
+        u[j] = (int32_t)(j == 0 ? lds_acc[0][0] : 0u - lds_acc[0][NTT_N - j]);
+    if (tid == 0) u[NTT_N] = (int32_t)lds_acc[1][0];
+    if (acc_dbg) {
+        int32_t *d = acc_dbg + (size_t)blockIdx.x * 2 * NTT_N;
+        for (int j = tid; j < 2 * NTT_N; j += THREADS) d[j] = (int32_t)lds_acc[j >> 10][j & (NTT_N - 1)];
+    }
+}
+
+// ---------------------------------------------------------------------------
+// K1+K2: blind rotate, throughput form.  grid = rotations, 128 threads: wave q
+// works modulo prime q and handles both input polynomials (6 forward + 2
+// inverse NTTs per step), 4 workgroups per CU.
 // ---------------------------------------------------------------------------
 __global__ __launch_bounds__(128) void blind_rotate_kernel(DevParams p, DevKey key, const int32_t *__restrict__ pool,
                                                            const RotDesc *__restrict__ rots,
@@ -146,112 +228,141 @@ __global__ __launch_bounds__(128) void blind_rotate_kernel(DevParams p, DevKey k
     const RotDesc rd = rots[blockIdx.x];
     const int n = p.n;
 
-    // K1: t = (0,c0) + sa*A + sb*B, modulus switch to Z_{2N} (tfhe modSwitchFromTorus32)
-    {
-        const int32_t *A = pool + (size_t)rd.slot_a * p.ct_stride;
-        const int32_t *B = pool + (size_t)rd.slot_b * p.ct_stride;
-        for (int i = tid; i <= n; i += 128) {
-            uint32_t t = (uint32_t)rd.sa * (uint32_t)A[i] + (uint32_t)rd.sb * (uint32_t)B[i];
-            if (i == n) t += (uint32_t)rd.c0;
-            lds_bar[i] = (uint16_t)((t + (1u << 20)) >> 21);     // round(t * 2N / 2^32) mod 2N, N = 1024
-        }
-    }
+    prelude_modswitch<128>(p, rd, pool, lds_bar, tid);
     __syncthreads();
-    {   // ACC = (0, X^{-barb} * (mu + mu X + ... + mu X^{N-1}))
+    {
         const int barb = lds_bar[n];
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             const int j = r * 64 + lane;
-            const int idx = (j + barb) & (2 * NTT_N - 1);
-            lds_acc[q][j] = q == 0 ? 0u : ((idx & NTT_N) ? (uint32_t)(-p.mu) : (uint32_t)p.mu);
+            lds_acc[q][j] = q == 0 ? 0u : testvector_coef(j, barb, p.mu);
         }
     }
     __syncthreads();
 
-    const uint32_t dmask = (1u << p.Bgbit) - 1u;
-    const uint32_t dbias = c.P - (1u << (p.Bgbit - 1));   // P - Bg/2
-    const int kpl = p.kpl;
+    const StepConsts sc{(1u << p.Bgbit) - 1u, 1 << (p.Bgbit - 1)};
 
     for (int i = 0; i < n; ++i) {
         const int abar = __builtin_amdgcn_readfirstlane((int)lds_bar[i]);
         if (abar == 0) continue;                            // tfhe_blindRotate_FFT skips these too
 
-        uint64_t acc0[16], acc1[16];
+        int64_t acc0[16], acc1[16];
 #pragma unroll
         for (int r = 0; r < 16; ++r) { acc0[r] = 0; acc1[r] = 0; }
-
 #pragma unroll 1
-        for (int u = 0; u < 2; ++u) {
-            // D = (X^abar - 1) * ACC_u, with the decomposition offset pre-added
-            uint32_t D[16];
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int j = r * 64 + lane;
-                const int idx = (j - abar) & (2 * NTT_N - 1);
-                const uint32_t v = lds_acc[u][idx & (NTT_N - 1)];
-                D[r] = ((idx & NTT_N) ? 0u - v : v) - lds_acc[u][j] + p.decomp_offset;
-            }
-#pragma unroll 1
-            for (int jj = 0; jj < p.l; ++jj) {
-                const int prow = u * p.l + jj;
-                const uint4 *bp = reinterpret_cast<const uint4 *>(
-                                      key.bk_img + ((size_t)((size_t)i * kpl + prow) * 2 + q) * 2 * NTT_N) + lane;
-                uint4 b0[4], b1[4];
-#pragma unroll
-                for (int g = 0; g < 4; ++g) { b0[g] = bp[g * 64]; b1[g] = bp[256 + g * 64]; }
-
-                const int shift = 32 - (jj + 1) * p.Bgbit;
-                uint32_t x[16];
-#pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const uint32_t xx = ((D[r] >> shift) & dmask) + dbias;   // digit + P
-                    x[r] = min(xx, xx - c.P);                               // digit mod P
-                }
-                ntt_fwd_1024(x, c, scr, lane);
-#pragma unroll
-                for (int g = 0; g < 4; ++g) {
-                    acc0[4 * g + 0] += (uint64_t)x[4 * g + 0] * b0[g].x;
-                    acc0[4 * g + 1] += (uint64_t)x[4 * g + 1] * b0[g].y;
-                    acc0[4 * g + 2] += (uint64_t)x[4 * g + 2] * b0[g].z;
-                    acc0[4 * g + 3] += (uint64_t)x[4 * g + 3] * b0[g].w;
-                    acc1[4 * g + 0] += (uint64_t)x[4 * g + 0] * b1[g].x;
-                    acc1[4 * g + 1] += (uint64_t)x[4 * g + 1] * b1[g].y;
-                    acc1[4 * g + 2] += (uint64_t)x[4 * g + 2] * b1[g].z;
-                    acc1[4 * g + 3] += (uint64_t)x[4 * g + 3] * b1[g].w;
-                }
-            }
-        }
+        for (int u = 0; u < 2; ++u) forward_poly(p, key, c, sc, lds_acc[u], scr, lane, q, i, u, abar, false, acc0, acc1);
 
         uint32_t y0[16], y1[16];
         finish_inverse(acc0, y0, c, scr, lane);
         finish_inverse(acc1, y1, c, scr, lane);
 
         // wave q owns output polynomial q: send the other one's residues across
+        const uint32_t *oscr = lds_scr[1 - q];
+        if (q == 0) {
 #pragma unroll
-        for (int r = 0; r < 16; ++r) scr[r * 64 + lane] = q == 0 ? y1[r] : y0[r];
-        __syncthreads();
-        {
-            const uint32_t *oscr = lds_scr[1 - q];
+            for (int r = 0; r < 16; ++r) scr[r * 64 + lane] = y1[r];
+            __syncthreads();
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const uint32_t other = oscr[r * 64 + lane];
-                const uint32_t r0 = q == 0 ? y0[r] : other;
-                const uint32_t r1 = q == 0 ? other : y1[r];
-                lds_acc[q][r * 64 + lane] += crt_to_torus(r0, r1);
-            }
+            for (int r = 0; r < 16; ++r) lds_acc[0][r * 64 + lane] += crt_to_torus(y0[r], oscr[r * 64 + lane]);
+        } else {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) scr[r * 64 + lane] = y0[r];
+            __syncthreads();
+#pragma unroll
+            for (int r = 0; r < 16; ++r) lds_acc[1][r * 64 + lane] += crt_to_torus(oscr[r * 64 + lane], y1[r]);
         }
         __syncthreads();
     }
+    extract_sample<128>(p, rd, lds_acc, u_buf, acc_dbg, tid);
+}
 
-    // sample extract at index 0 (tfhe tLweExtractLweSampleIndex)
-    int32_t *u = u_buf + (size_t)rd.u_index * p.u_stride;
-    for (int j = tid; j < NTT_N; j += 128)
-        u[j] = (int32_t)(j == 0 ? lds_acc[0][0] : 0u - lds_acc[0][NTT_N - j]);
-    if (tid == 0) u[NTT_N] = (int32_t)lds_acc[1][0];
-    if (acc_dbg) {
-        int32_t *d = acc_dbg + (size_t)blockIdx.x * 2 * NTT_N;
-        for (int j = tid; j < 2 * NTT_N; j += 128) d[j] = (int32_t)lds_acc[j >> 10][j & (NTT_N - 1)];
+// ---------------------------------------------------------------------------
+// K1+K2: blind rotate, latency form for narrow levels.  grid = rotations, 256
+// threads: wave (q,u) works modulo prime q on input polynomial u (3 forward
+// NTTs), hands the partial sum of the other output polynomial to wave (q,1-u),
+// runs ONE inverse NTT for output polynomial u, and shares the CRT with wave
+// (1-q,u).  Half the dependent work per wave of the throughput form; three
+// workgroup barriers per step.  Same integers, so bit-identical results.
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void blind_rotate4_kernel(DevParams p, DevKey key, const int32_t *__restrict__ pool,
+                                                            const RotDesc *__restrict__ rots,
+                                                            int32_t *__restrict__ u_buf, int32_t *__restrict__ acc_dbg) {
+    __shared__ __align__(16) uint32_t lds_acc[2][NTT_N];
+    __shared__ __align__(16) uint32_t lds_scr[4][NTT_SCRATCH_WORDS];
+    __shared__ __align__(16) uint32_t lds_x1[4][NTT_SCRATCH_WORDS];   // partial sums of the partner's output poly
+    __shared__ __align__(16) uint32_t lds_x2[4][NTT_N / 2];           // residues of the half the partner recombines
+    __shared__ uint16_t lds_bar[NTT_N + 8];
+
+    const int tid = threadIdx.x;
+    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int q = wv & 1, u = wv >> 1;
+    const int lane = tid & 63;
+    const PrimeCtx c = make_ctx(q, key.tw);
+    uint32_t *scr = lds_scr[wv];
+    const RotDesc rd = rots[blockIdx.x];
+    const int n = p.n;
+
+    prelude_modswitch<256>(p, rd, pool, lds_bar, tid);
+    __syncthreads();
+    if (q == 0) {
+        const int barb = lds_bar[n];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int j = r * 64 + lane;
+            lds_acc[u][j] = u == 0 ? 0u : testvector_coef(j, barb, p.mu);
+        }
     }
+    __syncthreads();
+
+    const StepConsts sc{(1u << p.Bgbit) - 1u, 1 << (p.Bgbit - 1)};
+
+    for (int i = 0; i < n; ++i) {
+        const int abar = __builtin_amdgcn_readfirstlane((int)lds_bar[i]);
+        if (abar == 0) continue;
+
+        int64_t acc0[16], acc1[16];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { acc0[r] = 0; acc1[r] = 0; }
+        // acc0 accumulates output poly u (kept), acc1 output poly 1-u (sent to wave (q,1-u))
+        forward_poly(p, key, c, sc, lds_acc[u], scr, lane, q, i, u, abar, u != 0, acc0, acc1);
+
+        int32_t t[16], send[16];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            t[r] = mont_redc(acc0[r], c.P, c.pinv);                // 3 rows: |.| < 1.45P
+            send[r] = mont_redc(acc1[r], c.P, c.pinv);
+        }
+        write_row16(send, lds_x1[wv], lane);
+        __syncthreads();
+        {
+            int32_t other[16];
+            read_row16(other, lds_x1[wv ^ 2], lane);
+#pragma unroll
+            for (int r = 0; r < 16; ++r) t[r] += other[r];         // |.| < 2.9P
+        }
+        ntt_inv_1024(t, c, scr, lane);
+        uint32_t y[16];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) y[r] = canon(t[r], c.P);
+
+        // CRT of output poly u is split with wave (1-q,u): wave q recombines registers [8q, 8q+8)
+        const uint32_t *ox = lds_x2[wv ^ 1];
+        if (q == 0) {
+#pragma unroll
+            for (int r = 0; r < 8; ++r) lds_x2[wv][r * 64 + lane] = y[8 + r];
+            __syncthreads();
+#pragma unroll
+            for (int r = 0; r < 8; ++r) lds_acc[u][r * 64 + lane] += crt_to_torus(y[r], ox[r * 64 + lane]);
+        } else {
+#pragma unroll
+            for (int r = 0; r < 8; ++r) lds_x2[wv][r * 64 + lane] = y[r];
+            __syncthreads();
+#pragma unroll
+            for (int r = 0; r < 8; ++r) lds_acc[u][(8 + r) * 64 + lane] += crt_to_torus(ox[r * 64 + lane], y[8 + r]);
+        }
+        __syncthreads();
+    }
+    extract_sample<256>(p, rd, lds_acc, u_buf, acc_dbg, tid);
 }
 
 // ---------------------------------------------------------------------------
@@ -352,6 +463,12 @@ void launch_blind_rotate(hipStream_t s, const DevParams &p, const DevKey &key, c
                          const RotDesc *rots, int count, int32_t *u_buf, int32_t *acc_dbg) {
     if (count <= 0) return;
     hipLaunchKernelGGL(blind_rotate_kernel, dim3(count), dim3(128), 0, s, p, key, pool, rots, u_buf, acc_dbg);
+}
+
+void launch_blind_rotate4(hipStream_t s, const DevParams &p, const DevKey &key, const int32_t *pool,
+                          const RotDesc *rots, int count, int32_t *u_buf, int32_t *acc_dbg) {
+    if (count <= 0) return;
+    hipLaunchKernelGGL(blind_rotate4_kernel, dim3(count), dim3(256), 0, s, p, key, pool, rots, u_buf, acc_dbg);
 }
 
 void launch_keyswitch(hipStream_t s, const DevParams &p, const DevKey &key, const int32_t *u_buf,

@@ -45,6 +45,9 @@ void launch_bk_transform(hipStream_t s, const DevParams &p, const int32_t *raw_p
                          const uint32_t *tw, int npoly_per_w, int nw, const uint32_t scale[2]);
 void launch_blind_rotate(hipStream_t s, const DevParams &p, const DevKey &key, const int32_t *pool,
                          const RotDesc *rots, int count, int32_t *u_buf, int32_t *acc_dbg);
+// latency form (4 waves per rotation), for launches that cannot fill the chip
+void launch_blind_rotate4(hipStream_t s, const DevParams &p, const DevKey &key, const int32_t *pool,
+                          const RotDesc *rots, int count, int32_t *u_buf, int32_t *acc_dbg);
 void launch_keyswitch(hipStream_t s, const DevParams &p, const DevKey &key, const int32_t *u_buf,
                       const KsDesc *descs, int count, int32_t *pool);
 void launch_not(hipStream_t s, const DevParams &p, const NotDesc *descs, int count, int32_t *pool);

@@ -572,6 +572,12 @@ int tfhe_hip_gate_batch(int gate, LweSample *result, const LweSample *a, const L
     return 0;
 }
 
+int tfhe_hip_set_tuning(const char *name, int64_t value) {
+    if (name && std::strcmp(name, "br4_max_rotations") == 0) { Engine::get().br4_max_rotations = (int)value; return 0; }
+    set_error(std::string("tfhe_hip_set_tuning: unknown name ") + (name ? name : "(null)"));
+    return -1;
+}
+
 void tfhe_hip_get_stats(TfheHipStats *out) { if (out) *out = Engine::get().stats; }
 void tfhe_hip_reset_stats(void) { Engine::get().stats = TfheHipStats{}; }
 void tfhe_hip_set_kernel_timing(int on) { Engine::get().kernel_timing = on != 0; }

@@ -50,6 +50,27 @@ def test_blind_rotate_matches_oracle(p128_keys, oracle):
         assert (u[c] == oks.sample_extract(want_acc)).all(), f"extract {c}"
 
 
+@pytest.mark.parametrize("br4_max", [0, 1 << 20])
+def test_both_blind_rotate_forms_are_bit_exact(p128_keys, oracle, br4_max):
+    """The 2-wave throughput kernel (br4_max=0) and the 4-wave latency kernel compute the same integers."""
+    from peba1_amd import api
+    _, ks, oks = p128_keys
+    r = oracle.Rng(23)
+    cts = oks.encrypt(r, [0, 1, 1, 1, 0, 0])
+    lins = np.stack([oks.prelude("OR", cts[0], cts[1]), oks.prelude("XNOR", cts[2], cts[3]),
+                     oks.prelude("ANDNY", cts[4], cts[5])])
+    api.set_tuning("br4_max_rotations", br4_max)
+    try:
+        u, acc = api.kernel_bootstrap_woks(ks, lins, want_acc=True)
+    finally:
+        api.set_tuning("br4_max_rotations", 512)
+    for c in range(3):
+        bar = oks.modswitch_ct(lins[c])
+        want_acc = oks.blind_rotate(bar[:-1], bar[-1])
+        assert (acc[c] == want_acc).all(), f"accumulator {c}"
+        assert (u[c] == oks.sample_extract(want_acc)).all()
+
+
 def test_blind_rotate_edge_inputs(p128_keys, oracle):
     """all-zero mask (every step skipped), barb = 0, and abar values at the wrap points."""
     from peba1_amd import api
