@@ -75,6 +75,7 @@ void Engine::ensure_init() {
         fatal("no HIP device available: libtfhe-hip evaluates gates on the GPU only (there is no CPU fallback)");
     if (const char *env = std::getenv("TFHE_HIP_DEVICE")) device_ = std::atoi(env);
     if (const char *env = std::getenv("TFHE_HIP_BR4_MAX")) br4_max_rotations = std::atoi(env);
+    if (const char *env = std::getenv("TFHE_HIP_KS_BLOCKS")) ks_target_blocks = std::atoi(env);
     hip_check(hipSetDevice(device_), "hipSetDevice");
     hip_check(hipStreamCreateWithFlags(&stream_, hipStreamNonBlocking), "hipStreamCreate");
     for (auto &e : ev_) hip_check(hipEventCreate(&e), "hipEventCreate");
@@ -255,6 +256,15 @@ void Engine::launch_br(const DeviceKeyImage *key, const int32_t *pool, const Rot
     else launch_blind_rotate(stream_, key->dp, key->key, pool, rots, count, u_buf, acc_dbg);
 }
 
+void Engine::launch_ks(const DeviceKeyImage *key, const int32_t *u_buf, const KsDesc *descs, int count, int32_t *pool) {
+    if (count <= 0) return;
+    int splits = 1;
+    while (splits < 32 && count * splits * 2 <= ks_target_blocks) splits *= 2;
+    int32_t *partial = nullptr;
+    if (splits > 1) partial = static_cast<int32_t *>(scratch(10, (size_t)count * splits * key->dp.ct_stride * 4));
+    launch_keyswitch(stream_, key->dp, key->key, u_buf, descs, count, pool, splits, partial);
+}
+
 void Engine::execute(const DeviceKeyImage *key, SlotPool *pool, const LevelPlan &plan) {
     const auto t0 = std::chrono::steady_clock::now();
     const int levels = (int)plan.rot_off.size() - 1;
@@ -278,7 +288,7 @@ void Engine::execute(const DeviceKeyImage *key, SlotPool *pool, const LevelPlan 
         if (kernel_timing) hip_check(hipEventRecord(ev_[0], stream_), "event");
         launch_br(key, pool->data(), drots + plan.rot_off[L], nrot, u_buf, nullptr);
         if (kernel_timing) hip_check(hipEventRecord(ev_[1], stream_), "event");
-        launch_keyswitch(stream_, key->dp, key->key, u_buf, dks + plan.ks_off[L], nks, pool->data());
+        launch_ks(key, u_buf, dks + plan.ks_off[L], nks, pool->data());
         if (kernel_timing) hip_check(hipEventRecord(ev_[2], stream_), "event");
         launch_not(stream_, key->dp, dnots + plan.not_off[L + 1], nnot, pool->data());
         if (kernel_timing) {
@@ -339,7 +349,7 @@ void Engine::run_keyswitch(const DeviceKeyImage *key, const Torus32 *u, int coun
     KsDesc *dks = static_cast<KsDesc *>(scratch(1, ks.size() * sizeof(KsDesc)));
     hip_check(hipMemcpyAsync(dks, ks.data(), ks.size() * sizeof(KsDesc), hipMemcpyHostToDevice, stream_), "upload ks");
     int32_t *dpool = static_cast<int32_t *>(scratch(6, (size_t)count * dp.ct_stride * 4));
-    launch_keyswitch(stream_, dp, key->key, u_buf, dks, count, dpool);
+    launch_ks(key, u_buf, dks, count, dpool);
     hip_check(hipGetLastError(), "keyswitch launch");
     std::vector<int32_t> res((size_t)count * dp.ct_stride);
     hip_check(hipMemcpyAsync(res.data(), dpool, res.size() * 4, hipMemcpyDeviceToHost, stream_), "download ks");

@@ -89,6 +89,9 @@ public:
     bool kernel_timing = false;
     // launches of at most this many rotations use the 4-wave latency kernel (2 workgroups per CU)
     int br4_max_rotations = 512;
+    // key switches of a launch are split so that about this many workgroups exist (power of two <= 32)
+    int ks_target_blocks = 2048;
+    void launch_ks(const DeviceKeyImage *key, const int32_t *u_buf, const KsDesc *descs, int count, int32_t *pool);
     void launch_br(const DeviceKeyImage *key, const int32_t *pool, const RotDesc *rots, int count, int32_t *u_buf,
                    int32_t *acc_dbg);
 

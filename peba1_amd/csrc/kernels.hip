@@ -372,22 +372,25 @@ __global__ __launch_bounds__(256) void blind_rotate4_kernel(DevParams p, DevKey 
 // ---------------------------------------------------------------------------
 constexpr int KS_THREADS = 192;
 
+// grid (gates, splits): block (g, s) handles input coefficients [s*nin/splits, (s+1)*nin/splits).
+// splits == 1: the result goes straight to the destination slot.  splits > 1 (narrow
+// levels, where one workgroup per gate would leave the chip idle and serialise 6,144
+// dependent row loads): partial sums go to `partial[g][s][ct_stride]` and
+// ks_reduce_kernel adds them (integer adds: any order is bit-exact).
 __global__ __launch_bounds__(KS_THREADS) void keyswitch_kernel(DevParams p, DevKey key, const int32_t *__restrict__ u_buf,
                                                                const KsDesc *__restrict__ descs,
-                                                               int32_t *__restrict__ pool) {
+                                                               int32_t *__restrict__ pool, int32_t *__restrict__ partial) {
     __shared__ uint32_t su[2048 + 8];
     const int tid = threadIdx.x;
     const KsDesc d = descs[blockIdx.x];
     const int nin = p.k * p.N;
+    const int splits = gridDim.y, split = blockIdx.y;
+    const int i0 = (int)((long long)nin * split / splits), i1 = (int)((long long)nin * (split + 1) / splits);
     {
         const int32_t *u0 = u_buf + (size_t)d.u0 * p.u_stride;
         const int32_t *u1 = d.u1 >= 0 ? u_buf + (size_t)d.u1 * p.u_stride : nullptr;
-        for (int j = tid; j <= nin; j += KS_THREADS) {
-            uint32_t v = (uint32_t)u0[j];
-            if (u1) v += (uint32_t)u1[j];
-            if (j == nin) v += (uint32_t)d.add_b;
-            su[j] = v;
-        }
+        for (int j = i0 + tid; j < i1; j += KS_THREADS) su[j - i0] = (uint32_t)u0[j] + (u1 ? (uint32_t)u1[j] : 0u);
+        if (tid == 0) su[i1 - i0] = (uint32_t)u0[nin] + (u1 ? (uint32_t)u1[nin] : 0u) + (uint32_t)d.add_b;   // body
     }
     __syncthreads();
     const int nvec = p.ct_stride >> 2;
@@ -397,8 +400,8 @@ __global__ __launch_bounds__(KS_THREADS) void keyswitch_kernel(DevParams p, DevK
     const size_t row_vecs = (size_t)nvec;
     const uint4 *ksk = reinterpret_cast<const uint4 *>(key.ksk) + tid;
     uint4 acc = make_uint4(0, 0, 0, 0);
-    for (int i = 0; i < nin; ++i) {
-        const uint32_t aibar = su[i] + p.ks_prec_offset;
+    for (int i = i0; i < i1; ++i) {
+        const uint32_t aibar = su[i - i0] + p.ks_prec_offset;
         for (int j = 0; j < t; ++j) {
             const uint32_t aij = (aibar >> (32 - (j + 1) * bb)) & mask;
             if (aij == 0) continue;
@@ -410,10 +413,26 @@ __global__ __launch_bounds__(KS_THREADS) void keyswitch_kernel(DevParams p, DevK
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
         const int wi = 4 * tid + e;
-        if (wi == p.n) o[e] += su[nin];
+        if (wi == p.n && split == 0) o[e] += su[i1 - i0];
         if (wi > p.n) o[e] = 0;
     }
-    reinterpret_cast<uint4 *>(pool + (size_t)d.dst_slot * p.ct_stride)[tid] = make_uint4(o[0], o[1], o[2], o[3]);
+    int32_t *dst = splits == 1 ? pool + (size_t)d.dst_slot * p.ct_stride
+                               : partial + ((size_t)blockIdx.x * splits + split) * p.ct_stride;
+    reinterpret_cast<uint4 *>(dst)[tid] = make_uint4(o[0], o[1], o[2], o[3]);
+}
+
+__global__ __launch_bounds__(KS_THREADS) void ks_reduce_kernel(DevParams p, const KsDesc *__restrict__ descs, int splits,
+                                                               const int32_t *__restrict__ partial,
+                                                               int32_t *__restrict__ pool) {
+    const int tid = threadIdx.x;
+    if (tid >= (p.ct_stride >> 2)) return;
+    const uint4 *src = reinterpret_cast<const uint4 *>(partial + (size_t)blockIdx.x * splits * p.ct_stride) + tid;
+    uint4 acc = make_uint4(0, 0, 0, 0);
+    for (int s = 0; s < splits; ++s) {
+        const uint4 v = src[(size_t)s * (p.ct_stride >> 2)];
+        acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
+    }
+    reinterpret_cast<uint4 *>(pool + (size_t)descs[blockIdx.x].dst_slot * p.ct_stride)[tid] = acc;
 }
 
 // K5: bootsNOT
@@ -472,9 +491,14 @@ void launch_blind_rotate4(hipStream_t s, const DevParams &p, const DevKey &key, 
 }
 
 void launch_keyswitch(hipStream_t s, const DevParams &p, const DevKey &key, const int32_t *u_buf,
-                      const KsDesc *descs, int count, int32_t *pool) {
+                      const KsDesc *descs, int count, int32_t *pool, int splits, int32_t *partial) {
     if (count <= 0) return;
-    hipLaunchKernelGGL(keyswitch_kernel, dim3(count), dim3(KS_THREADS), 0, s, p, key, u_buf, descs, pool);
+    if (splits <= 1 || !partial) {
+        hipLaunchKernelGGL(keyswitch_kernel, dim3(count, 1), dim3(KS_THREADS), 0, s, p, key, u_buf, descs, pool, nullptr);
+        return;
+    }
+    hipLaunchKernelGGL(keyswitch_kernel, dim3(count, splits), dim3(KS_THREADS), 0, s, p, key, u_buf, descs, pool, partial);
+    hipLaunchKernelGGL(ks_reduce_kernel, dim3(count), dim3(KS_THREADS), 0, s, p, descs, splits, partial, pool);
 }
 
 void launch_not(hipStream_t s, const DevParams &p, const NotDesc *descs, int count, int32_t *pool) {

@@ -48,8 +48,10 @@ void launch_blind_rotate(hipStream_t s, const DevParams &p, const DevKey &key, c
 // latency form (4 waves per rotation), for launches that cannot fill the chip
 void launch_blind_rotate4(hipStream_t s, const DevParams &p, const DevKey &key, const int32_t *pool,
                           const RotDesc *rots, int count, int32_t *u_buf, int32_t *acc_dbg);
+// splits > 1: each gate's key switch is cut into `splits` ranges of input coefficients
+// (partial sums in `partial[count][splits][ct_stride]`, then a reduce launch)
 void launch_keyswitch(hipStream_t s, const DevParams &p, const DevKey &key, const int32_t *u_buf,
-                      const KsDesc *descs, int count, int32_t *pool);
+                      const KsDesc *descs, int count, int32_t *pool, int splits, int32_t *partial);
 void launch_not(hipStream_t s, const DevParams &p, const NotDesc *descs, int count, int32_t *pool);
 // res[c] = ip[c] * (poly whose image is img[c]) through the device NTT
 void launch_negacyclic(hipStream_t s, const DevParams &p, const uint32_t *tw, const int32_t *ip,

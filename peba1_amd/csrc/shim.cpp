@@ -574,6 +574,7 @@ int tfhe_hip_gate_batch(int gate, LweSample *result, const LweSample *a, const L
 
 int tfhe_hip_set_tuning(const char *name, int64_t value) {
     if (name && std::strcmp(name, "br4_max_rotations") == 0) { Engine::get().br4_max_rotations = (int)value; return 0; }
+    if (name && std::strcmp(name, "ks_target_blocks") == 0) { Engine::get().ks_target_blocks = (int)value; return 0; }
     set_error(std::string("tfhe_hip_set_tuning: unknown name ") + (name ? name : "(null)"));
     return -1;
 }

@@ -86,14 +86,19 @@ def test_blind_rotate_edge_inputs(p128_keys, oracle):
         assert (acc[c] == want).all(), f"case {c}"
 
 
-def test_keyswitch_matches_oracle(p128_keys, oracle):
-    """a17: key switch of arbitrary extracted samples."""
+@pytest.mark.parametrize("ks_blocks", [0, 2048, 1 << 20])
+def test_keyswitch_matches_oracle(p128_keys, oracle, ks_blocks):
+    """a17: key switch of arbitrary extracted samples, unsplit and split 32 ways."""
     from peba1_amd import api
+    api.set_tuning("ks_target_blocks", ks_blocks)
     pp, ks, oks = p128_keys
     rng = np.random.default_rng(3)
     u = rng.integers(-2**31, 2**31, (5, pp.N + 1), dtype=np.int64).astype(np.int32)
     u[0, :] = 0                      # all digits zero: nothing subtracted
     u[1, :-1] = -1                   # all digits 3 after rounding offset wraps
-    got = api.kernel_keyswitch(ks, u)
+    try:
+        got = api.kernel_keyswitch(ks, u)
+    finally:
+        api.set_tuning("ks_target_blocks", 2048)
     for c in range(5):
         assert (got[c] == oks.keyswitch(u[c])).all(), f"sample {c}"
