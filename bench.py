@@ -43,7 +43,8 @@ def cpu_baseline(seed):
     """The oracle (exact-integer C port, oracle/) timed on this box's host cores on a bounded
     sample of the same work: independent bootsAND gates, all cores."""
     from oracle import pyoracle as O
-    cores = os.cpu_count() or 1
+    # the GPU box gives one GPU's share of the host (16 cores), whatever cpu_count() says
+    cores = min(16, len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1))
     count = min(48, 3 * cores)
     oks = O.KeySet(O.params("P128"), seed)
     r = O.Rng(77)
@@ -70,6 +71,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--slots", type=int, default=128)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--force-dist", action="store_true",
+                    help="initialise the RCCL process group even at world size 1 (exercises the N>1 code path)")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -80,9 +83,12 @@ def main():
             raise SystemExit("launch N>1 with torch.distributed.run (one process per GPU)")
     dist = None
     torch = None
-    if world > 1:
+    use_dist = world > 1 or args.force_dist
+    if use_dist:
         import torch
         import torch.distributed as dist
+        if "MASTER_ADDR" not in os.environ:
+            os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT="29577", RANK="0", WORLD_SIZE="1")
         torch.cuda.set_device(local_rank)
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
 
@@ -108,7 +114,7 @@ def main():
     api.set_deferred(True)
 
     gather_buf = None
-    if world > 1:
+    if use_dist:
         mine = torch.empty(pp.words, dtype=torch.int32, device="cuda")
         gather_buf = [torch.empty(pp.words, dtype=torch.int32, device="cuda") for _ in range(world)] if rank == 0 else None
 
@@ -116,13 +122,13 @@ def main():
         rb = api.CiphertextArray(pp, 3 * bitsize)
         circuits.function_f(rb, probe, tmpl, bound, bitsize, ks)   # records ~350k API calls
         api.flush()                                                # levelised batched execution
-        if world > 1:   # the exchange step: match-bit ciphertexts to rank 0 over RCCL
+        if use_dist:    # the exchange step: match-bit ciphertexts to rank 0 over RCCL
             L.tfhe_hip_export_samples_device(rb.ptr, 1, pp.ptr, mine.data_ptr())
             dist.gather(mine, gather_buf, dst=0)
         return rb
 
     def sync():
-        if world > 1:
+        if use_dist:
             dist.barrier()
             torch.cuda.synchronize()
 
@@ -137,7 +143,7 @@ def main():
     sync()
     elapsed = time.perf_counter() - t0
     st = api.stats()
-    if world > 1:
+    if use_dist:
         tt = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
@@ -146,11 +152,14 @@ def main():
     bit = int(last.decrypt(ks)[0])
     assert bit == (1 if dist2 > threshold else 0), f"rank {rank}: match bit {bit}, distance {dist2}"
     ok_all = True
-    if world > 1 and rank == 0:
+    if use_dist and rank == 0:
         tmp = api.CiphertextArray(pp, 1)
         for r in range(world):
             L.tfhe_hip_import_samples_device(tmp.ptr, 1, pp.ptr, gather_buf[r].data_ptr())
             ok_all &= int(tmp.decrypt(ks)[0]) in (0, 1)
+        # rank 0's own entry must be its own match bit, bit for bit
+        L.tfhe_hip_import_samples_device(tmp.ptr, 1, pp.ptr, gather_buf[0].data_ptr())
+        assert (tmp.words()[0] == last.words()[0]).all() and ok_all, "gathered match-bit ciphertext differs"
 
     if rank == 0:
         a_br, a_ks, ct = algorithmic_bytes(pp)
@@ -158,6 +167,9 @@ def main():
         value = world * st["blind_rotates"] / elapsed
         br_gbps = st["blind_rotates"] * a_br / (st["ms_blind_rotate"] * 1e-3) / 1e9 if st["ms_blind_rotate"] else 0.0
         ks_gbps = st["keyswitches"] * a_ks / (st["ms_keyswitch"] * 1e-3) / 1e9 if st["ms_keyswitch"] else 0.0
+        # HBM-side bytes per blind-rotate launch from the PMC passes (tools/pmc_summary.py); the
+        # counters cannot be read inside this process, so the committed summary of the same
+        # command is quoted, in GB like `achieved` is in GB/s
         traffic = None
         pmc = os.path.join(ROOT, "profiles", "pmc_blind_rotate.json")
         if os.path.exists(pmc):
@@ -186,7 +198,7 @@ def main():
         else:
             out["cpu_baseline"] = None
         print(json.dumps(out), flush=True)
-    if world > 1:
+    if use_dist:
         dist.barrier()
         dist.destroy_process_group()
     ks.close()
