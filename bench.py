@@ -71,6 +71,9 @@ def main():
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--slots", type=int, default=128)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--batched-extra", type=int, default=4,
+                    help="after the timed single-match steps, also run this many matches recorded together "
+                         "(1-to-N identification, BASELINE configs[3]) and report their rate; 0 = skip")
     ap.add_argument("--force-dist", action="store_true",
                     help="initialise the RCCL process group even at world size 1 (exercises the N>1 code path)")
     args = ap.parse_args()
@@ -192,6 +195,22 @@ def main():
                          "algorithmic_bytes_per_blind_rotate": a_br,
                          "keyswitch_GBps": ks_gbps, "algorithmic_bytes_per_keyswitch": a_ks},
         }
+        if world == 1 and args.batched_extra > 1:
+            # extra, not the headline: B matches recorded together fill the narrow levels of the DAG
+            B = args.batched_extra
+            api.reset_stats()
+            tb = time.perf_counter()
+            outs = []
+            for _ in range(B):
+                rb = api.CiphertextArray(pp, 3 * bitsize)
+                circuits.function_f(rb, probe, tmpl, bound, bitsize, ks)
+                outs.append(rb)
+            api.flush()
+            tb = time.perf_counter() - tb
+            sb = api.stats()
+            assert all(int(o.decrypt(ks)[0]) == bit for o in outs)
+            out["batched_matches"] = {"matches": B, "gates_per_s": sb["blind_rotates"] / tb, "seconds": tb,
+                                      "levels": int(sb["levels"])}
         if world == 1 and not args.no_cpu_baseline:
             api.set_deferred(False)
             out["cpu_baseline"] = cpu_baseline(seed)

@@ -77,6 +77,11 @@ void Engine::ensure_init() {
     if (const char *env = std::getenv("TFHE_HIP_BR4_MAX")) br4_max_rotations = std::atoi(env);
     if (const char *env = std::getenv("TFHE_HIP_KS_BLOCKS")) ks_target_blocks = std::atoi(env);
     hip_check(hipSetDevice(device_), "hipSetDevice");
+    {
+        hipDeviceProp_t prop;
+        hip_check(hipGetDeviceProperties(&prop, device_), "hipGetDeviceProperties");
+        cu_count_ = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+    }
     hip_check(hipStreamCreateWithFlags(&stream_, hipStreamNonBlocking), "hipStreamCreate");
     for (auto &e : ev_) hip_check(hipEventCreate(&e), "hipEventCreate");
     inited_ = true;
@@ -193,7 +198,7 @@ SlotPool *Engine::pool_for(const Params &p) {
     ensure_init();
     for (SlotPool *pl : pools_)
         if (pl->ct_stride() == p.ct_stride() && pl->ct_words() == p.ct_words()) return pl;
-    size_t cap = 1u << 19;   // 524,288 slots = 1.3 GB at n = 630; HBM is 288 GB
+    size_t cap = 1u << 21;   // 2,097,152 slots = 5.3 GB at n = 630 (HBM is 288 GB): ~9 matches in flight
     if (const char *env = std::getenv("TFHE_HIP_POOL_SLOTS")) cap = (size_t)std::atoll(env);
     auto *pl = new SlotPool(p.ct_words(), p.ct_stride(), cap);
     // shared read-only slots: trivial 0 (fresh samples), constants -1/8 and +1/8
@@ -252,8 +257,13 @@ void Engine::read_slots_packed(SlotPool *pool, const int32_t *slots, int count, 
 
 void Engine::launch_br(const DeviceKeyImage *key, const int32_t *pool, const RotDesc *rots, int count, int32_t *u_buf,
                        int32_t *acc_dbg) {
-    if (count <= br4_max_rotations) launch_blind_rotate4(stream_, key->dp, key->key, pool, rots, count, u_buf, acc_dbg);
-    else launch_blind_rotate(stream_, key->dp, key->key, pool, rots, count, u_buf, acc_dbg);
+    if (count <= br4_max_rotations) {
+        launch_blind_rotate4(stream_, key->dp, key->key, pool, rots, count, u_buf, acc_dbg);
+        return;
+    }
+    // (splitting a short last round off to the latency kernel was measured: the kernel
+    // boundary costs more overlap than the faster tail gains -- match 3.99 s -> 4.15 s)
+    launch_blind_rotate(stream_, key->dp, key->key, pool, rots, count, u_buf, acc_dbg);
 }
 
 void Engine::launch_ks(const DeviceKeyImage *key, const int32_t *u_buf, const KsDesc *descs, int count, int32_t *pool) {

@@ -99,6 +99,7 @@ private:
     Engine() = default;
     void *scratch(size_t idx, size_t bytes);   // grow-only device scratch buffers
     int device_ = 0;
+    int cu_count_ = 256;
     bool inited_ = false;
     hipStream_t stream_ = nullptr;
     hipEvent_t ev_[4] = {nullptr, nullptr, nullptr, nullptr};
