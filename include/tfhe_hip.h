@@ -88,7 +88,9 @@ int tfhe_hip_gate_batch(int gate, LweSample *result, const LweSample *a, const L
  * env TFHE_HIP_BR4_MAX); 0 disables it.
  * "ks_target_blocks": a launch's key switches are each cut into 2^s <= 32 ranges of
  * input coefficients until about this many workgroups exist (default 2048, env
- * TFHE_HIP_KS_BLOCKS); 0 disables splitting.  Returns 0, or -1 for an unknown name. */
+ * TFHE_HIP_KS_BLOCKS); 0 disables splitting.
+ * "balance_levels": 1 (default) = slack-aware level filling at flush, 0 = plain ASAP
+ * levels.  Returns 0, or -1 for an unknown name. */
 int tfhe_hip_set_tuning(const char *name, int64_t value);
 
 /* ---- statistics ---- */
@@ -107,6 +109,11 @@ void tfhe_hip_get_stats(TfheHipStats *out);
 void tfhe_hip_reset_stats(void);
 /* when on, every kernel launch is bracketed by HIP events (adds sync points) */
 void tfhe_hip_set_kernel_timing(int on);
+
+/* ---- host-logic test entry: levelise a DAG given as count x {kind, dst, a, b, c} slot
+ * records (kind: gate code 0..9, 16 = MUX, 17 = NOT; absent operands -1) without
+ * touching the device; writes the level of each op, returns the depth ---- */
+int tfhe_hip_test_schedule(const int32_t *ops5, int32_t count, int32_t unit, int32_t balance, int32_t *levels_out);
 
 /* ---- kernel-level entry points (K2/K3 parity tests against the oracle) ---- */
 /* exact negacyclic products res[c] = ip[c] * tp[c] mod (X^N+1) mod 2^32 through

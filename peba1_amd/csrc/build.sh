@@ -12,8 +12,9 @@ $HIPCC $FLAGS --offload-arch=gfx950 -c kernels.hip -o kernels.o &
 $CXX $HOSTFLAGS -c host_keys.cpp -o host_keys.o &
 $CXX $HOSTFLAGS -c engine.cpp -o engine.o &
 $CXX $HOSTFLAGS -c shim.cpp -o shim.o &
-wait -n; wait -n; wait -n; wait -n
-$HIPCC -shared -o $OUT kernels.o host_keys.o engine.o shim.o
+$CXX $HOSTFLAGS -c scheduler.cpp -o scheduler.o &
+wait -n; wait -n; wait -n; wait -n; wait -n
+$HIPCC -shared -o $OUT kernels.o host_keys.o engine.o shim.o scheduler.o
 echo "built $(realpath $OUT)"
 # circuits: calls only the public tfhe API; symbols resolve at load time against
 # whichever provider is loaded first (libtfhe-hip.so, or the tests' plain mock)

@@ -66,6 +66,7 @@ public:
     static Engine &get();
     void ensure_init();
     int device() const { return device_; }
+    int cu_count() const { return cu_count_; }
     void set_device(int d);
     hipStream_t stream() const { return stream_; }
 

@@ -276,6 +276,31 @@ __global__ __launch_bounds__(128) void blind_rotate_kernel(DevParams p, DevKey k
     extract_sample<128>(p, rd, lds_acc, u_buf, acc_dbg, tid);
 }
 
+#ifdef TFHE_HIP_STAMPS
+// Diagnostic build only (peba1_amd/csrc/build.sh stamps): per-phase shader-cycle sums of
+// the latency kernel, lane 0 of each wave, accumulated into a buffer nothing else reads.
+__device__ unsigned long long g_stamps[4][8];
+#define STAMP_DECL unsigned long long st_prev = __builtin_amdgcn_s_memtime(), st_sum[8] = {0, 0, 0, 0, 0, 0, 0, 0}
+#define STAMP(k)                                                             \
+    do {                                                                     \
+        __builtin_amdgcn_sched_barrier(0);                                   \
+        const unsigned long long st_now = __builtin_amdgcn_s_memtime();      \
+        __builtin_amdgcn_s_waitcnt(0xC07F);                                  \
+        st_sum[k] += st_now - st_prev;                                       \
+        st_prev = st_now;                                                    \
+        __builtin_amdgcn_sched_barrier(0);                                   \
+    } while (0)
+#define STAMP_FLUSH                                                          \
+    do {                                                                     \
+        if (lane == 0)                                                       \
+            for (int k = 0; k < 8; ++k) atomicAdd(&g_stamps[wv][k], st_sum[k]); \
+    } while (0)
+#else
+#define STAMP_DECL
+#define STAMP(k)
+#define STAMP_FLUSH
+#endif
+
 // ---------------------------------------------------------------------------
 // K1+K2: blind rotate, latency form for narrow levels.  grid = rotations, 256
 // threads: wave (q,u) works modulo prime q on input polynomial u (3 forward
@@ -315,16 +340,19 @@ __global__ __launch_bounds__(256) void blind_rotate4_kernel(DevParams p, DevKey 
     __syncthreads();
 
     const StepConsts sc{(1u << p.Bgbit) - 1u, 1 << (p.Bgbit - 1)};
+    STAMP_DECL;
 
     for (int i = 0; i < n; ++i) {
         const int abar = __builtin_amdgcn_readfirstlane((int)lds_bar[i]);
         if (abar == 0) continue;
+        STAMP(0);
 
         int64_t acc0[16], acc1[16];
 #pragma unroll
         for (int r = 0; r < 16; ++r) { acc0[r] = 0; acc1[r] = 0; }
         // acc0 accumulates output poly u (kept), acc1 output poly 1-u (sent to wave (q,1-u))
         forward_poly(p, key, c, sc, lds_acc[u], scr, lane, q, i, u, abar, u != 0, acc0, acc1);
+        STAMP(1);
 
         int32_t t[16], send[16];
 #pragma unroll
@@ -333,7 +361,9 @@ __global__ __launch_bounds__(256) void blind_rotate4_kernel(DevParams p, DevKey 
             send[r] = mont_redc(acc1[r], c.P, c.pinv);
         }
         write_row16(send, lds_x1[wv], lane);
+        STAMP(2);
         __syncthreads();
+        STAMP(3);
         {
             int32_t other[16];
             read_row16(other, lds_x1[wv ^ 2], lane);
@@ -344,6 +374,7 @@ __global__ __launch_bounds__(256) void blind_rotate4_kernel(DevParams p, DevKey 
         uint32_t y[16];
 #pragma unroll
         for (int r = 0; r < 16; ++r) y[r] = canon(t[r], c.P);
+        STAMP(4);
 
         // CRT of output poly u is split with wave (1-q,u): wave q recombines registers [8q, 8q+8)
         const uint32_t *ox = lds_x2[wv ^ 1];
@@ -360,8 +391,11 @@ __global__ __launch_bounds__(256) void blind_rotate4_kernel(DevParams p, DevKey 
 #pragma unroll
             for (int r = 0; r < 8; ++r) lds_acc[u][(8 + r) * 64 + lane] += crt_to_torus(ox[r * 64 + lane], y[8 + r]);
         }
+        STAMP(5);
         __syncthreads();
+        STAMP(6);
     }
+    STAMP_FLUSH;
     extract_sample<256>(p, rd, lds_acc, u_buf, acc_dbg, tid);
 }
 
@@ -483,6 +517,13 @@ void launch_blind_rotate(hipStream_t s, const DevParams &p, const DevKey &key, c
     if (count <= 0) return;
     hipLaunchKernelGGL(blind_rotate_kernel, dim3(count), dim3(128), 0, s, p, key, pool, rots, u_buf, acc_dbg);
 }
+
+#ifdef TFHE_HIP_STAMPS
+void read_stamps(unsigned long long *out, bool reset) {
+    (void)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_stamps), sizeof(unsigned long long) * 32);
+    if (reset) { unsigned long long z[32] = {0}; (void)hipMemcpyToSymbol(HIP_SYMBOL(g_stamps), z, sizeof z); }
+}
+#endif
 
 void launch_blind_rotate4(hipStream_t s, const DevParams &p, const DevKey &key, const int32_t *pool,
                           const RotDesc *rots, int count, int32_t *u_buf, int32_t *acc_dbg) {

@@ -1,0 +1,117 @@
+// scheduler.cpp -- see scheduler.hpp.  Host logic only.
+#include "scheduler.hpp"
+
+#include <algorithm>
+#include <queue>
+#include <unordered_map>
+
+namespace tfhe_hip {
+
+namespace {
+struct HeapItem {
+    int32_t alap, idx;
+    bool operator>(const HeapItem &o) const { return alap != o.alap ? alap > o.alap : idx > o.idx; }
+};
+}  // namespace
+
+int schedule_levels(const std::vector<PendingOp> &ops, int asap_depth, bool balance, int unit,
+                    std::vector<int32_t> &lvl) {
+    const int n = (int)ops.size();
+    lvl.resize(n);
+    for (int i = 0; i < n; ++i) lvl[i] = ops[i].level;
+    if (!balance || asap_depth <= 2 || n < 4 * unit) return asap_depth;
+
+    // producer of each pending slot (destinations are unique: SSA)
+    std::unordered_map<int32_t, int32_t> producer;
+    producer.reserve((size_t)n * 2);
+    for (int i = 0; i < n; ++i) producer.emplace(ops[i].dst, i);
+
+    // predecessor lists (<= 3 each) and successor lists in CSR form
+    std::vector<int32_t> pred(3 * (size_t)n, -1), npred(n, 0), succ_off(n + 1, 0);
+    for (int i = 0; i < n; ++i) {
+        const int32_t src[3] = {ops[i].a, ops[i].b, ops[i].c};
+        for (int s = 0; s < 3; ++s) {
+            if (src[s] < 0) continue;
+            auto it = producer.find(src[s]);
+            if (it == producer.end() || it->second >= i) continue;   // materialised before this flush
+            bool dup = false;
+            for (int t = 0; t < npred[i]; ++t) dup |= pred[3 * (size_t)i + t] == it->second;
+            if (dup) continue;
+            pred[3 * (size_t)i + npred[i]++] = it->second;
+            ++succ_off[it->second + 1];
+        }
+    }
+    for (int i = 0; i < n; ++i) succ_off[i + 1] += succ_off[i];
+    std::vector<int32_t> succ(succ_off[n]), cursor(succ_off.begin(), succ_off.end() - 1);
+    for (int i = 0; i < n; ++i)
+        for (int t = 0; t < npred[i]; ++t) succ[cursor[pred[3 * (size_t)i + t]]++] = i;
+
+    // ALAP: recording order is topological, so one reverse sweep suffices
+    std::vector<int32_t> alap(n, asap_depth);
+    for (int i = n - 1; i >= 0; --i) {
+        const int32_t need = ops[i].kind == OP_NOT ? alap[i] : alap[i] - 1;   // a NOT runs after its level's gates
+        for (int t = 0; t < npred[i]; ++t) {
+            int32_t &a = alap[pred[3 * (size_t)i + t]];
+            a = std::min(a, need);
+        }
+    }
+
+    // list scheduling, least slack first
+    long long remaining = 0;
+    for (const PendingOp &op : ops) remaining += op_rotations(op);
+    std::vector<int32_t> left(npred), est(n, 1);
+    std::vector<std::vector<int32_t>> avail(asap_depth + 2);
+    auto release_successors = [&](int32_t i, int32_t level_done, auto &&self) -> void {
+        for (int32_t e = succ_off[i]; e < succ_off[i + 1]; ++e) {
+            const int32_t s = succ[e];
+            const bool is_not = ops[s].kind == OP_NOT;
+            est[s] = std::max(est[s], is_not ? level_done : level_done + 1);
+            if (--left[s] != 0) continue;
+            if (is_not) {                       // linear: rides along with its operand's level
+                lvl[s] = est[s];
+                self(s, lvl[s], self);
+            } else {
+                avail[std::min<int32_t>(est[s], asap_depth + 1)].push_back(s);
+            }
+        }
+    };
+    for (int i = 0; i < n; ++i) {
+        if (left[i] != 0) continue;
+        if (ops[i].kind == OP_NOT) {
+            if (npred[i] == 0) { lvl[i] = 0; est[i] = 0; }
+        } else {
+            avail[1].push_back(i);
+        }
+    }
+    // NOTs of materialised inputs release their successors now (level 0 is "before level 1")
+    for (int i = 0; i < n; ++i)
+        if (ops[i].kind == OP_NOT && npred[i] == 0) release_successors(i, 0, release_successors);
+
+    std::priority_queue<HeapItem, std::vector<HeapItem>, std::greater<HeapItem>> heap;
+    std::vector<int32_t> batch;
+    for (int L = 1; L <= asap_depth; ++L) {
+        for (int32_t i : avail[L]) heap.push(HeapItem{alap[i], i});
+        const long long levels_left = asap_depth - L + 1;
+        long long cap;
+        if (remaining <= (long long)unit * levels_left) cap = unit;
+        else if (remaining <= 2LL * unit * levels_left) cap = 2LL * unit;
+        else if (remaining <= 4LL * unit * levels_left) cap = 4LL * unit;
+        else cap = ((remaining + levels_left - 1) / levels_left + 4LL * unit - 1) / (4LL * unit) * (4LL * unit);
+        long long width = 0;
+        batch.clear();
+        while (!heap.empty()) {
+            const HeapItem top = heap.top();
+            const int w = op_rotations(ops[top.idx]);
+            if (top.alap > L && width + w > cap) break;
+            heap.pop();
+            lvl[top.idx] = L;
+            width += w;
+            batch.push_back(top.idx);
+        }
+        remaining -= width;
+        for (int32_t i : batch) release_successors(i, L, release_successors);
+    }
+    return asap_depth;
+}
+
+}  // namespace tfhe_hip

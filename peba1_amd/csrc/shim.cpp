@@ -18,9 +18,11 @@
 #include <mutex>
 #include <new>
 #include <string>
+#include <unordered_map>
 #include <vector>
 
 #include "engine.hpp"
+#include "scheduler.hpp"
 #include "../../include/tfhe/tfhe.h"
 
 using namespace tfhe_hip;
@@ -51,13 +53,6 @@ ArrayHeader *header_of(LweSample *samples) {
     return h;
 }
 
-struct PendingOp {
-    uint8_t kind;       // 0..9 two-input gate code, 16 MUX, 17 NOT
-    int32_t dst, a, b, c;
-    int32_t level;
-};
-constexpr uint8_t OP_MUX = 16, OP_NOT = 17;
-
 // prelude constants of the two-input gates: (c0 in eighths, sa, sb), tfhe boot-gates.cpp
 struct GateLin { int32_t c8, sa, sb; };
 const GateLin GATE_LIN[10] = {
@@ -74,6 +69,8 @@ struct Recorder {
     int32_t max_level = 0;
     Rng enc_rng{0x5EBA1};
     uint64_t keygen_counter = 0;
+    bool balance_levels = true;   // slack-aware level filling (scheduler.hpp)
+    std::unordered_map<int32_t, int32_t> not_origin;   // pending NOT output slot -> its operand slot
 };
 Recorder &rec() {
     static Recorder r;
@@ -166,14 +163,17 @@ int flush_locked() {
     Recorder &r = rec();
     if (r.ops.empty()) return 0;
     SlotPool *pool = r.pool;
-    const int levels = r.max_level;
     LevelPlan plan;
+    // level of every op: ASAP, or slack-aware balanced (same depth, fuller narrow levels)
+    std::vector<int32_t> lvl;
+    const int levels = schedule_levels(r.ops, r.max_level, r.balance_levels, Engine::get().cu_count(), lvl);
     // counting sort by level
     std::vector<int32_t> nrot(levels + 2, 0), nks(levels + 2, 0), nnot(levels + 2, 0);
-    for (const PendingOp &op : r.ops) {
-        if (op.kind == OP_NOT) ++nnot[op.level];
-        else if (op.kind == OP_MUX) { nrot[op.level] += 2; ++nks[op.level]; }
-        else { ++nrot[op.level]; ++nks[op.level]; }
+    for (size_t i = 0; i < r.ops.size(); ++i) {
+        const PendingOp &op = r.ops[i];
+        if (op.kind == OP_NOT) ++nnot[lvl[i]];
+        else if (op.kind == OP_MUX) { nrot[lvl[i]] += 2; ++nks[lvl[i]]; }
+        else { ++nrot[lvl[i]]; ++nks[lvl[i]]; }
     }
     plan.rot_off.assign(levels + 1, 0);
     plan.ks_off.assign(levels + 1, 0);
@@ -191,12 +191,13 @@ int flush_locked() {
     std::vector<int32_t> kpos(plan.ks_off.begin(), plan.ks_off.end() - 1);
     std::vector<int32_t> npos(plan.not_off.begin(), plan.not_off.end() - 1);   // index L
     const int32_t mu = 1 << 29;
-    for (const PendingOp &op : r.ops) {
+    for (size_t i = 0; i < r.ops.size(); ++i) {
+        const PendingOp &op = r.ops[i];
         if (op.kind == OP_NOT) {
-            plan.nots[npos[op.level]++] = NotDesc{op.a, op.dst};
+            plan.nots[npos[lvl[i]]++] = NotDesc{op.a, op.dst};
             continue;
         }
-        const int L = op.level - 1;
+        const int L = lvl[i] - 1;
         const int32_t base = plan.rot_off[L];
         if (op.kind == OP_MUX) {
             // tfhe bootsMUX: u1 = BR(-1/8 + a + b), u2 = BR(-1/8 - a + c), KS(u1 + u2 + 1/8)
@@ -220,6 +221,7 @@ int flush_locked() {
         if (op.c >= 0) pool->release(op.c);
     }
     r.ops.clear();
+    r.not_origin.clear();
     r.max_level = 0;
     return levels;
 }
@@ -378,11 +380,23 @@ void bootsNOT(LweSample *result, const LweSample *ca, const TFheGateBootstrappin
     begin_op(bk);
     SlotPool *pool = r.pool;
     const int32_t sa = ensure_slot(ca, pool);
+    {   // NOT of a still-pending NOT: -(-x) = x exactly, so alias the original operand; two NOTs
+        // of one level would otherwise sit in the same launch and race
+        auto it = r.not_origin.find(sa);
+        if (it != r.not_origin.end()) {
+            pool->retain(it->second);
+            if (result->slot >= 0) pool->release(result->slot);
+            result->slot = it->second;
+            finish_op(result);
+            return;
+        }
+    }
     const int32_t dst = pool->alloc();
     const int32_t level = pool->level[sa];     // linear: rides on its operand's level
     pool->level[dst] = level;
     pool->retain(sa); pool->retain(dst);
     r.ops.push_back(PendingOp{OP_NOT, dst, sa, -1, -1, level});
+    r.not_origin.emplace(dst, sa);
     r.max_level = std::max(r.max_level, level);
     if (result->slot >= 0) pool->release(result->slot);
     result->slot = dst;
@@ -575,6 +589,7 @@ int tfhe_hip_gate_batch(int gate, LweSample *result, const LweSample *a, const L
 int tfhe_hip_set_tuning(const char *name, int64_t value) {
     if (name && std::strcmp(name, "br4_max_rotations") == 0) { Engine::get().br4_max_rotations = (int)value; return 0; }
     if (name && std::strcmp(name, "ks_target_blocks") == 0) { Engine::get().ks_target_blocks = (int)value; return 0; }
+    if (name && std::strcmp(name, "balance_levels") == 0) { rec().balance_levels = value != 0; return 0; }
     set_error(std::string("tfhe_hip_set_tuning: unknown name ") + (name ? name : "(null)"));
     return -1;
 }
@@ -582,6 +597,28 @@ int tfhe_hip_set_tuning(const char *name, int64_t value) {
 void tfhe_hip_get_stats(TfheHipStats *out) { if (out) *out = Engine::get().stats; }
 void tfhe_hip_reset_stats(void) { Engine::get().stats = TfheHipStats{}; }
 void tfhe_hip_set_kernel_timing(int on) { Engine::get().kernel_timing = on != 0; }
+
+int tfhe_hip_test_schedule(const int32_t *ops5, int32_t count, int32_t unit, int32_t balance, int32_t *levels_out) {
+    // ops5[i] = {kind, dst, a, b, c}; ASAP levels are derived here exactly as the recorder derives them
+    std::vector<PendingOp> ops((size_t)count);
+    std::vector<int32_t> slot_level;
+    int depth = 0;
+    auto level_of = [&](int32_t s) { return s >= 0 && (size_t)s < slot_level.size() ? slot_level[s] : 0; };
+    for (int32_t i = 0; i < count; ++i) {
+        const int32_t *o = ops5 + 5 * (size_t)i;
+        PendingOp op{(uint8_t)o[0], o[1], o[2], o[3], o[4], 0};
+        const int32_t in = std::max(level_of(op.a), std::max(level_of(op.b), level_of(op.c)));
+        op.level = op.kind == OP_NOT ? in : in + 1;
+        if ((size_t)op.dst >= slot_level.size()) slot_level.resize((size_t)op.dst + 1, 0);
+        slot_level[op.dst] = op.level;
+        depth = std::max(depth, op.level);
+        ops[i] = op;
+    }
+    std::vector<int32_t> lvl;
+    const int d = schedule_levels(ops, depth, balance != 0, unit, lvl);
+    for (int32_t i = 0; i < count; ++i) levels_out[i] = lvl[i];
+    return d;
+}
 
 int tfhe_hip_kernel_negacyclic(const TFheGateBootstrappingCloudKeySet *bk, const int32_t *ip, const Torus32 *tp,
                                Torus32 *res, int32_t count) {

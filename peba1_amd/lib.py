@@ -105,6 +105,7 @@ SIGNATURES = {
     "tfhe_hip_get_stats": (None, [C.POINTER(Stats)]),
     "tfhe_hip_reset_stats": (None, []),
     "tfhe_hip_set_kernel_timing": (None, [C.c_int]),
+    "tfhe_hip_test_schedule": (C.c_int, [I32P, C.c_int32, C.c_int32, C.c_int32, I32P]),
     "tfhe_hip_kernel_negacyclic": (C.c_int, [CK, I32P, I32P, I32P, C.c_int32]),
     "tfhe_hip_kernel_bootstrap_woks": (C.c_int, [CK, I32P, C.c_int32, I32P, I32P]),
     "tfhe_hip_kernel_keyswitch": (C.c_int, [CK, I32P, C.c_int32, I32P]),

@@ -132,3 +132,54 @@ def test_fresh_samples_are_trivial_zero(p128_keys, oracle):
     assert (fresh.words()[0] == oks.constant(0)).all()
     assert (r.words()[0] == oks.gate("XOR", one.words()[0], oks.constant(0))).all()
     assert fresh.decrypt(ks)[0] == 0 and r.decrypt(ks)[0] == 1
+
+
+def test_not_of_not_and_not_chains_deferred(p128_keys, oracle):
+    """NOT(NOT(x)) recorded in one flush must not race: it aliases x (exact double negation)."""
+    from peba1_amd import api, lib
+    pp, ks, oks = p128_keys
+    L = lib.load()
+    L.tfhe_hip_set_encrypt_seed(31)
+    x = api.CiphertextArray(pp, 2).encrypt([1, 0], ks)
+    wx = x.words()
+    r = api.CiphertextArray(pp, 4)
+    api.set_deferred(True)
+    try:
+        L.bootsNOT(r.at(0), x.at(0), ks.cloud)
+        L.bootsNOT(r.at(1), r.at(0), ks.cloud)                 # = x[0]
+        L.bootsAND(r.at(2), r.at(1), x.at(1), ks.cloud)
+        L.bootsNOT(r.at(3), r.at(2), ks.cloud)                 # NOT of a bootstrapped value
+        api.flush()
+    finally:
+        api.set_deferred(False)
+    got = r.words()
+    assert (got[0] == oks.gate_not(wx[0])).all()
+    assert (got[1] == wx[0]).all()
+    g = oks.gate("AND", wx[0], wx[1])
+    assert (got[2] == g).all() and (got[3] == oks.gate_not(g)).all()
+    assert list(r.decrypt(ks)) == [0, 1, 0, 1]
+
+
+def test_balanced_and_asap_schedules_give_identical_ciphertexts(p128_keys, oracle):
+    """A multiplier + adder circuit (fat levels then a carry chain) run with slack-aware level
+    filling and with plain ASAP levels: same ciphertext words, correct plaintext."""
+    from peba1_amd import api, circuits, lib
+    pp, ks, oks = p128_keys
+    L = lib.load()
+    results = []
+    for balance in (1, 0):
+        api.set_tuning("balance_levels", balance)
+        L.tfhe_hip_set_encrypt_seed(77)
+        a = circuits.encrypt_number(pp, 13, 9, ks)
+        b = circuits.encrypt_number(pp, 11, 9, ks)
+        prod = api.CiphertextArray(pp, 24)
+        api.set_deferred(True)
+        try:
+            circuits.load().peba1_multiply(prod.ptr, a.ptr, b.ptr, 4, ks.cloud)
+            api.flush()
+        finally:
+            api.set_deferred(False)
+        results.append(prod.words())
+        assert circuits.decrypt_number(prod, ks, 23) == 13 * 11
+    api.set_tuning("balance_levels", 1)
+    assert (results[0] == results[1]).all()
