@@ -84,8 +84,8 @@ int tfhe_hip_gate_batch(int gate, LweSample *result, const LweSample *a, const L
 
 /* ---- tuning (results never depend on these) ----
  * "br4_max_rotations": launches of at most this many blind rotations use the
- * 4-wave latency kernel instead of the 2-wave throughput kernel (default 512,
- * env TFHE_HIP_BR4_MAX); 0 disables it.
+ * 4-wave kernel (one wave per prime and input polynomial) instead of the 2-wave
+ * kernel (one wave per prime); default 2^30 = always, env TFHE_HIP_BR4_MAX; 0 = never.
  * "ks_target_blocks": a launch's key switches are each cut into 2^s <= 32 ranges of
  * input coefficients until about this many workgroups exist (default 2048, env
  * TFHE_HIP_KS_BLOCKS); 0 disables splitting.

@@ -88,8 +88,10 @@ public:
 
     TfheHipStats stats{};
     bool kernel_timing = false;
-    // launches of at most this many rotations use the 4-wave latency kernel (2 workgroups per CU)
-    int br4_max_rotations = 512;
+    // launches of at most this many rotations use the 4-wave kernel; measured
+    // (tools/width_sweep.py) it matches or beats the 2-wave form at every width, so the
+    // default is "always"; the 2-wave form stays selectable and tested
+    int br4_max_rotations = 1 << 30;
     // key switches of a launch are split so that about this many workgroups exist (power of two <= 32)
     int ks_target_blocks = 2048;
     void launch_ks(const DeviceKeyImage *key, const int32_t *u_buf, const KsDesc *descs, int count, int32_t *pool);

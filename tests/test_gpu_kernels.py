@@ -63,7 +63,7 @@ def test_both_blind_rotate_forms_are_bit_exact(p128_keys, oracle, br4_max):
     try:
         u, acc = api.kernel_bootstrap_woks(ks, lins, want_acc=True)
     finally:
-        api.set_tuning("br4_max_rotations", 512)
+        api.set_tuning("br4_max_rotations", 1 << 30)
     for c in range(3):
         bar = oks.modswitch_ct(lins[c])
         want_acc = oks.blind_rotate(bar[:-1], bar[-1])
