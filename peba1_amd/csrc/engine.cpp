@@ -142,10 +142,11 @@ static DevParams make_dev_params(const Params &p) {
 DeviceKeyImage *Engine::upload_key(const TfheHipCloudKey &ck) {
     ensure_init();
     const Params &p = ck.p;
-    if (p.N != NTT_N || p.k != 1)
-        fatal("this build's blind-rotate kernel is specialised for N=1024, k=1 (got N=" + std::to_string(p.N) +
+    if ((p.N != 1024 && p.N != 2048) || p.k != 1)
+        fatal("the blind-rotate kernels are built for N = 1024 or 2048 and k = 1 (got N=" + std::to_string(p.N) +
               ", k=" + std::to_string(p.k) + ")");
-    if (p.n > 1024) fatal("n > 1024 unsupported");
+    if (p.n > 1024 || p.ct_stride() / 4 > 320) fatal("n > 1024 unsupported");
+    if (p.l * p.Bgbit > 32 || p.Bgbit > 12) fatal("gadget digits must fit 12 bits");
     // exactness of the CRT range: (k+1) l N (Bg/2) 2^31 must stay below P0*P1/2
     const double bound = (double)(p.k + 1) * p.l * p.N * (double)(1u << (p.Bgbit - 1)) * 2147483648.0;
     if (bound >= (double)CRT_HALF) fatal("gadget parameters exceed the exact range of the two-prime NTT");

@@ -10,7 +10,9 @@
 // / tGswFFTExternMulToTLwe / lweKeySwitch as described in SURVEY.md Appendix A.3;
 // reference call sites: /root/reference/src/Math.cpp:34-43 (every bootsXOR/bootsAND).
 //
-// Mapping (N = 1024, k = 1): one workgroup of two wave64 per blind rotation, wave
+// All kernels are templates on LOGN (N = 1024: TFHE's 128-bit set, N = 2048: BASELINE
+// configs[4]); 16 or 32 coefficients per lane.
+// Mapping of the 2-wave form (k = 1): one workgroup of two wave64 per blind rotation, wave
 // q does all arithmetic modulo prime q.  The accumulator (2 x 1024 Torus32) lives
 // in LDS for the whole n-step loop; per step a wave reads the rotated
 // accumulator, extracts gadget digits, runs 6 forward NTTs (ntt_wave.hpp),
@@ -26,26 +28,29 @@ namespace tfhe_hip {
 
 namespace {
 
-__device__ __forceinline__ PrimeCtx make_ctx(int q, const uint32_t *tw) {
+__device__ __forceinline__ PrimeCtx make_ctx(int q, const uint32_t *tw, int n_ring) {
     PrimeCtx c;
     c.P = q ? NTT_P1 : NTT_P0;
     c.pinv = q ? NTT_PINV1 : NTT_PINV0;
     c.rmod = q ? NTT_R[1] : NTT_R[0];
-    c.wf = tw + (size_t)(q * 2 + 0) * NTT_N;
-    c.wi = tw + (size_t)(q * 2 + 1) * NTT_N;
+    c.wf = tw + (size_t)(q * 2 + 0) * n_ring;
+    c.wi = tw + (size_t)(q * 2 + 1) * n_ring;
     return c;
 }
 
-// acc64 (sum of <= 6 products x*bk, |x| < 10.1P, 0 <= bk < P, so |acc| < 2^60) ->
-// Montgomery reduction (|.| < 2.4P), inverse NTT, canonical residue in [0,P)
-__device__ __forceinline__ void finish_inverse(const int64_t (&acc)[16], uint32_t (&y)[16],
+// acc64 (sum of <= 6 products x*bk, |x| < 11.1P, 0 <= bk < P, so |acc| < 2^61) ->
+// Montgomery reduction (|.| < 2.6P), inverse NTT, canonical residue in [0,P)
+template <int LOGN>
+__device__ __forceinline__ void finish_inverse(const int64_t (&acc)[WaveNtt<LOGN>::REGS],
+                                               uint32_t (&y)[WaveNtt<LOGN>::REGS],
                                                const PrimeCtx &c, uint32_t *scr, int lane) {
-    int32_t t[16];
+    constexpr int REGS = WaveNtt<LOGN>::REGS;
+    int32_t t[REGS];
 #pragma unroll
-    for (int r = 0; r < 16; ++r) t[r] = mont_redc(acc[r], c.P, c.pinv);
-    ntt_inv_1024(t, c, scr, lane);
+    for (int r = 0; r < REGS; ++r) t[r] = mont_redc(acc[r], c.P, c.pinv);
+    WaveNtt<LOGN>::inverse(t, c, scr, lane);
 #pragma unroll
-    for (int r = 0; r < 16; ++r) y[r] = canon(t[r], c.P);
+    for (int r = 0; r < REGS; ++r) y[r] = canon(t[r], c.P);
 }
 
 // ---------------------------------------------------------------------------
@@ -54,24 +59,27 @@ __device__ __forceinline__ void finish_inverse(const int64_t (&acc)[16], uint32_
 // holding register 4g+e of `lane` in layout L2, i.e. exactly what a lane of the
 // blind-rotate kernel fetches with one 16-byte load.
 // ---------------------------------------------------------------------------
+template <int LOGN>
 __global__ __launch_bounds__(64) void bk_transform_kernel(const int32_t *__restrict__ raw, uint32_t *__restrict__ img,
                                                           const uint32_t *__restrict__ tw, int nw,
                                                           uint32_t scale0, uint32_t scale1) {
-    __shared__ __align__(16) uint32_t scr[NTT_SCRATCH_WORDS];
+    using NTT = WaveNtt<LOGN>;
+    constexpr int N = NTT::N, REGS = NTT::REGS;
+    __shared__ __align__(16) uint32_t scr[NTT::SCRATCH_WORDS];
     const int lane = threadIdx.x;
     const int q = blockIdx.y;
     const int poly = blockIdx.x;          // X*nw + w
     const int X = poly / nw, w = poly % nw;
-    const PrimeCtx c = make_ctx(q, tw);
+    const PrimeCtx c = make_ctx(q, tw, N);
     const uint32_t scale = q ? scale1 : scale0;
-    const int32_t *src = raw + (size_t)poly * NTT_N;
-    int32_t x[16];
+    const int32_t *src = raw + (size_t)poly * N;
+    int32_t x[REGS];
 #pragma unroll
-    for (int r = 0; r < 16; ++r) x[r] = src[r * 64 + lane] % (int32_t)c.P;     // |x| < P
-    ntt_fwd_1024(x, c, scr, lane);                                             // |x| < 11P
-    uint4 *dst = reinterpret_cast<uint4 *>(img + ((size_t)(X * 2 + q) * nw + w) * NTT_N) + lane;
+    for (int r = 0; r < REGS; ++r) x[r] = src[r * 64 + lane] % (int32_t)c.P;   // |x| < P
+    NTT::forward(x, c, scr, lane);                                             // |x| < 12P
+    uint4 *dst = reinterpret_cast<uint4 *>(img + ((size_t)(X * 2 + q) * nw + w) * N) + lane;
 #pragma unroll
-    for (int g = 0; g < 4; ++g) {
+    for (int g = 0; g < REGS / 4; ++g) {
         uint32_t v[4];
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
@@ -86,39 +94,42 @@ __global__ __launch_bounds__(64) void bk_transform_kernel(const int32_t *__restr
 // ---------------------------------------------------------------------------
 // test kernel: res = ip * tp (negacyclic, mod 2^32), tp given as image
 // ---------------------------------------------------------------------------
+template <int LOGN>
 __global__ __launch_bounds__(128) void negacyclic_kernel(const int32_t *__restrict__ ip, const uint32_t *__restrict__ img,
                                                          const uint32_t *__restrict__ tw, int32_t *__restrict__ res) {
-    __shared__ __align__(16) uint32_t lds_scr[2][NTT_SCRATCH_WORDS];
+    using NTT = WaveNtt<LOGN>;
+    constexpr int N = NTT::N, REGS = NTT::REGS;
+    __shared__ __align__(16) uint32_t lds_scr[2][NTT::SCRATCH_WORDS];
     const int tid = threadIdx.x;
     const int q = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int lane = tid & 63;
-    const PrimeCtx c = make_ctx(q, tw);
+    const PrimeCtx c = make_ctx(q, tw, N);
     uint32_t *scr = lds_scr[q];
-    const int32_t *src = ip + (size_t)blockIdx.x * NTT_N;
-    int32_t x[16];
+    const int32_t *src = ip + (size_t)blockIdx.x * N;
+    int32_t x[REGS];
 #pragma unroll
-    for (int r = 0; r < 16; ++r) x[r] = src[r * 64 + lane];
-    ntt_fwd_1024(x, c, scr, lane);
-    const uint4 *bp = reinterpret_cast<const uint4 *>(img + (size_t)(blockIdx.x * 2 + q) * NTT_N) + lane;
-    int64_t acc[16];
+    for (int r = 0; r < REGS; ++r) x[r] = src[r * 64 + lane];
+    NTT::forward(x, c, scr, lane);
+    const uint4 *bp = reinterpret_cast<const uint4 *>(img + (size_t)(blockIdx.x * 2 + q) * N) + lane;
+    int64_t acc[REGS];
 #pragma unroll
-    for (int g = 0; g < 4; ++g) {
+    for (int g = 0; g < REGS / 4; ++g) {
         const uint4 b = bp[g * 64];
         acc[4 * g + 0] = (int64_t)x[4 * g + 0] * (int32_t)b.x;
         acc[4 * g + 1] = (int64_t)x[4 * g + 1] * (int32_t)b.y;
         acc[4 * g + 2] = (int64_t)x[4 * g + 2] * (int32_t)b.z;
         acc[4 * g + 3] = (int64_t)x[4 * g + 3] * (int32_t)b.w;
     }
-    uint32_t y[16];
-    finish_inverse(acc, y, c, scr, lane);
+    uint32_t y[REGS];
+    finish_inverse<LOGN>(acc, y, c, scr, lane);
 #pragma unroll
-    for (int r = 0; r < 16; ++r) scr[r * 64 + lane] = y[r];
+    for (int r = 0; r < REGS; ++r) scr[r * 64 + lane] = y[r];
     __syncthreads();
     if (q == 0) {
         const uint32_t *oscr = lds_scr[1];
 #pragma unroll
-        for (int r = 0; r < 16; ++r)
-            res[(size_t)blockIdx.x * NTT_N + r * 64 + lane] = (int32_t)crt_to_torus(y[r], oscr[r * 64 + lane]);
+        for (int r = 0; r < REGS; ++r)
+            res[(size_t)blockIdx.x * N + r * 64 + lane] = (int32_t)crt_to_torus(y[r], oscr[r * 64 + lane]);
     }
 }
 
@@ -130,8 +141,8 @@ struct StepConsts {
     int32_t half;        // Bg/2
 };
 
-// K1: t = (0,c0) + sa*A + sb*B, modulus switch to Z_{2N} (tfhe modSwitchFromTorus32), N = 1024
-template <int THREADS>
+// K1: t = (0,c0) + sa*A + sb*B, modulus switch to Z_{2N} (tfhe modSwitchFromTorus32)
+template <int LOGN, int THREADS>
 __device__ __forceinline__ void prelude_modswitch(const DevParams &p, const RotDesc &rd, const int32_t *__restrict__ pool,
                                                   uint16_t *lds_bar, int tid) {
     const int32_t *A = pool + (size_t)rd.slot_a * p.ct_stride;
@@ -139,49 +150,54 @@ __device__ __forceinline__ void prelude_modswitch(const DevParams &p, const RotD
     for (int i = tid; i <= p.n; i += THREADS) {
         uint32_t t = (uint32_t)rd.sa * (uint32_t)A[i] + (uint32_t)rd.sb * (uint32_t)B[i];
         if (i == p.n) t += (uint32_t)rd.c0;
-        lds_bar[i] = (uint16_t)((t + (1u << 20)) >> 21);     // round(t * 2N / 2^32) mod 2N
+        lds_bar[i] = (uint16_t)((t + (1u << (30 - LOGN))) >> (31 - LOGN));     // round(t * 2N / 2^32) mod 2N
     }
 }
 
 // body polynomial of ACC = (0, X^{-barb} * (mu + mu X + ... + mu X^{N-1})), coefficient j
+template <int LOGN>
 __device__ __forceinline__ uint32_t testvector_coef(int j, int barb, int32_t mu) {
-    const int idx = (j + barb) & (2 * NTT_N - 1);
-    return (idx & NTT_N) ? (uint32_t)(-mu) : (uint32_t)mu;
+    constexpr int N = 1 << LOGN;
+    const int idx = (j + barb) & (2 * N - 1);
+    return (idx & N) ? (uint32_t)(-mu) : (uint32_t)mu;
 }
 
 // One input polynomial u of one blind-rotate step, modulo the wave's prime:
 // D = (X^abar - 1) * ACC_u, its l gadget digits, forward NTT of each, and the
 // multiply-accumulate against key rows u*l+jj for both output polynomials
 // (acc0 <- output poly 0, acc1 <- output poly 1; exchanged when swap_outputs).
+template <int LOGN>
 __device__ __forceinline__ void forward_poly(const DevParams &p, const DevKey &key, const PrimeCtx &c,
                                              const StepConsts &sc, const uint32_t *lds_acc_u, uint32_t *scr,
                                              int lane, int q, int i, int u, int abar, bool swap_outputs,
-                                             int64_t (&acc0)[16], int64_t (&acc1)[16]) {
-    uint32_t D[16];
+                                             int64_t (&acc0)[WaveNtt<LOGN>::REGS], int64_t (&acc1)[WaveNtt<LOGN>::REGS]) {
+    using NTT = WaveNtt<LOGN>;
+    constexpr int N = NTT::N, REGS = NTT::REGS, G4 = REGS / 4;
+    uint32_t D[REGS];
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
+    for (int r = 0; r < REGS; ++r) {
         const int j = r * 64 + lane;
-        const int idx = (j - abar) & (2 * NTT_N - 1);
-        const uint32_t v = lds_acc_u[idx & (NTT_N - 1)];
-        D[r] = ((idx & NTT_N) ? 0u - v : v) - lds_acc_u[j] + p.decomp_offset;   // offset pre-added
+        const int idx = (j - abar) & (2 * N - 1);
+        const uint32_t v = lds_acc_u[idx & (N - 1)];
+        D[r] = ((idx & N) ? 0u - v : v) - lds_acc_u[j] + p.decomp_offset;   // offset pre-added
     }
 #pragma unroll 1
     for (int jj = 0; jj < p.l; ++jj) {
         const int prow = u * p.l + jj;
         const uint4 *bp = reinterpret_cast<const uint4 *>(
-                              key.bk_img + ((size_t)((size_t)i * p.kpl + prow) * 2 + q) * 2 * NTT_N) + lane;
-        uint4 b0[4], b1[4];
-        const int o0 = swap_outputs ? 256 : 0, o1 = 256 - o0;      // uint4 offset of output poly 0 / 1
+                              key.bk_img + ((size_t)((size_t)i * p.kpl + prow) * 2 + q) * 2 * N) + lane;
+        uint4 b0[G4], b1[G4];
+        const int o0 = swap_outputs ? N / 4 : 0, o1 = N / 4 - o0;      // uint4 offset of output poly 0 / 1
 #pragma unroll
-        for (int g = 0; g < 4; ++g) { b0[g] = bp[o0 + g * 64]; b1[g] = bp[o1 + g * 64]; }
+        for (int g = 0; g < G4; ++g) { b0[g] = bp[o0 + g * 64]; b1[g] = bp[o1 + g * 64]; }
 
         const int shift = 32 - (jj + 1) * p.Bgbit;
-        int32_t x[16];
+        int32_t x[REGS];
 #pragma unroll
-        for (int r = 0; r < 16; ++r) x[r] = (int32_t)((D[r] >> shift) & sc.dmask) - sc.half;   // signed digit
-        ntt_fwd_1024(x, c, scr, lane);
+        for (int r = 0; r < REGS; ++r) x[r] = (int32_t)((D[r] >> shift) & sc.dmask) - sc.half;   // signed digit
+        NTT::forward(x, c, scr, lane);
 #pragma unroll
-        for (int g = 0; g < 4; ++g) {
+        for (int g = 0; g < G4; ++g) {
             acc0[4 * g + 0] += (int64_t)x[4 * g + 0] * (int32_t)b0[g].x;
             acc0[4 * g + 1] += (int64_t)x[4 * g + 1] * (int32_t)b0[g].y;
             acc0[4 * g + 2] += (int64_t)x[4 * g + 2] * (int32_t)b0[g].z;
@@ -195,47 +211,53 @@ __device__ __forceinline__ void forward_poly(const DevParams &p, const DevKey &k
 }
 
 // sample extract at index 0 (tfhe tLweExtractLweSampleIndex) + optional raw accumulator dump
-template <int THREADS>
-__device__ __forceinline__ void extract_sample(const DevParams &p, const RotDesc &rd, const uint32_t (*lds_acc)[NTT_N],
+template <int LOGN, int THREADS>
+__device__ __forceinline__ void extract_sample(const DevParams &p, const RotDesc &rd,
+                                               const uint32_t (*lds_acc)[1 << LOGN],
                                                int32_t *__restrict__ u_buf, int32_t *__restrict__ acc_dbg, int tid) {
+    constexpr int N = 1 << LOGN;
     int32_t *u = u_buf + (size_t)rd.u_index * p.u_stride;
-    for (int j = tid; j < NTT_N; j += THREADS)
-        u[j] = (int32_t)(j == 0 ? lds_acc[0][0] : 0u - lds_acc[0][NTT_N - j]);
-    if (tid == 0) u[NTT_N] = (int32_t)lds_acc[1][0];
+    for (int j = tid; j < N; j += THREADS)
+        u[j] = (int32_t)(j == 0 ? lds_acc[0][0] : 0u - lds_acc[0][N - j]);
+    if (tid == 0) u[N] = (int32_t)lds_acc[1][0];
     if (acc_dbg) {
-        int32_t *d = acc_dbg + (size_t)blockIdx.x * 2 * NTT_N;
-        for (int j = tid; j < 2 * NTT_N; j += THREADS) d[j] = (int32_t)lds_acc[j >> 10][j & (NTT_N - 1)];
+        int32_t *d = acc_dbg + (size_t)blockIdx.x * 2 * N;
+        for (int j = tid; j < 2 * N; j += THREADS) d[j] = (int32_t)lds_acc[j >> LOGN][j & (N - 1)];
     }
 }
 
 // ---------------------------------------------------------------------------
-// K1+K2: blind rotate, throughput form.  grid = rotations, 128 threads: wave q
-// works modulo prime q and handles both input polynomials (6 forward + 2
-// inverse NTTs per step), 4 workgroups per CU.
+// K1+K2: blind rotate, 2-wave form.  grid = rotations, 128 threads: wave q works
+// modulo prime q and handles both input polynomials (6 forward + 2 inverse NTTs
+// per step), 4 workgroups per CU.  Kept selectable ("br4_max_rotations" = 0) and
+// tested; the 4-wave form below is faster at every launch width (N = 1024 only).
 // ---------------------------------------------------------------------------
+template <int LOGN>
 __global__ __launch_bounds__(128) void blind_rotate_kernel(DevParams p, DevKey key, const int32_t *__restrict__ pool,
                                                            const RotDesc *__restrict__ rots,
                                                            int32_t *__restrict__ u_buf, int32_t *__restrict__ acc_dbg) {
-    __shared__ __align__(16) uint32_t lds_acc[2][NTT_N];
-    __shared__ __align__(16) uint32_t lds_scr[2][NTT_SCRATCH_WORDS];
-    __shared__ uint16_t lds_bar[NTT_N + 8];
+    using NTT = WaveNtt<LOGN>;
+    constexpr int N = NTT::N, REGS = NTT::REGS;
+    __shared__ __align__(16) uint32_t lds_acc[2][N];
+    __shared__ __align__(16) uint32_t lds_scr[2][NTT::SCRATCH_WORDS];
+    __shared__ uint16_t lds_bar[1024 + 8];
 
     const int tid = threadIdx.x;
     const int q = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int lane = tid & 63;
-    const PrimeCtx c = make_ctx(q, key.tw);
+    const PrimeCtx c = make_ctx(q, key.tw, N);
     uint32_t *scr = lds_scr[q];
     const RotDesc rd = rots[blockIdx.x];
     const int n = p.n;
 
-    prelude_modswitch<128>(p, rd, pool, lds_bar, tid);
+    prelude_modswitch<LOGN, 128>(p, rd, pool, lds_bar, tid);
     __syncthreads();
     {
         const int barb = lds_bar[n];
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
+        for (int r = 0; r < REGS; ++r) {
             const int j = r * 64 + lane;
-            lds_acc[q][j] = q == 0 ? 0u : testvector_coef(j, barb, p.mu);
+            lds_acc[q][j] = q == 0 ? 0u : testvector_coef<LOGN>(j, barb, p.mu);
         }
     }
     __syncthreads();
@@ -246,39 +268,40 @@ __global__ __launch_bounds__(128) void blind_rotate_kernel(DevParams p, DevKey k
         const int abar = __builtin_amdgcn_readfirstlane((int)lds_bar[i]);
         if (abar == 0) continue;                            // tfhe_blindRotate_FFT skips these too
 
-        int64_t acc0[16], acc1[16];
+        int64_t acc0[REGS], acc1[REGS];
 #pragma unroll
-        for (int r = 0; r < 16; ++r) { acc0[r] = 0; acc1[r] = 0; }
+        for (int r = 0; r < REGS; ++r) { acc0[r] = 0; acc1[r] = 0; }
 #pragma unroll 1
-        for (int u = 0; u < 2; ++u) forward_poly(p, key, c, sc, lds_acc[u], scr, lane, q, i, u, abar, false, acc0, acc1);
+        for (int u = 0; u < 2; ++u)
+            forward_poly<LOGN>(p, key, c, sc, lds_acc[u], scr, lane, q, i, u, abar, false, acc0, acc1);
 
-        uint32_t y0[16], y1[16];
-        finish_inverse(acc0, y0, c, scr, lane);
-        finish_inverse(acc1, y1, c, scr, lane);
+        uint32_t y0[REGS], y1[REGS];
+        finish_inverse<LOGN>(acc0, y0, c, scr, lane);
+        finish_inverse<LOGN>(acc1, y1, c, scr, lane);
 
         // wave q owns output polynomial q: send the other one's residues across
         const uint32_t *oscr = lds_scr[1 - q];
         if (q == 0) {
 #pragma unroll
-            for (int r = 0; r < 16; ++r) scr[r * 64 + lane] = y1[r];
+            for (int r = 0; r < REGS; ++r) scr[r * 64 + lane] = y1[r];
             __syncthreads();
 #pragma unroll
-            for (int r = 0; r < 16; ++r) lds_acc[0][r * 64 + lane] += crt_to_torus(y0[r], oscr[r * 64 + lane]);
+            for (int r = 0; r < REGS; ++r) lds_acc[0][r * 64 + lane] += crt_to_torus(y0[r], oscr[r * 64 + lane]);
         } else {
 #pragma unroll
-            for (int r = 0; r < 16; ++r) scr[r * 64 + lane] = y0[r];
+            for (int r = 0; r < REGS; ++r) scr[r * 64 + lane] = y0[r];
             __syncthreads();
 #pragma unroll
-            for (int r = 0; r < 16; ++r) lds_acc[1][r * 64 + lane] += crt_to_torus(oscr[r * 64 + lane], y1[r]);
+            for (int r = 0; r < REGS; ++r) lds_acc[1][r * 64 + lane] += crt_to_torus(oscr[r * 64 + lane], y1[r]);
         }
         __syncthreads();
     }
-    extract_sample<128>(p, rd, lds_acc, u_buf, acc_dbg, tid);
+    extract_sample<LOGN, 128>(p, rd, lds_acc, u_buf, acc_dbg, tid);
 }
 
 #ifdef TFHE_HIP_STAMPS
-// Diagnostic build only (peba1_amd/csrc/build.sh stamps): per-phase shader-cycle sums of
-// the latency kernel, lane 0 of each wave, accumulated into a buffer nothing else reads.
+// Diagnostic build only (tools/diag/build_stamps.sh): per-phase shader-cycle sums of
+// the 4-wave kernel, lane 0 of each wave, accumulated into a buffer nothing else reads.
 __device__ unsigned long long g_stamps[4][8];
 #define STAMP_DECL unsigned long long st_prev = __builtin_amdgcn_s_memtime(), st_sum[8] = {0, 0, 0, 0, 0, 0, 0, 0}
 #define STAMP(k)                                                             \
@@ -302,39 +325,41 @@ __device__ unsigned long long g_stamps[4][8];
 #endif
 
 // ---------------------------------------------------------------------------
-// K1+K2: blind rotate, latency form for narrow levels.  grid = rotations, 256
-// threads: wave (q,u) works modulo prime q on input polynomial u (3 forward
-// NTTs), hands the partial sum of the other output polynomial to wave (q,1-u),
-// runs ONE inverse NTT for output polynomial u, and shares the CRT with wave
-// (1-q,u).  Half the dependent work per wave of the throughput form; three
-// workgroup barriers per step.  Same integers, so bit-identical results.
+// K1+K2: blind rotate, 4-wave form (the default).  grid = rotations, 256 threads:
+// wave (q,u) works modulo prime q on input polynomial u (l forward NTTs), hands
+// the partial sum of the other output polynomial to wave (q,1-u), runs ONE
+// inverse NTT for output polynomial u, and shares the CRT with wave (1-q,u).
+// Three workgroup barriers per step.  N = 1024: 2 workgroups per CU; N = 2048: 1.
 // ---------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void blind_rotate4_kernel(DevParams p, DevKey key, const int32_t *__restrict__ pool,
-                                                            const RotDesc *__restrict__ rots,
-                                                            int32_t *__restrict__ u_buf, int32_t *__restrict__ acc_dbg) {
-    __shared__ __align__(16) uint32_t lds_acc[2][NTT_N];
-    __shared__ __align__(16) uint32_t lds_scr[4][NTT_SCRATCH_WORDS];
-    __shared__ __align__(16) uint32_t lds_x1[4][NTT_SCRATCH_WORDS];   // partial sums of the partner's output poly
-    __shared__ __align__(16) uint32_t lds_x2[4][NTT_N / 2];           // residues of the half the partner recombines
-    __shared__ uint16_t lds_bar[NTT_N + 8];
+template <int LOGN>
+__global__ __launch_bounds__(256, LOGN == 10 ? 2 : 1) void blind_rotate4_kernel(
+    DevParams p, DevKey key, const int32_t *__restrict__ pool, const RotDesc *__restrict__ rots,
+    int32_t *__restrict__ u_buf, int32_t *__restrict__ acc_dbg) {
+    using NTT = WaveNtt<LOGN>;
+    constexpr int N = NTT::N, REGS = NTT::REGS, HALF = REGS / 2;
+    __shared__ __align__(16) uint32_t lds_acc[2][N];
+    __shared__ __align__(16) uint32_t lds_scr[4][NTT::SCRATCH_WORDS];
+    __shared__ __align__(16) uint32_t lds_x1[4][NTT::SCRATCH_WORDS];  // partial sums of the partner's output poly
+    __shared__ __align__(16) uint32_t lds_x2[4][N / 2];               // residues of the half the partner recombines
+    __shared__ uint16_t lds_bar[1024 + 8];
 
     const int tid = threadIdx.x;
     const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int q = wv & 1, u = wv >> 1;
     const int lane = tid & 63;
-    const PrimeCtx c = make_ctx(q, key.tw);
+    const PrimeCtx c = make_ctx(q, key.tw, N);
     uint32_t *scr = lds_scr[wv];
     const RotDesc rd = rots[blockIdx.x];
     const int n = p.n;
 
-    prelude_modswitch<256>(p, rd, pool, lds_bar, tid);
+    prelude_modswitch<LOGN, 256>(p, rd, pool, lds_bar, tid);
     __syncthreads();
     if (q == 0) {
         const int barb = lds_bar[n];
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
+        for (int r = 0; r < REGS; ++r) {
             const int j = r * 64 + lane;
-            lds_acc[u][j] = u == 0 ? 0u : testvector_coef(j, barb, p.mu);
+            lds_acc[u][j] = u == 0 ? 0u : testvector_coef<LOGN>(j, barb, p.mu);
         }
     }
     __syncthreads();
@@ -347,56 +372,57 @@ __global__ __launch_bounds__(256) void blind_rotate4_kernel(DevParams p, DevKey 
         if (abar == 0) continue;
         STAMP(0);
 
-        int64_t acc0[16], acc1[16];
+        int64_t acc0[REGS], acc1[REGS];
 #pragma unroll
-        for (int r = 0; r < 16; ++r) { acc0[r] = 0; acc1[r] = 0; }
+        for (int r = 0; r < REGS; ++r) { acc0[r] = 0; acc1[r] = 0; }
         // acc0 accumulates output poly u (kept), acc1 output poly 1-u (sent to wave (q,1-u))
-        forward_poly(p, key, c, sc, lds_acc[u], scr, lane, q, i, u, abar, u != 0, acc0, acc1);
+        forward_poly<LOGN>(p, key, c, sc, lds_acc[u], scr, lane, q, i, u, abar, u != 0, acc0, acc1);
         STAMP(1);
 
-        int32_t t[16], send[16];
+        int32_t t[REGS], send[REGS];
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            t[r] = mont_redc(acc0[r], c.P, c.pinv);                // 3 rows: |.| < 1.45P
+        for (int r = 0; r < REGS; ++r) {
+            t[r] = mont_redc(acc0[r], c.P, c.pinv);                // l rows: |.| < 1.6P
             send[r] = mont_redc(acc1[r], c.P, c.pinv);
         }
-        write_row16(send, lds_x1[wv], lane);
+        NTT::write_row(send, lds_x1[wv], lane);
         STAMP(2);
         __syncthreads();
         STAMP(3);
         {
-            int32_t other[16];
-            read_row16(other, lds_x1[wv ^ 2], lane);
+            int32_t other[REGS];
+            NTT::read_row(other, lds_x1[wv ^ 2], lane);
 #pragma unroll
-            for (int r = 0; r < 16; ++r) t[r] += other[r];         // |.| < 2.9P
+            for (int r = 0; r < REGS; ++r) t[r] += other[r];       // |.| < 3.1P
         }
-        ntt_inv_1024(t, c, scr, lane);
-        uint32_t y[16];
+        NTT::inverse(t, c, scr, lane);
+        uint32_t y[REGS];
 #pragma unroll
-        for (int r = 0; r < 16; ++r) y[r] = canon(t[r], c.P);
+        for (int r = 0; r < REGS; ++r) y[r] = canon(t[r], c.P);
         STAMP(4);
 
-        // CRT of output poly u is split with wave (1-q,u): wave q recombines registers [8q, 8q+8)
+        // CRT of output poly u is split with wave (1-q,u): wave q recombines registers [q*HALF, (q+1)*HALF)
         const uint32_t *ox = lds_x2[wv ^ 1];
         if (q == 0) {
 #pragma unroll
-            for (int r = 0; r < 8; ++r) lds_x2[wv][r * 64 + lane] = y[8 + r];
+            for (int r = 0; r < HALF; ++r) lds_x2[wv][r * 64 + lane] = y[HALF + r];
             __syncthreads();
 #pragma unroll
-            for (int r = 0; r < 8; ++r) lds_acc[u][r * 64 + lane] += crt_to_torus(y[r], ox[r * 64 + lane]);
+            for (int r = 0; r < HALF; ++r) lds_acc[u][r * 64 + lane] += crt_to_torus(y[r], ox[r * 64 + lane]);
         } else {
 #pragma unroll
-            for (int r = 0; r < 8; ++r) lds_x2[wv][r * 64 + lane] = y[r];
+            for (int r = 0; r < HALF; ++r) lds_x2[wv][r * 64 + lane] = y[r];
             __syncthreads();
 #pragma unroll
-            for (int r = 0; r < 8; ++r) lds_acc[u][(8 + r) * 64 + lane] += crt_to_torus(ox[r * 64 + lane], y[8 + r]);
+            for (int r = 0; r < HALF; ++r)
+                lds_acc[u][(HALF + r) * 64 + lane] += crt_to_torus(ox[r * 64 + lane], y[HALF + r]);
         }
         STAMP(5);
         __syncthreads();
         STAMP(6);
     }
     STAMP_FLUSH;
-    extract_sample<256>(p, rd, lds_acc, u_buf, acc_dbg, tid);
+    extract_sample<LOGN, 256>(p, rd, lds_acc, u_buf, acc_dbg, tid);
 }
 
 // ---------------------------------------------------------------------------
@@ -404,14 +430,14 @@ __global__ __launch_bounds__(256) void blind_rotate4_kernel(DevParams p, DevKey 
 // One workgroup per gate; thread t owns 4 consecutive output words and
 // subtracts the selected KSK rows with 16-byte loads.
 // ---------------------------------------------------------------------------
-constexpr int KS_THREADS = 192;
+constexpr int KS_MAX_THREADS = 320;   // launched with ct_stride/4 rounded up to a wave: 192 (n=630), 320 (n=1024)
 
 // grid (gates, splits): block (g, s) handles input coefficients [s*nin/splits, (s+1)*nin/splits).
 // splits == 1: the result goes straight to the destination slot.  splits > 1 (narrow
 // levels, where one workgroup per gate would leave the chip idle and serialise 6,144
 // dependent row loads): partial sums go to `partial[g][s][ct_stride]` and
 // ks_reduce_kernel adds them (integer adds: any order is bit-exact).
-__global__ __launch_bounds__(KS_THREADS) void keyswitch_kernel(DevParams p, DevKey key, const int32_t *__restrict__ u_buf,
+__global__ __launch_bounds__(KS_MAX_THREADS) void keyswitch_kernel(DevParams p, DevKey key, const int32_t *__restrict__ u_buf,
                                                                const KsDesc *__restrict__ descs,
                                                                int32_t *__restrict__ pool, int32_t *__restrict__ partial) {
     __shared__ uint32_t su[2048 + 8];
@@ -423,7 +449,7 @@ __global__ __launch_bounds__(KS_THREADS) void keyswitch_kernel(DevParams p, DevK
     {
         const int32_t *u0 = u_buf + (size_t)d.u0 * p.u_stride;
         const int32_t *u1 = d.u1 >= 0 ? u_buf + (size_t)d.u1 * p.u_stride : nullptr;
-        for (int j = i0 + tid; j < i1; j += KS_THREADS) su[j - i0] = (uint32_t)u0[j] + (u1 ? (uint32_t)u1[j] : 0u);
+        for (int j = i0 + tid; j < i1; j += (int)blockDim.x) su[j - i0] = (uint32_t)u0[j] + (u1 ? (uint32_t)u1[j] : 0u);
         if (tid == 0) su[i1 - i0] = (uint32_t)u0[nin] + (u1 ? (uint32_t)u1[nin] : 0u) + (uint32_t)d.add_b;   // body
     }
     __syncthreads();
@@ -455,7 +481,7 @@ __global__ __launch_bounds__(KS_THREADS) void keyswitch_kernel(DevParams p, DevK
     reinterpret_cast<uint4 *>(dst)[tid] = make_uint4(o[0], o[1], o[2], o[3]);
 }
 
-__global__ __launch_bounds__(KS_THREADS) void ks_reduce_kernel(DevParams p, const KsDesc *__restrict__ descs, int splits,
+__global__ __launch_bounds__(KS_MAX_THREADS) void ks_reduce_kernel(DevParams p, const KsDesc *__restrict__ descs, int splits,
                                                                const int32_t *__restrict__ partial,
                                                                int32_t *__restrict__ pool) {
     const int tid = threadIdx.x;
@@ -506,16 +532,23 @@ void launch_scatter_slots(hipStream_t s, int32_t *pool, int stride, int words, c
 
 void launch_bk_transform(hipStream_t s, const DevParams &p, const int32_t *raw_polys, uint32_t *img,
                          const uint32_t *tw, int npoly_per_w, int nw, const uint32_t scale[2]) {
-    (void)p;
     if (npoly_per_w * nw <= 0) return;
-    hipLaunchKernelGGL(bk_transform_kernel, dim3(npoly_per_w * nw, 2), dim3(64), 0, s, raw_polys, img, tw, nw,
-                       scale[0], scale[1]);
+    if (p.N == 2048)
+        hipLaunchKernelGGL(bk_transform_kernel<11>, dim3(npoly_per_w * nw, 2), dim3(64), 0, s, raw_polys, img, tw, nw,
+                           scale[0], scale[1]);
+    else
+        hipLaunchKernelGGL(bk_transform_kernel<10>, dim3(npoly_per_w * nw, 2), dim3(64), 0, s, raw_polys, img, tw, nw,
+                           scale[0], scale[1]);
 }
 
 void launch_blind_rotate(hipStream_t s, const DevParams &p, const DevKey &key, const int32_t *pool,
                          const RotDesc *rots, int count, int32_t *u_buf, int32_t *acc_dbg) {
     if (count <= 0) return;
-    hipLaunchKernelGGL(blind_rotate_kernel, dim3(count), dim3(128), 0, s, p, key, pool, rots, u_buf, acc_dbg);
+    // the 2-wave form exists for N = 1024 only; N = 2048 always takes the 4-wave form
+    if (p.N == 2048)
+        hipLaunchKernelGGL(blind_rotate4_kernel<11>, dim3(count), dim3(256), 0, s, p, key, pool, rots, u_buf, acc_dbg);
+    else
+        hipLaunchKernelGGL(blind_rotate_kernel<10>, dim3(count), dim3(128), 0, s, p, key, pool, rots, u_buf, acc_dbg);
 }
 
 #ifdef TFHE_HIP_STAMPS
@@ -528,18 +561,22 @@ void read_stamps(unsigned long long *out, bool reset) {
 void launch_blind_rotate4(hipStream_t s, const DevParams &p, const DevKey &key, const int32_t *pool,
                           const RotDesc *rots, int count, int32_t *u_buf, int32_t *acc_dbg) {
     if (count <= 0) return;
-    hipLaunchKernelGGL(blind_rotate4_kernel, dim3(count), dim3(256), 0, s, p, key, pool, rots, u_buf, acc_dbg);
+    if (p.N == 2048)
+        hipLaunchKernelGGL(blind_rotate4_kernel<11>, dim3(count), dim3(256), 0, s, p, key, pool, rots, u_buf, acc_dbg);
+    else
+        hipLaunchKernelGGL(blind_rotate4_kernel<10>, dim3(count), dim3(256), 0, s, p, key, pool, rots, u_buf, acc_dbg);
 }
 
 void launch_keyswitch(hipStream_t s, const DevParams &p, const DevKey &key, const int32_t *u_buf,
                       const KsDesc *descs, int count, int32_t *pool, int splits, int32_t *partial) {
     if (count <= 0) return;
+    const int threads = ((p.ct_stride / 4 + 63) / 64) * 64;      // one 16-byte lane per 4 output words
     if (splits <= 1 || !partial) {
-        hipLaunchKernelGGL(keyswitch_kernel, dim3(count, 1), dim3(KS_THREADS), 0, s, p, key, u_buf, descs, pool, nullptr);
+        hipLaunchKernelGGL(keyswitch_kernel, dim3(count, 1), dim3(threads), 0, s, p, key, u_buf, descs, pool, nullptr);
         return;
     }
-    hipLaunchKernelGGL(keyswitch_kernel, dim3(count, splits), dim3(KS_THREADS), 0, s, p, key, u_buf, descs, pool, partial);
-    hipLaunchKernelGGL(ks_reduce_kernel, dim3(count), dim3(KS_THREADS), 0, s, p, descs, splits, partial, pool);
+    hipLaunchKernelGGL(keyswitch_kernel, dim3(count, splits), dim3(threads), 0, s, p, key, u_buf, descs, pool, partial);
+    hipLaunchKernelGGL(ks_reduce_kernel, dim3(count), dim3(threads), 0, s, p, descs, splits, partial, pool);
 }
 
 void launch_not(hipStream_t s, const DevParams &p, const NotDesc *descs, int count, int32_t *pool) {
@@ -549,9 +586,9 @@ void launch_not(hipStream_t s, const DevParams &p, const NotDesc *descs, int cou
 
 void launch_negacyclic(hipStream_t s, const DevParams &p, const uint32_t *tw, const int32_t *ip,
                        const uint32_t *img, int32_t *res, int count) {
-    (void)p;
     if (count <= 0) return;
-    hipLaunchKernelGGL(negacyclic_kernel, dim3(count), dim3(128), 0, s, ip, img, tw, res);
+    if (p.N == 2048) hipLaunchKernelGGL(negacyclic_kernel<11>, dim3(count), dim3(128), 0, s, ip, img, tw, res);
+    else hipLaunchKernelGGL(negacyclic_kernel<10>, dim3(count), dim3(128), 0, s, ip, img, tw, res);
 }
 
 }  // namespace tfhe_hip

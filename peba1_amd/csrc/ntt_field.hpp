@@ -18,7 +18,6 @@ namespace tfhe_hip {
 
 constexpr uint32_t NTT_P[2] = {134111233u /*0x7fe6001*/, 134176769u /*0x7ff6001*/};
 constexpr int NTT_MAX_LOGN = 11;   // 4096 | P-1 for both primes
-constexpr int NTT_N = 1024;         // ring degree the wave kernels are specialised for
 
 constexpr uint32_t neg_inv32(uint32_t p) {
     // Newton iteration for p^-1 mod 2^32, then negate

@@ -1,12 +1,15 @@
-// ntt_wave.hpp -- one wave64 computes one 1024-point negacyclic NTT mod a
-// 27-bit prime, 16 coefficients per lane in registers, two LDS transposes.
+// ntt_wave.hpp -- one wave64 computes one N-point negacyclic NTT (N = 1024 or 2048)
+// modulo a 27-bit prime: N/64 coefficients per lane in registers, two LDS transposes.
 //
-// Index j = b9..b0.  Register/lane layouts (validated by tools/ntt_model.py):
-//   L0: reg = b9..b6, lane = b5..b0            (natural: j = 64*reg + lane)
-//   L1: reg = b5..b2, lane = (b9..b6, b1, b0)
-//   L2: reg = b3..b0, lane = b9..b4            (j = 16*lane + reg)
+// Index j has LOGN bits; RB = LOGN-6 register bits, REGS = 2^RB coefficients per lane,
+// LC = LOGN-2*RB (2 for N=1024, 1 for N=2048).  Register/lane layouts (validated by
+// tools/ntt_model.py and tools/ntt_model_generic.py):
+//   L0: reg = top RB bits,        lane = low 6 bits              (natural: j = 64*reg + lane)
+//   L1: reg = next RB bits,       lane = (top RB bits, low LC bits)
+//   L2: reg = low RB bits,        lane = top 6 bits              (j = REGS*lane + reg)
 // forward (Cooley-Tukey, natural in -> bit-reversed out, psi-merged twiddles):
-//   stages 0-3 in L0, transpose, 4-7 in L1, transpose, 8-9 in L2.
+//   RB stages in L0, transpose, RB stages in L1, transpose, LC stages in L2
+//   (4+4+2 for N=1024, 5+5+1 for N=2048).
 // inverse (Gentleman-Sande) runs the same path backwards and ends in L0.
 // A butterfly always pairs two registers of one lane; the twiddle of stage s is
 // W[2^s + (top s bits of j)]: lane-uniform in L0 (scalar loads), per-lane but
@@ -16,12 +19,12 @@
 //   Montgomery product r = b*w/R mod P with |r| < P for ANY |b| < 2^31, w in [0,P)
 //   (v_mad_i64_i32, v_mul_lo_u32, v_mad_i64_i32);
 //   forward butterfly (a,b) -> (a + r, a - r): 5 instructions, magnitudes grow by
-//   P per stage: digits (|d| <= 2^11) end below 10P + 2^11 < 2^31, no reductions;
+//   P per stage: digits (|d| <= 2^11) end below LOGN*P + 2^11 < 2^31, no reductions;
 //   inverse butterfly (a,b) -> (a + b, (a - b)*w): sums double, so the sum is
-//   renormalised (times R mod P, 3 more instructions) at stages 8, 4 and 0 only:
-//   |in| < 3P -> 6P -> [8] P -> 2P,4P,8P -> [4] P -> 2P,4P,8P -> [0] P, and the
-//   largest intermediate, a +- b at the renormalising stages, is < 16P < 2^31
-//   (16*P1 = 2,146,828,304).
+//   renormalised (times R mod P, 3 more instructions) only at the stages where the
+//   next doubling would pass 16P < 2^31 (16*P1 = 2,146,828,304), and at the last:
+//   stages 8,4,0 for N=1024 and 9,5,1,0 for N=2048 (inv_renorm_mask below), for any
+//   input below 4P.
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -29,8 +32,6 @@
 #include "ntt_field.hpp"
 
 namespace tfhe_hip {
-
-constexpr int NTT_SCRATCH_WORDS = 1088;   // 16 rows of 64 words, each padded by 4
 
 struct PrimeCtx {
     uint32_t P;        // prime
@@ -79,139 +80,182 @@ __device__ __forceinline__ void gs_bfly(int32_t &a, int32_t &b, uint32_t w, cons
     b = mont_mul(a0 - b0, w, c.P, c.pinv);
 }
 
-// ---- transposes through wave-private LDS scratch -------------------------
-// T1 address space: word(lane', reg') = lane'*16 + reg' + 4*(lane'>>2) in L1 terms
-__device__ __forceinline__ int t1_l0_addr(int lane, int reg) { return reg * 68 + (lane & 3) * 16 + (lane >> 2); }
-// T2 address space: natural order padded, word(j) = j + 4*(j>>6)
-__device__ __forceinline__ int t2_l1_addr(int lane, int reg) { return reg * 4 + (lane >> 2) * 68 + (lane & 3); }
-__device__ __forceinline__ int row16_base(int lane) { return lane * 16 + 4 * (lane >> 2); }
+// stages of the inverse transform whose sums are renormalised (bit s set), for inputs < 4P
+constexpr uint32_t inv_renorm_mask(int logn) {
+    uint32_t mask = 0;
+    int bound = 4;                       // in units of P
+    for (int s = logn - 1; s >= 0; --s) {
+        // this stage forms a +- b < 2*bound*P (must stay <= 16P); without renormalisation the
+        // next stage would form sums below 4*bound*P
+        if (s == 0 || 4 * bound > 16) { mask |= 1u << s; bound = 1; }
+        else bound *= 2;
+    }
+    return mask;
+}
+static_assert(inv_renorm_mask(10) == ((1u << 8) | (1u << 4) | 1u), "N=1024 renormalisation schedule");
+static_assert(inv_renorm_mask(11) == ((1u << 9) | (1u << 5) | (1u << 1) | 1u), "N=2048 renormalisation schedule");
 
-template <typename T>
-__device__ __forceinline__ void read_row16(T (&x)[16], const uint32_t *scr, int lane) {
-    const uint4 *p = reinterpret_cast<const uint4 *>(scr + row16_base(lane));
-#pragma unroll
-    for (int g = 0; g < 4; ++g) {
-        const uint4 v = p[g];
-        x[4 * g] = (T)v.x; x[4 * g + 1] = (T)v.y; x[4 * g + 2] = (T)v.z; x[4 * g + 3] = (T)v.w;
-    }
-}
-template <typename T>
-__device__ __forceinline__ void write_row16(const T (&x)[16], uint32_t *scr, int lane) {
-    uint4 *p = reinterpret_cast<uint4 *>(scr + row16_base(lane));
-#pragma unroll
-    for (int g = 0; g < 4; ++g)
-        p[g] = make_uint4((uint32_t)x[4 * g], (uint32_t)x[4 * g + 1], (uint32_t)x[4 * g + 2], (uint32_t)x[4 * g + 3]);
-}
+template <int LOGN>
+struct WaveNtt {
+    static constexpr int N = 1 << LOGN;
+    static constexpr int RB = LOGN - 6;              // register bits
+    static constexpr int REGS = 1 << RB;             // coefficients per lane
+    static constexpr int LC = LOGN - 2 * RB;         // stages of the last pass
+    static constexpr int SCRATCH_WORDS = N + 4 * (64 >> LC);   // rows of REGS words, padded
+    static_assert(LOGN == 10 || LOGN == 11, "wave NTT is laid out for N = 1024 or 2048");
 
-// forward NTT: x in L0 (natural order), |x| <= 2^11 -> L2, |x| < 10P + 2^11
-__device__ __forceinline__ void ntt_fwd_1024(int32_t (&x)[16], const PrimeCtx &c, uint32_t *scr, int lane) {
-    // pass A: stages 0..3, pairs differ in reg bit 3-s, twiddles lane-uniform
-#pragma unroll
-    for (int s = 0; s < 4; ++s) {
-        const int h = 1 << (3 - s);
-#pragma unroll
-        for (int r = 0; r < 16; ++r)
-            if (!(r & h)) ct_bfly(x[r], x[r | h], c.wf[(1 << s) + (r >> (4 - s))], c);
+    // ---- transposes through wave-private LDS scratch ---------------------------
+    // row of `lane` in the layout being read: REGS contiguous words
+    static __device__ __forceinline__ int row_base(int lane) { return lane * REGS + 4 * (lane >> LC); }
+    // where (lane, reg) of L0 lands so that L1 reads rows
+    static __device__ __forceinline__ int t1_l0_addr(int lane, int reg) {
+        const int lane1 = (reg << LC) | (lane & ((1 << LC) - 1));
+        return lane1 * REGS + (lane >> LC) + 4 * (lane1 >> LC);
     }
-    // L0 -> L1
-#pragma unroll
-    for (int r = 0; r < 16; ++r) scr[t1_l0_addr(lane, r)] = (uint32_t)x[r];
-    wave_lds_fence();
-    read_row16(x, scr, lane);
-    wave_lds_fence();
-    {   // pass B: stages 4..7, twiddle index 2^s + (a << (s-4)) + (reg >> (8-s)), a = lane>>2
-        const int a = lane >> 2;
-        const uint32_t w4 = c.wf[16 + a];
-        const uint2 w5 = *reinterpret_cast<const uint2 *>(c.wf + 32 + 2 * a);
-        const uint4 w6 = *reinterpret_cast<const uint4 *>(c.wf + 64 + 4 * a);
-        const uint4 w7a = *reinterpret_cast<const uint4 *>(c.wf + 128 + 8 * a);
-        const uint4 w7b = *reinterpret_cast<const uint4 *>(c.wf + 128 + 8 * a + 4);
-        const uint32_t t5[2] = {w5.x, w5.y};
-        const uint32_t t6[4] = {w6.x, w6.y, w6.z, w6.w};
-        const uint32_t t7[8] = {w7a.x, w7a.y, w7a.z, w7a.w, w7b.x, w7b.y, w7b.z, w7b.w};
-#pragma unroll
-        for (int r = 0; r < 8; ++r) ct_bfly(x[r], x[r | 8], w4, c);
-#pragma unroll
-        for (int r = 0; r < 16; ++r) if (!(r & 4)) ct_bfly(x[r], x[r | 4], t5[r >> 3], c);
-#pragma unroll
-        for (int r = 0; r < 16; ++r) if (!(r & 2)) ct_bfly(x[r], x[r | 2], t6[r >> 2], c);
-#pragma unroll
-        for (int r = 0; r < 16; ++r) if (!(r & 1)) ct_bfly(x[r], x[r | 1], t7[r >> 1], c);
+    // where (lane, reg) of L1 lands so that L2 reads rows: natural order j, padded
+    static __device__ __forceinline__ int t2_l1_addr(int lane, int reg) {
+        const int j = ((lane >> LC) << (LOGN - RB)) | (reg << LC) | (lane & ((1 << LC) - 1));
+        return j + 4 * (j >> (LOGN - RB));
     }
-    // L1 -> L2
+    template <typename T>
+    static __device__ __forceinline__ void read_row(T (&x)[REGS], const uint32_t *scr, int lane) {
+        const uint4 *p = reinterpret_cast<const uint4 *>(scr + row_base(lane));
 #pragma unroll
-    for (int r = 0; r < 16; ++r) scr[t2_l1_addr(lane, r)] = (uint32_t)x[r];
-    wave_lds_fence();
-    read_row16(x, scr, lane);
-    wave_lds_fence();
-    {   // pass C: stages 8,9, twiddle index 2^s + (lane << (s-6)) + (reg >> (10-s))
-        const uint4 w8 = *reinterpret_cast<const uint4 *>(c.wf + 256 + 4 * lane);
-        const uint4 w9a = *reinterpret_cast<const uint4 *>(c.wf + 512 + 8 * lane);
-        const uint4 w9b = *reinterpret_cast<const uint4 *>(c.wf + 512 + 8 * lane + 4);
-        const uint32_t t8[4] = {w8.x, w8.y, w8.z, w8.w};
-        const uint32_t t9[8] = {w9a.x, w9a.y, w9a.z, w9a.w, w9b.x, w9b.y, w9b.z, w9b.w};
-#pragma unroll
-        for (int r = 0; r < 16; ++r) if (!(r & 2)) ct_bfly(x[r], x[r | 2], t8[r >> 2], c);
-#pragma unroll
-        for (int r = 0; r < 16; ++r) if (!(r & 1)) ct_bfly(x[r], x[r | 1], t9[r >> 1], c);
+        for (int g = 0; g < REGS / 4; ++g) {
+            const uint4 v = p[g];
+            x[4 * g] = (T)v.x; x[4 * g + 1] = (T)v.y; x[4 * g + 2] = (T)v.z; x[4 * g + 3] = (T)v.w;
+        }
     }
-}
+    template <typename T>
+    static __device__ __forceinline__ void write_row(const T (&x)[REGS], uint32_t *scr, int lane) {
+        uint4 *p = reinterpret_cast<uint4 *>(scr + row_base(lane));
+#pragma unroll
+        for (int g = 0; g < REGS / 4; ++g)
+            p[g] = make_uint4((uint32_t)x[4 * g], (uint32_t)x[4 * g + 1], (uint32_t)x[4 * g + 2], (uint32_t)x[4 * g + 3]);
+    }
 
-// inverse NTT (unscaled: the 1/N is folded into the key image):
-// x in L2, |x| < 3P -> L0 (natural order), |x| < P
-__device__ __forceinline__ void ntt_inv_1024(int32_t (&x)[16], const PrimeCtx &c, uint32_t *scr, int lane) {
-    {
-        const uint4 w8 = *reinterpret_cast<const uint4 *>(c.wi + 256 + 4 * lane);
-        const uint4 w9a = *reinterpret_cast<const uint4 *>(c.wi + 512 + 8 * lane);
-        const uint4 w9b = *reinterpret_cast<const uint4 *>(c.wi + 512 + 8 * lane + 4);
-        const uint32_t t8[4] = {w8.x, w8.y, w8.z, w8.w};
-        const uint32_t t9[8] = {w9a.x, w9a.y, w9a.z, w9a.w, w9b.x, w9b.y, w9b.z, w9b.w};
+    // CNT consecutive twiddles starting at w (CNT = 1, 2, 4, 8, 16; w aligned to CNT words)
+    template <int CNT>
+    static __device__ __forceinline__ void load_tw(uint32_t (&t)[CNT], const uint32_t *__restrict__ w) {
+        if constexpr (CNT == 1) {
+            t[0] = w[0];
+        } else if constexpr (CNT == 2) {
+            const uint2 v = *reinterpret_cast<const uint2 *>(w);
+            t[0] = v.x; t[1] = v.y;
+        } else {
 #pragma unroll
-        for (int r = 0; r < 16; ++r) if (!(r & 1)) gs_bfly<false>(x[r], x[r | 1], t9[r >> 1], c);
-#pragma unroll
-        for (int r = 0; r < 16; ++r) if (!(r & 2)) gs_bfly<true>(x[r], x[r | 2], t8[r >> 2], c);
+            for (int g = 0; g < CNT / 4; ++g) {
+                const uint4 v = reinterpret_cast<const uint4 *>(w)[g];
+                t[4 * g] = v.x; t[4 * g + 1] = v.y; t[4 * g + 2] = v.z; t[4 * g + 3] = v.w;
+            }
+        }
     }
-    // L2 -> L1
-    write_row16(x, scr, lane);
-    wave_lds_fence();
+
+    // One stage whose butterflies pair register bit RBIT of a lane; `tw` holds the
+    // REGS >> (RBIT+1) twiddles this lane needs, indexed by the register bits above RBIT.
+    template <int RBIT>
+    static __device__ __forceinline__ void fwd_stage(int32_t (&x)[REGS], const uint32_t (&tw)[REGS >> (RBIT + 1)],
+                                                     const PrimeCtx &c) {
+        constexpr int h = 1 << RBIT;
 #pragma unroll
-    for (int r = 0; r < 16; ++r) x[r] = (int32_t)scr[t2_l1_addr(lane, r)];
-    wave_lds_fence();
-    {
-        const int a = lane >> 2;
-        const uint32_t w4 = c.wi[16 + a];
-        const uint2 w5 = *reinterpret_cast<const uint2 *>(c.wi + 32 + 2 * a);
-        const uint4 w6 = *reinterpret_cast<const uint4 *>(c.wi + 64 + 4 * a);
-        const uint4 w7a = *reinterpret_cast<const uint4 *>(c.wi + 128 + 8 * a);
-        const uint4 w7b = *reinterpret_cast<const uint4 *>(c.wi + 128 + 8 * a + 4);
-        const uint32_t t5[2] = {w5.x, w5.y};
-        const uint32_t t6[4] = {w6.x, w6.y, w6.z, w6.w};
-        const uint32_t t7[8] = {w7a.x, w7a.y, w7a.z, w7a.w, w7b.x, w7b.y, w7b.z, w7b.w};
-#pragma unroll
-        for (int r = 0; r < 16; ++r) if (!(r & 1)) gs_bfly<false>(x[r], x[r | 1], t7[r >> 1], c);
-#pragma unroll
-        for (int r = 0; r < 16; ++r) if (!(r & 2)) gs_bfly<false>(x[r], x[r | 2], t6[r >> 2], c);
-#pragma unroll
-        for (int r = 0; r < 16; ++r) if (!(r & 4)) gs_bfly<false>(x[r], x[r | 4], t5[r >> 3], c);
-#pragma unroll
-        for (int r = 0; r < 8; ++r) gs_bfly<true>(x[r], x[r | 8], w4, c);
+        for (int r = 0; r < REGS; ++r)
+            if (!(r & h)) ct_bfly(x[r], x[r | h], tw[r >> (RBIT + 1)], c);
     }
-    // L1 -> L0
-    write_row16(x, scr, lane);
-    wave_lds_fence();
+    template <int RBIT, bool RENORM>
+    static __device__ __forceinline__ void inv_stage(int32_t (&x)[REGS], const uint32_t (&tw)[REGS >> (RBIT + 1)],
+                                                     const PrimeCtx &c) {
+        constexpr int h = 1 << RBIT;
 #pragma unroll
-    for (int r = 0; r < 16; ++r) x[r] = (int32_t)scr[t1_l0_addr(lane, r)];
-    wave_lds_fence();
-#pragma unroll
-    for (int s = 3; s >= 1; --s) {
-        const int h = 1 << (3 - s);
-#pragma unroll
-        for (int r = 0; r < 16; ++r)
-            if (!(r & h)) gs_bfly<false>(x[r], x[r | h], c.wi[(1 << s) + (r >> (4 - s))], c);
+        for (int r = 0; r < REGS; ++r)
+            if (!(r & h)) gs_bfly<RENORM>(x[r], x[r | h], tw[r >> (RBIT + 1)], c);
     }
+
+    // stage S of the forward transform in the layout it belongs to
+    template <int S>
+    static __device__ __forceinline__ void fwd(int32_t (&x)[REGS], const PrimeCtx &c, int lane) {
+        if constexpr (S < RB) {                                   // L0: lane-uniform twiddles
+            constexpr int RBIT = RB - 1 - S;
+            uint32_t tw[REGS >> (RBIT + 1)];
 #pragma unroll
-    for (int r = 0; r < 8; ++r) gs_bfly<true>(x[r], x[r | 8], c.wi[1], c);
-}
+            for (int e = 0; e < (REGS >> (RBIT + 1)); ++e) tw[e] = c.wf[(1 << S) + e];
+            fwd_stage<RBIT>(x, tw, c);
+        } else if constexpr (S < 2 * RB) {                        // L1
+            constexpr int RBIT = 2 * RB - 1 - S;
+            uint32_t tw[REGS >> (RBIT + 1)];
+            load_tw<(REGS >> (RBIT + 1))>(tw, c.wf + (1 << S) + ((lane >> LC) << (S - RB)));
+            fwd_stage<RBIT>(x, tw, c);
+        } else {                                                  // L2
+            constexpr int RBIT = LOGN - 1 - S;
+            uint32_t tw[REGS >> (RBIT + 1)];
+            load_tw<(REGS >> (RBIT + 1))>(tw, c.wf + (1 << S) + (lane << (S - 6)));
+            fwd_stage<RBIT>(x, tw, c);
+        }
+    }
+    template <int S>
+    static __device__ __forceinline__ void inv(int32_t (&x)[REGS], const PrimeCtx &c, int lane) {
+        constexpr bool RN = (inv_renorm_mask(LOGN) >> S) & 1u;
+        if constexpr (S < RB) {
+            constexpr int RBIT = RB - 1 - S;
+            uint32_t tw[REGS >> (RBIT + 1)];
+#pragma unroll
+            for (int e = 0; e < (REGS >> (RBIT + 1)); ++e) tw[e] = c.wi[(1 << S) + e];
+            inv_stage<RBIT, RN>(x, tw, c);
+        } else if constexpr (S < 2 * RB) {
+            constexpr int RBIT = 2 * RB - 1 - S;
+            uint32_t tw[REGS >> (RBIT + 1)];
+            load_tw<(REGS >> (RBIT + 1))>(tw, c.wi + (1 << S) + ((lane >> LC) << (S - RB)));
+            inv_stage<RBIT, RN>(x, tw, c);
+        } else {
+            constexpr int RBIT = LOGN - 1 - S;
+            uint32_t tw[REGS >> (RBIT + 1)];
+            load_tw<(REGS >> (RBIT + 1))>(tw, c.wi + (1 << S) + (lane << (S - 6)));
+            inv_stage<RBIT, RN>(x, tw, c);
+        }
+    }
+    template <int S0, int S1>   // stages S0 .. S1-1 ascending
+    static __device__ __forceinline__ void fwd_range(int32_t (&x)[REGS], const PrimeCtx &c, int lane) {
+        if constexpr (S0 < S1) { fwd<S0>(x, c, lane); fwd_range<S0 + 1, S1>(x, c, lane); }
+    }
+    template <int S1, int S0>   // stages S1-1 .. S0 descending
+    static __device__ __forceinline__ void inv_range(int32_t (&x)[REGS], const PrimeCtx &c, int lane) {
+        if constexpr (S1 > S0) { inv<S1 - 1>(x, c, lane); inv_range<S1 - 1, S0>(x, c, lane); }
+    }
+
+    // forward NTT: x in L0 (natural order), |x| <= 2^11 -> L2, |x| < LOGN*P + 2^11
+    static __device__ __forceinline__ void forward(int32_t (&x)[REGS], const PrimeCtx &c, uint32_t *scr, int lane) {
+        fwd_range<0, RB>(x, c, lane);
+#pragma unroll
+        for (int r = 0; r < REGS; ++r) scr[t1_l0_addr(lane, r)] = (uint32_t)x[r];
+        wave_lds_fence();
+        read_row(x, scr, lane);
+        wave_lds_fence();
+        fwd_range<RB, 2 * RB>(x, c, lane);
+#pragma unroll
+        for (int r = 0; r < REGS; ++r) scr[t2_l1_addr(lane, r)] = (uint32_t)x[r];
+        wave_lds_fence();
+        read_row(x, scr, lane);
+        wave_lds_fence();
+        fwd_range<2 * RB, LOGN>(x, c, lane);
+    }
+
+    // inverse NTT (unscaled: the 1/N is folded into the key image):
+    // x in L2, |x| < 4P -> L0 (natural order), |x| < P
+    static __device__ __forceinline__ void inverse(int32_t (&x)[REGS], const PrimeCtx &c, uint32_t *scr, int lane) {
+        inv_range<LOGN, 2 * RB>(x, c, lane);
+        write_row(x, scr, lane);
+        wave_lds_fence();
+#pragma unroll
+        for (int r = 0; r < REGS; ++r) x[r] = (int32_t)scr[t2_l1_addr(lane, r)];
+        wave_lds_fence();
+        inv_range<2 * RB, RB>(x, c, lane);
+        write_row(x, scr, lane);
+        wave_lds_fence();
+#pragma unroll
+        for (int r = 0; r < REGS; ++r) x[r] = (int32_t)scr[t1_l0_addr(lane, r)];
+        wave_lds_fence();
+        inv_range<RB, 0>(x, c, lane);
+    }
+};
 
 // CRT of canonical residues r0 (mod P0) and r1 (mod P1): the centred integer
 // they represent, reduced mod 2^32

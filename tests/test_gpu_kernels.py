@@ -102,3 +102,52 @@ def test_keyswitch_matches_oracle(p128_keys, oracle, ks_blocks):
         api.set_tuning("ks_target_blocks", 2048)
     for c in range(5):
         assert (got[c] == oks.keyswitch(u[c])).all(), f"sample {c}"
+
+
+# ---------------------------------------------------------------- BASELINE configs[4]: N = 2048
+@pytest.fixture(scope="module")
+def p2048_keys(oracle):
+    """High-security set (N=2048, Bg=2^6, l=3; n=1024, ks 8x2 bit fixed by this repo)."""
+    from peba1_amd import api
+    seed = 0x2048
+    pp = api.ParameterSet(p2048=True)
+    ks = api.SecretKeySet(pp, seed, device=True)
+    oks = oracle.KeySet(oracle.params("P2048"), seed)
+    yield pp, ks, oks
+    ks.close()
+
+
+def test_p2048_negacyclic_and_gates(p2048_keys, oracle):
+    from peba1_amd import api, lib
+    pp, ks, oks = p2048_keys
+    assert (ks.bk() == oks.bk()).all() and (ks.ksk() == oks.ksk()).all()
+    rng = np.random.default_rng(11)
+    ip = rng.integers(-32, 32, (3, 2048), dtype=np.int64).astype(np.int32)
+    tp = rng.integers(-2**31, 2**31, (3, 2048), dtype=np.int64).astype(np.int32)
+    ip[0, :] = -32; tp[0, :] = -2**31
+    got = api.kernel_negacyclic(ks, ip, tp)
+    for c in range(3):
+        assert (got[c] == oracle.negacyclic(ip[c], tp[c], ntt=False)).all(), c
+    # one blind rotation + key switch, word for word
+    r = oracle.Rng(5)
+    cts = oks.encrypt(r, [1, 0, 1])
+    lin = oks.prelude("XOR", cts[0], cts[1])
+    u, acc = api.kernel_bootstrap_woks(ks, lin[None, :], want_acc=True)
+    bar = oks.modswitch_ct(lin)
+    want_acc = oks.blind_rotate(bar[:-1], bar[-1])
+    assert (acc[0] == want_acc).all()
+    assert (u[0] == oks.sample_extract(want_acc)).all()
+    assert (api.kernel_keyswitch(ks, u)[0] == oks.keyswitch(u[0])).all()
+    # gates through the public API
+    L = lib.load()
+    L.tfhe_hip_set_encrypt_seed(9)
+    a = api.CiphertextArray(pp, 4).encrypt([0, 0, 1, 1], ks)
+    b = api.CiphertextArray(pp, 4).encrypt([0, 1, 0, 1], ks)
+    res = api.CiphertextArray(pp, 4)
+    api.gate_batch("NAND", res, a, b, ks)
+    wa, wb, got = a.words(), b.words(), res.words()
+    assert (got[1] == oks.gate("NAND", wa[1], wb[1])).all()
+    assert list(res.decrypt(ks)) == [1, 1, 1, 0]
+    m = api.CiphertextArray(pp, 1)
+    L.bootsMUX(m.at(0), a.at(2), b.at(1), b.at(0), ks.cloud)
+    assert (m.words()[0] == oks.mux(wa[2], wb[1], wb[0])).all() and m.decrypt(ks)[0] == 1
