@@ -67,6 +67,20 @@ void peba1_partial_distance(LweSample *partial, LweSample *const *a, LweSample *
 void peba1_combine_and_compare(LweSample *result_b, LweSample *const *partials, int nparts, LweSample *bound_match,
                                const TFheGateBootstrappingCloudKeySet *ck);
 
+/* ---- Hamming distance + threshold (not in the reference; BASELINE.json's wording of the
+ * workload).  Built from the reference's own blocks: XOR per bit, a pairwise
+ * tree of its ripple adders (Math.cpp:54-67) as population count, its comparator
+ * (Math.cpp:265-286).  Results are pinned by plaintext arithmetic and per-gate parity. ---- */
+/* number of samples of a population count of nbits bits: floor(log2 nbits) + 1 */
+int peba1_hamming_count_bits(int nbits);
+/* count (peba1_hamming_count_bits(nbits) samples) = popcount(a XOR b); a, b: nbits samples */
+void peba1_hamming_distance(LweSample *count, LweSample *a, LweSample *b, int nbits,
+                            const TFheGateBootstrappingCloudKeySet *ck);
+/* result_b[0] = (hamming(a,b) > bound), same polarity as Function_f; result_b and bound have
+ * peba1_hamming_count_bits(nbits) samples */
+void peba1_hamming_match(LweSample *result_b, LweSample *a, LweSample *b, int nbits, LweSample *bound_match,
+                         const TFheGateBootstrappingCloudKeySet *ck);
+
 #ifdef __cplusplus
 }
 #endif

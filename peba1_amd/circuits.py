@@ -35,11 +35,15 @@ def load():
             "peba1_function_g": [LS, LS, LS, LS, C.c_int, CK],
             "peba1_partial_distance": [LS, LSP, LSP, C.c_int, C.c_int, CK],
             "peba1_combine_and_compare": [LS, LSP, C.c_int, LS, CK],
+            "peba1_hamming_distance": [LS, LS, LS, C.c_int, CK],
+            "peba1_hamming_match": [LS, LS, LS, C.c_int, LS, CK],
         }
         for name, args in sig.items():
             f = getattr(Lc, name)
             f.restype = None
             f.argtypes = args
+        Lc.peba1_hamming_count_bits.restype = C.c_int
+        Lc.peba1_hamming_count_bits.argtypes = [C.c_int]
         _circ = Lc
     return _circ
 
@@ -97,3 +101,16 @@ def partial_distance(partial, sample_slots, template_slots, bitsize, key):
 
 def combine_and_compare(result_b, partials, bound, key):
     load().peba1_combine_and_compare(result_b.ptr, _ptr_array(partials), len(partials), bound.ptr, key.cloud)
+
+
+def hamming_match(result_b, a, b, nbits, bound, key):
+    """result_b[0] = (popcount(a XOR b) > bound); a, b: CiphertextArray of nbits samples."""
+    load().peba1_hamming_match(result_b.ptr, a.ptr, b.ptr, nbits, bound.ptr, key.cloud)
+
+
+def hamming_distance(count, a, b, nbits, key):
+    load().peba1_hamming_distance(count.ptr, a.ptr, b.ptr, nbits, key.cloud)
+
+
+def hamming_count_bits(nbits):
+    return load().peba1_hamming_count_bits(nbits)

@@ -231,4 +231,52 @@ void peba1_combine_and_compare(LweSample *result_b, LweSample *const *partials, 
     for (Tmp *t : owned) delete t;
 }
 
+// ---- Hamming distance + threshold (not in the reference) ----------
+int peba1_hamming_count_bits(int nbits) {
+    int w = 1;
+    while ((1 << w) <= nbits) ++w;
+    return w;
+}
+
+void peba1_hamming_distance(LweSample *count, LweSample *a, LweSample *b, int nbits, CK *ck) {
+    struct Term { Tmp *bits; int width; };
+    std::vector<Term> cur;
+    cur.reserve((size_t)nbits);
+    for (int i = 0; i < nbits; ++i) {                       // 1-bit terms: a_i XOR b_i
+        Tmp *t = new Tmp(1, ck);
+        bootsXOR(*t, a + i, b + i, ck);
+        cur.push_back(Term{t, 1});
+    }
+    Tmp carry(1, ck);
+    while (cur.size() > 1) {                                // pairwise sums, widths grow by one per level
+        std::vector<Term> next;
+        for (size_t i = 0; i + 1 < cur.size(); i += 2) {
+            Term &x = cur[i], &y = cur[i + 1];              // x.width >= y.width by construction
+            const int w = x.width;
+            Tmp padded(w, ck);
+            copy_bits(padded, *y.bits, y.width, ck);
+            set_zero(padded, y.width, w, ck);
+            Tmp *sum = new Tmp(w + 1, ck);
+            peba1_add_nbit(*sum, *x.bits, padded, carry, w, ck);
+            bootsCOPY(*sum + w, carry, ck);
+            delete x.bits;
+            delete y.bits;
+            next.push_back(Term{sum, w + 1});
+        }
+        if (cur.size() & 1) next.push_back(cur.back());
+        cur.swap(next);
+    }
+    const int w = peba1_hamming_count_bits(nbits);          // drop structurally-zero top bits
+    copy_bits(count, *cur[0].bits, cur[0].width < w ? cur[0].width : w, ck);
+    set_zero(count, cur[0].width < w ? cur[0].width : w, w, ck);
+    delete cur[0].bits;
+}
+
+void peba1_hamming_match(LweSample *result_b, LweSample *a, LweSample *b, int nbits, LweSample *bound_match, CK *ck) {
+    const int w = peba1_hamming_count_bits(nbits);
+    Tmp count(w, ck), smaller(w, ck);
+    peba1_hamming_distance(count, a, b, nbits, ck);
+    peba1_minimum(smaller, result_b, count, bound_match, w, ck);
+}
+
 }  // extern "C"
