@@ -211,6 +211,26 @@ def main():
             assert all(int(o.decrypt(ks)[0]) == bit for o in outs)
             out["batched_matches"] = {"matches": B, "gates_per_s": sb["blind_rotates"] / tb, "seconds": tb,
                                       "levels": int(sb["levels"])}
+        if world == 1 and args.batched_extra > 0:
+            # extra: BASELINE.json's literal wording, a 128-BIT template under Hamming distance +
+            # threshold (peba1_hamming_match; not in the reference)
+            import random
+            rnd = random.Random(7)
+            ta, tb = rnd.getrandbits(128), rnd.getrandbits(128)
+            w = circuits.hamming_count_bits(128)
+            A = circuits.encrypt_number(pp, ta, 128, ks); A.set_words(A.words())
+            Bv = circuits.encrypt_number(pp, tb, 128, ks); Bv.set_words(Bv.words())
+            hb = circuits.encrypt_number(pp, 40, w, ks)
+            api.reset_stats()
+            th = time.perf_counter()
+            rbh = api.CiphertextArray(pp, w)
+            circuits.hamming_match(rbh, A, Bv, 128, hb, ks)
+            api.flush()
+            th = time.perf_counter() - th
+            sh = api.stats()
+            assert int(rbh.decrypt(ks)[0]) == (1 if bin(ta ^ tb).count("1") > 40 else 0)
+            out["hamming128_match"] = {"match_ms": th * 1e3, "blind_rotates": int(sh["blind_rotates"]),
+                                       "levels": int(sh["levels"]), "gates_per_s": sh["blind_rotates"] / th}
         if world == 1 and not args.no_cpu_baseline:
             api.set_deferred(False)
             out["cpu_baseline"] = cpu_baseline(seed)

@@ -40,6 +40,9 @@ def sharded_match(dist, torch, gate_lib, circ_lib, params_ptr, cloud_ptr, words,
     (LweSample* each, `bitsize` samples).  Returns the 24-sample result array pointer on
     rank 0 (caller frees it with delete_gate_bootstrapping_ciphertext_array(24, p)), None elsewhere."""
     rank, world = dist.get_rank(), dist.get_world_size()
+    # private handles: the prototypes set below must not disturb the callers' own bindings
+    gate_lib = C.CDLL(gate_lib._name)
+    circ_lib = C.CDLL(circ_lib._name)
     new_arr = gate_lib.new_gate_bootstrapping_ciphertext_array
     new_arr.restype = C.c_void_p
     new_arr.argtypes = [C.c_int32, C.c_void_p]

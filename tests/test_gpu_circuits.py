@@ -1,0 +1,108 @@
+"""GPU runs of whole circuits through libpeba1-circuits + libtfhe-hip in deferred mode:
+decrypted results against plaintext arithmetic, and ciphertext words against the CPU oracle
+evaluating the same gate sequence where that is cheap."""
+import ctypes as C
+import os
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def test_full_adder_ciphertexts_match_oracle(p128_keys, oracle):
+    """bootsADD1bit (Math.cpp:27-50): 7 bootstraps, every output word equal to the oracle's."""
+    from peba1_amd import api, circuits, lib
+    pp, ks, oks = p128_keys
+    L = lib.load()
+    L.tfhe_hip_set_encrypt_seed(41)
+    x = api.CiphertextArray(pp, 3).encrypt([1, 1, 1], ks)       # a, b, carry-in
+    w = x.words()
+    out = api.CiphertextArray(pp, 1)
+    api.set_deferred(True)
+    try:
+        circuits.load().peba1_add_1bit(out.ptr, x.at(0), x.at(1), x.at(2), ks.cloud)
+        api.flush()
+    finally:
+        api.set_deferred(False)
+    t = oks.gate("XOR", w[0], w[1])
+    s = oks.gate("XOR", t, w[2])
+    ab = oks.gate("AND", w[0], w[1])
+    ac = oks.gate("AND", w[0], w[2])
+    c1 = oks.gate("XOR", ab, ac)
+    cb = oks.gate("AND", w[2], w[1])
+    c2 = oks.gate("XOR", c1, cb)
+    assert (out.words()[0] == s).all()
+    assert (x.words()[2] == c2).all()                            # carry updated in place
+    assert out.decrypt(ks)[0] == 1 and x.decrypt(ks)[2] == 1
+
+
+def test_small_euclidean_match_and_hamming_match(p128_keys):
+    """Function_f on 3 slots and a 16-bit Hamming match: decrypted bits equal the plaintext rule
+    (distance > bound), SURVEY D2 polarity."""
+    from peba1_amd import api, circuits, lib
+    pp, ks, _ = p128_keys
+    L = lib.load()
+    L.tfhe_hip_set_encrypt_seed(43)
+    tmpl_v, probe_v = [12, 200, 77], [15, 190, 78]
+    d = sum((a - b) ** 2 for a, b in zip(probe_v, tmpl_v))        # 9 + 100 + 1
+    T = circuits.EncryptedVector(pp, tmpl_v, 8, ks)
+    S = circuits.EncryptedVector(pp, probe_v, 8, ks)
+    api.set_deferred(True)
+    try:
+        outs = []
+        for bound in (d - 1, d, 4000):
+            rb = api.CiphertextArray(pp, 24)
+            circuits.function_f(rb, S, T, circuits.encrypt_number(pp, bound, 24, ks), 8, ks)
+            outs.append((bound, rb))
+        a_bits, b_bits = 0xBEEF, 0x1234
+        hd = bin(a_bits ^ b_bits).count("1")
+        w = circuits.hamming_count_bits(16)
+        A = circuits.encrypt_number(pp, a_bits, 16, ks)
+        B = circuits.encrypt_number(pp, b_bits, 16, ks)
+        cnt = api.CiphertextArray(pp, w)
+        circuits.hamming_distance(cnt, A, B, 16, ks)
+        hm = []
+        for bound in (hd - 1, hd):
+            rb = api.CiphertextArray(pp, w)
+            circuits.hamming_match(rb, A, B, 16, circuits.encrypt_number(pp, bound, w, ks), ks)
+            hm.append((bound, rb))
+        api.flush()
+    finally:
+        api.set_deferred(False)
+    for bound, rb in outs:
+        assert rb.decrypt(ks)[0] == (1 if d > bound else 0), bound
+    assert circuits.decrypt_number(cnt, ks) == hd
+    for bound, rb in hm:
+        assert rb.decrypt(ks)[0] == (1 if hd > bound else 0), bound
+
+
+def test_sharded_match_over_rccl_world1(p128_keys):
+    """peba1_amd/dist.py on the GPU with the nccl (RCCL) backend at world size 1: exercises the
+    device-pointer export/import of ciphertexts and the gather; 2 slots."""
+    import torch
+    import torch.distributed as dist
+    from peba1_amd import api, circuits, lib
+    from peba1_amd import dist as pd
+    pp, ks, _ = p128_keys
+    L = lib.load()
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("MASTER_PORT", "29611")
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+    try:
+        L.tfhe_hip_set_encrypt_seed(47)
+        tmpl_v, probe_v = [100, 3], [90, 7]
+        d = sum((a - b) ** 2 for a, b in zip(probe_v, tmpl_v))
+        T = circuits.EncryptedVector(pp, tmpl_v, 8, ks)
+        S = circuits.EncryptedVector(pp, probe_v, 8, ks)
+        bound = circuits.encrypt_number(pp, d - 1, 24, ks)
+        api.set_deferred(True)
+        res = pd.sharded_match(dist, torch, L, circuits.load(), pp.ptr, ks.cloud, pp.words,
+                               [a.ptr for a in S.slots], [a.ptr for a in T.slots], bound.ptr, 8, device="cuda")
+        api.set_deferred(False)
+        res_ls = C.cast(res, lib.LS)
+        assert L.bootsSymDecrypt(res_ls, ks.ptr) == 1               # d > d-1
+        L.delete_gate_bootstrapping_ciphertext_array(24, res_ls)
+    finally:
+        api.set_deferred(False)
+        dist.destroy_process_group()
