@@ -47,10 +47,22 @@ struct alignas(16) ArrayHeader {
     void *reserved;
 };
 
-ArrayHeader *header_of(LweSample *samples) {
-    auto *h = reinterpret_cast<ArrayHeader *>(reinterpret_cast<char *>(samples) - sizeof(ArrayHeader));
-    if (h->magic != ARRAY_MAGIC) fatal("LweSample array was not allocated by new_gate_bootstrapping_ciphertext_array");
+// Every sample's host mirror is preceded by a back-pointer to its array's header, so the
+// pool a sample lives in can be found from any element pointer (&array[i]).
+constexpr int MIRROR_PREFIX_WORDS = 2;   // one pointer
+
+ArrayHeader *header_of(const LweSample *sample) {
+    ArrayHeader *h;
+    std::memcpy(&h, sample->a - MIRROR_PREFIX_WORDS, sizeof h);
+    if (!h || h->magic != ARRAY_MAGIC) fatal("LweSample was not allocated by new_gate_bootstrapping_ciphertext_array");
     return h;
+}
+
+// bind the sample's array to `pool` on first device use; one array never spans two pools
+void bind_pool(const LweSample *sample, SlotPool *pool) {
+    ArrayHeader *h = header_of(sample);
+    if (!h->pool) h->pool = pool;
+    else if (h->pool != pool) fatal("ciphertext used with a key of different LWE dimension than the one it was first used with");
 }
 
 // prelude constants of the two-input gates: (c0 in eighths, sa, sb), tfhe boot-gates.cpp
@@ -93,6 +105,7 @@ int flush_locked();
 // make sure `s` has a device slot holding its current value; returns the slot
 int32_t ensure_slot(const LweSample *cs, SlotPool *pool) {
     auto *s = const_cast<LweSample *>(cs);
+    bind_pool(cs, pool);
     if (s->slot >= 0) return s->slot;
     if (s->slot == SLOT_ZERO) {
         pool->retain(pool->const_slot[0]);
@@ -105,9 +118,16 @@ int32_t ensure_slot(const LweSample *cs, SlotPool *pool) {
     return slot;
 }
 
-void drop_slot(LweSample *s, SlotPool *pool) {
-    if (s->slot >= 0 && pool) pool->release(s->slot);
+void drop_slot(LweSample *s) {
+    if (s->slot >= 0) header_of(s)->pool->release(s->slot);
     s->slot = SLOT_HOST;
+}
+
+// re-point a handle to `slot` (already retained for it), releasing what it held
+void repoint(LweSample *s, SlotPool *pool, int32_t slot) {
+    bind_pool(s, pool);
+    if (s->slot >= 0) pool->release(s->slot);
+    s->slot = slot;
 }
 
 void begin_op(const TFheGateBootstrappingCloudKeySet *bk) {
@@ -115,18 +135,19 @@ void begin_op(const TFheGateBootstrappingCloudKeySet *bk) {
     if (r.key && r.key != bk && !r.ops.empty()) flush_locked();
     r.key = bk;
     r.pool = pool_of_key(bk);
+    // pending operations pin their slots until they run: flush before the pool runs dry, so
+    // arbitrarily long recordings need only bounded device memory
+    if (!r.ops.empty() && r.pool->capacity() - r.pool->in_use() < 4096) flush_locked();
 }
 
 void sync_sample_locked(const LweSample *cs) {
     Recorder &r = rec();
     auto *s = const_cast<LweSample *>(cs);
-    if (s->slot < 0) {
-        if (s->slot == SLOT_ZERO) { /* host mirror already zero */ }
-        return;
-    }
-    if (!r.pool) fatal("device-resident sample without a pool");
-    if (r.pool->level[s->slot] > 0) flush_locked();
-    Engine::get().read_slot(r.pool, s->slot, s->a, &s->b);
+    if (s->slot < 0) return;                       // host mirror is authoritative (fresh: trivial 0)
+    SlotPool *pool = header_of(s)->pool;
+    if (pool->level[s->slot] > 0) flush_locked();
+    (void)r;
+    Engine::get().read_slot(pool, s->slot, s->a, &s->b);
 }
 
 void finish_op(LweSample *result) {
@@ -150,8 +171,7 @@ void record_gate2(int code, LweSample *result, const LweSample *ca, const LweSam
     pool->retain(sa); pool->retain(sb); pool->retain(dst);   // pending references
     r.ops.push_back(PendingOp{(uint8_t)code, dst, sa, sb, -1, level});
     r.max_level = std::max(r.max_level, level);
-    if (result->slot >= 0) pool->release(result->slot);
-    result->slot = dst;
+    repoint(result, pool, dst);
     finish_op(result);
 }
 
@@ -301,15 +321,17 @@ void delete_gate_bootstrapping_cloud_keyset(TFheGateBootstrappingCloudKeySet *) 
 LweSample *new_gate_bootstrapping_ciphertext_array(int32_t nbelems, const TFheGateBootstrappingParameterSet *params) {
     if (nbelems < 0 || !params) { set_error("bad arguments to new_gate_bootstrapping_ciphertext_array"); return nullptr; }
     const int32_t n = params->in_out_params->n;
-    const size_t bytes = sizeof(ArrayHeader) + (size_t)nbelems * sizeof(LweSample) + (size_t)nbelems * n * sizeof(Torus32);
-    char *mem = static_cast<char *>(std::calloc(1, bytes ? bytes : 1));
+    const size_t mirror = (size_t)(n + MIRROR_PREFIX_WORDS + 1) & ~(size_t)1;   // words per sample, pointer-aligned
+    const size_t bytes = sizeof(ArrayHeader) + (size_t)nbelems * sizeof(LweSample) + (size_t)nbelems * mirror * sizeof(Torus32);
+    char *mem = static_cast<char *>(std::calloc(1, bytes));
     if (!mem) fatal("out of host memory");
     auto *h = reinterpret_cast<ArrayHeader *>(mem);
     h->magic = ARRAY_MAGIC; h->count = nbelems; h->n = n; h->pool = nullptr;
     auto *samples = reinterpret_cast<LweSample *>(mem + sizeof(ArrayHeader));
     auto *words = reinterpret_cast<Torus32 *>(mem + sizeof(ArrayHeader) + (size_t)nbelems * sizeof(LweSample));
     for (int32_t i = 0; i < nbelems; ++i) {
-        samples[i].a = words + (size_t)i * n;
+        samples[i].a = words + (size_t)i * mirror + MIRROR_PREFIX_WORDS;
+        std::memcpy(samples[i].a - MIRROR_PREFIX_WORDS, &h, sizeof h);
         samples[i].b = -(1 << 29);      // fresh = trivial encryption of 0, like bootsCONSTANT(.., 0)
         samples[i].slot = SLOT_ZERO;
         samples[i].current_variance = 0.0;
@@ -319,12 +341,13 @@ LweSample *new_gate_bootstrapping_ciphertext_array(int32_t nbelems, const TFheGa
 
 void delete_gate_bootstrapping_ciphertext_array(int32_t nbelems, LweSample *samples) {
     if (!samples) return;
-    ArrayHeader *h = header_of(samples);
+    auto *h = reinterpret_cast<ArrayHeader *>(reinterpret_cast<char *>(samples) - sizeof(ArrayHeader));
+    if (h->magic != ARRAY_MAGIC) fatal("delete_gate_bootstrapping_ciphertext_array: not an array base pointer");
     if (h->count != nbelems) set_error("delete_gate_bootstrapping_ciphertext_array: count differs from allocation");
     Recorder &r = rec();
     std::lock_guard<std::recursive_mutex> g(r.mtx);
     for (int32_t i = 0; i < h->count; ++i)
-        if (samples[i].slot >= 0 && r.pool) r.pool->release(samples[i].slot);
+        if (samples[i].slot >= 0) h->pool->release(samples[i].slot);
     h->magic = 0;
     std::free(h);
 }
@@ -337,7 +360,7 @@ void delete_gate_bootstrapping_ciphertext(LweSample *sample) { delete_gate_boots
 void bootsSymEncrypt(LweSample *result, int32_t message, const TFheGateBootstrappingSecretKeySet *key) {
     Recorder &r = rec();
     std::lock_guard<std::recursive_mutex> g(r.mtx);
-    drop_slot(result, r.pool);
+    drop_slot(result);
     encrypt_bit(*key->lwe_key, r.enc_rng, message, result->a, &result->b);
 }
 
@@ -354,8 +377,7 @@ void bootsCONSTANT(LweSample *result, int32_t value, const TFheGateBootstrapping
     begin_op(bk);
     const int32_t s = r.pool->const_slot[value ? 1 : 0];
     r.pool->retain(s);
-    if (result->slot >= 0) r.pool->release(result->slot);
-    result->slot = s;
+    repoint(result, r.pool, s);
     if (!r.deferred) {   // keep the host mirror exact without a device round trip
         std::memset(result->a, 0, (size_t)bk->params->in_out_params->n * sizeof(Torus32));
         result->b = value ? (1 << 29) : -(1 << 29);
@@ -369,8 +391,7 @@ void bootsCOPY(LweSample *result, const LweSample *ca, const TFheGateBootstrappi
     if (result == ca) return;
     const int32_t s = ensure_slot(ca, r.pool);
     r.pool->retain(s);
-    if (result->slot >= 0) r.pool->release(result->slot);
-    result->slot = s;
+    repoint(result, r.pool, s);
     if (!r.deferred) sync_sample_locked(result);
 }
 
@@ -385,8 +406,7 @@ void bootsNOT(LweSample *result, const LweSample *ca, const TFheGateBootstrappin
         auto it = r.not_origin.find(sa);
         if (it != r.not_origin.end()) {
             pool->retain(it->second);
-            if (result->slot >= 0) pool->release(result->slot);
-            result->slot = it->second;
+            repoint(result, pool, it->second);
             finish_op(result);
             return;
         }
@@ -398,8 +418,7 @@ void bootsNOT(LweSample *result, const LweSample *ca, const TFheGateBootstrappin
     r.ops.push_back(PendingOp{OP_NOT, dst, sa, -1, -1, level});
     r.not_origin.emplace(dst, sa);
     r.max_level = std::max(r.max_level, level);
-    if (result->slot >= 0) pool->release(result->slot);
-    result->slot = dst;
+    repoint(result, pool, dst);
     finish_op(result);
 }
 
@@ -427,8 +446,7 @@ void bootsMUX(LweSample *result, const LweSample *a, const LweSample *b, const L
     pool->retain(sa); pool->retain(sb); pool->retain(sc); pool->retain(dst);
     r.ops.push_back(PendingOp{OP_MUX, dst, sa, sb, sc, level});
     r.max_level = std::max(r.max_level, level);
-    if (result->slot >= 0) pool->release(result->slot);
-    result->slot = dst;
+    repoint(result, pool, dst);
     finish_op(result);
 }
 
@@ -523,8 +541,8 @@ static int import_impl(LweSample *samples, int32_t count, int32_t n, const Torus
     }
     std::vector<int32_t> slots(count);
     for (int32_t i = 0; i < count; ++i) {
-        if (samples[i].slot >= 0) r.pool->release(samples[i].slot);
-        slots[i] = samples[i].slot = r.pool->alloc();
+        repoint(&samples[i], r.pool, r.pool->alloc());
+        slots[i] = samples[i].slot;
         if (!device_src) {
             std::memcpy(samples[i].a, in + (size_t)i * (n + 1), (size_t)n * 4);
             samples[i].b = in[(size_t)i * (n + 1) + n];
