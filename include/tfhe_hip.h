@@ -87,7 +87,7 @@ int tfhe_hip_gate_batch(int gate, LweSample *result, const LweSample *a, const L
  * 4-wave kernel (one wave per prime and input polynomial) instead of the 2-wave
  * kernel (one wave per prime); default 2^30 = always, env TFHE_HIP_BR4_MAX; 0 = never.
  * "ks_target_blocks": a launch's key switches are each cut into 2^s <= 32 ranges of
- * input coefficients until about this many workgroups exist (default 2048, env
+ * input coefficients until about this many workgroups exist (default 32768, env
  * TFHE_HIP_KS_BLOCKS); 0 disables splitting.
  * "balance_levels": 1 (default) = slack-aware level filling at flush, 0 = plain ASAP
  * levels.  Returns 0, or -1 for an unknown name. */

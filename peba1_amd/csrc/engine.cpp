@@ -76,6 +76,7 @@ void Engine::ensure_init() {
     if (const char *env = std::getenv("TFHE_HIP_DEVICE")) device_ = std::atoi(env);
     if (const char *env = std::getenv("TFHE_HIP_BR4_MAX")) br4_max_rotations = std::atoi(env);
     if (const char *env = std::getenv("TFHE_HIP_KS_BLOCKS")) ks_target_blocks = std::atoi(env);
+    if (const char *env = std::getenv("TFHE_HIP_KS_MAX_SPLITS")) ks_max_splits = std::atoi(env);
     hip_check(hipSetDevice(device_), "hipSetDevice");
     {
         hipDeviceProp_t prop;
@@ -270,7 +271,7 @@ void Engine::launch_br(const DeviceKeyImage *key, const int32_t *pool, const Rot
 void Engine::launch_ks(const DeviceKeyImage *key, const int32_t *u_buf, const KsDesc *descs, int count, int32_t *pool) {
     if (count <= 0) return;
     int splits = 1;
-    while (splits < 32 && count * splits * 2 <= ks_target_blocks) splits *= 2;
+    while (splits < ks_max_splits && count * splits * 2 <= ks_target_blocks) splits *= 2;
     int32_t *partial = nullptr;
     if (splits > 1) partial = static_cast<int32_t *>(scratch(10, (size_t)count * splits * key->dp.ct_stride * 4));
     launch_keyswitch(stream_, key->dp, key->key, u_buf, descs, count, pool, splits, partial);

@@ -92,8 +92,11 @@ public:
     // (tools/width_sweep.py) it matches or beats the 2-wave form at every width, so the
     // default is "always"; the 2-wave form stays selectable and tested
     int br4_max_rotations = 1 << 30;
-    // key switches of a launch are split so that about this many workgroups exist (power of two <= 32)
-    int ks_target_blocks = 2048;
+    // key switches of a launch are split (power of two <= ks_max_splits) until about this many
+    // workgroups exist: beyond filling the chip, more splits mean the blocks in flight share a
+    // KSK sub-table small enough for an XCD's L2 (measured optimum: 32 splits)
+    int ks_target_blocks = 32768;
+    int ks_max_splits = 32;
     void launch_ks(const DeviceKeyImage *key, const int32_t *u_buf, const KsDesc *descs, int count, int32_t *pool);
     void launch_br(const DeviceKeyImage *key, const int32_t *pool, const RotDesc *rots, int count, int32_t *u_buf,
                    int32_t *acc_dbg);
