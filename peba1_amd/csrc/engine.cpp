@@ -203,10 +203,8 @@ SlotPool *Engine::pool_for(const Params &p) {
     size_t cap = 1u << 21;   // 2,097,152 slots = 5.3 GB at n = 630 (HBM is 288 GB): ~9 matches in flight
     if (const char *env = std::getenv("TFHE_HIP_POOL_SLOTS")) cap = (size_t)std::atoll(env);
     auto *pl = new SlotPool(p.ct_words(), p.ct_stride(), cap);
-    // shared read-only slots: trivial 0 (fresh samples), constants -1/8 and +1/8
+    // shared read-only slots: the trivial samples (0, -1/8) -- also what a fresh sample is -- and (0, +1/8)
     std::vector<Torus32> z(p.n, 0);
-    pl->zero_slot = pl->alloc();
-    write_slot(pl, pl->zero_slot, z.data(), 0);
     pl->const_slot[0] = pl->alloc();
     write_slot(pl, pl->const_slot[0], z.data(), -(1 << 29));
     pl->const_slot[1] = pl->alloc();

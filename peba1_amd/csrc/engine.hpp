@@ -43,7 +43,7 @@ public:
     size_t capacity() const { return cap_; }
     size_t in_use() const { return cap_ - free_.size(); }
     std::vector<int32_t> level;      // pending level of each slot's value, 0 = materialised
-    int32_t zero_slot = -1, const_slot[2] = {-1, -1};
+    int32_t const_slot[2] = {-1, -1};   // shared read-only trivial samples (0, -1/8) and (0, +1/8)
 private:
     int words_, stride_;
     size_t cap_;
@@ -108,7 +108,7 @@ private:
     int cu_count_ = 256;
     bool inited_ = false;
     hipStream_t stream_ = nullptr;
-    hipEvent_t ev_[4] = {nullptr, nullptr, nullptr, nullptr};
+    hipEvent_t ev_[3] = {nullptr, nullptr, nullptr};
     std::vector<SlotPool *> pools_;
     std::vector<void *> scratch_ptr_;
     std::vector<size_t> scratch_size_;

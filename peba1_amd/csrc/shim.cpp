@@ -42,9 +42,8 @@ struct alignas(16) ArrayHeader {
     uint32_t magic;
     int32_t count;
     int32_t n;
-    int32_t pad;
+    int32_t unused;
     SlotPool *pool;     // set when the first element moves to the device
-    void *reserved;
 };
 
 // Every sample's host mirror is preceded by a back-pointer to its array's header, so the

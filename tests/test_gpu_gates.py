@@ -1,6 +1,7 @@
 """GPU parity of the boots* gates (a4-a9) against the CPU oracle: decrypted truth tables
 AND ciphertext words, through the upstream-compatible C ABI."""
 import ctypes as C
+import os
 
 import numpy as np
 import pytest
@@ -183,3 +184,32 @@ def test_balanced_and_asap_schedules_give_identical_ciphertexts(p128_keys, oracl
         assert circuits.decrypt_number(prod, ks, 23) == 13 * 11
     api.set_tuning("balance_levels", 1)
     assert (results[0] == results[1]).all()
+
+
+def test_recording_survives_a_tiny_slot_pool():
+    """With a pool far smaller than the circuit, the recorder flushes before the pool runs dry;
+    the result is the same number.  Runs in a subprocess (the pool size is fixed at first use)."""
+    import subprocess
+    import sys
+    code = r'''
+import sys
+sys.path.insert(0, %r)
+from peba1_amd import api, circuits, lib
+L = lib.load()
+pp = api.ParameterSet(128)
+ks = api.SecretKeySet(pp, 0x5EBA2)
+L.tfhe_hip_set_encrypt_seed(3)
+a = circuits.encrypt_number(pp, 201, 9, ks)
+b = circuits.encrypt_number(pp, 77, 9, ks)
+prod = api.CiphertextArray(pp, 24)
+api.set_deferred(True)
+circuits.load().peba1_multiply(prod.ptr, a.ptr, b.ptr, 8, ks.cloud)     # 1,296 gates, ~2,000 slots
+api.flush()
+api.set_deferred(False)
+assert api.stats()["flushes"] >= 2, api.stats()
+assert circuits.decrypt_number(prod, ks, 23) == 201 * 77
+print("OK", api.stats()["flushes"])
+''' % os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, TFHE_HIP_POOL_SLOTS="5000")
+    out = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0 and "OK" in out.stdout, out.stdout + out.stderr
