@@ -90,7 +90,12 @@ int tfhe_hip_gate_batch(int gate, LweSample *result, const LweSample *a, const L
  * input coefficients until about this many workgroups exist (default 32768, env
  * TFHE_HIP_KS_BLOCKS); 0 disables splitting.
  * "balance_levels": 1 (default) = slack-aware level filling at flush, 0 = plain ASAP
- * levels.  Returns 0, or -1 for an unknown name. */
+ * levels.
+ * "dataflow": 0 (default) = one blind-rotate + one key-switch launch per level; 1 (env
+ * TFHE_HIP_DATAFLOW) = experimental: a flush runs as ONE launch in which workgroups take
+ * gates in priority order, wait on done flags of their producers and do the key switch
+ * inside the workgroup (measured slower than the default on MI355X).
+ * Returns 0, or -1 for an unknown name. */
 int tfhe_hip_set_tuning(const char *name, int64_t value);
 
 /* ---- statistics ---- */

@@ -2,6 +2,8 @@
 #include "engine.hpp"
 
 #include <chrono>
+#include <ctime>
+#include <unistd.h>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -173,7 +175,7 @@ DeviceKeyImage *Engine::upload_key(const TfheHipCloudKey &ck) {
     // KSK: drop the all-zero digit-0 rows, pad rows to ct_stride
     const int base = 1 << p.ks_basebit, stride = p.ct_stride();
     const size_t rows = (size_t)p.k * p.N * p.ks_t;
-    std::vector<int32_t> compact(rows * (base - 1) * stride, 0);
+    std::vector<int32_t> compact((rows * (base - 1) + 1) * stride, 0);   // + one row of zeros (digit 0)
     for (size_t r = 0; r < rows; ++r)
         for (int v = 1; v < base; ++v)
             std::memcpy(&compact[(r * (base - 1) + (v - 1)) * stride], &ck.ksk[(r * base + v) * (size_t)(p.n + 1)],
@@ -183,6 +185,7 @@ DeviceKeyImage *Engine::upload_key(const TfheHipCloudKey &ck) {
 
     img->key.bk_img = img->bk_img;
     img->key.ksk = img->ksk;
+    img->key.ksk_zero = img->ksk + rows * (base - 1) * stride;
     img->key.tw = img->tw;
     return img;
 }
@@ -318,6 +321,59 @@ void Engine::execute(const DeviceKeyImage *key, SlotPool *pool, const LevelPlan 
     hip_check(hipGetLastError(), "kernel launch");
     hip_check(hipStreamSynchronize(stream_), "level execution");
     stats.levels += (uint64_t)levels;
+    ++stats.flushes;
+    stats.ms_flush_wall += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+}
+
+void Engine::execute_dataflow(const DeviceKeyImage *key, SlotPool *pool, const std::vector<GateTask> &tasks, int depth) {
+    const auto t0 = std::chrono::steady_clock::now();
+    const int ntasks = (int)tasks.size();
+    if (ntasks == 0) return;
+    GateTask *dtasks = static_cast<GateTask *>(scratch(11, tasks.size() * sizeof(GateTask)));
+    constexpr int CTRL_WORDS = 4 + 64;   // next, error, 2 spare, 64 progress words (debug)
+    int32_t *dflags = static_cast<int32_t *>(scratch(12, ((size_t)ntasks + CTRL_WORDS) * sizeof(int32_t)));   // done[ntasks], ctrl[]
+    hip_check(hipMemcpyAsync(dtasks, tasks.data(), tasks.size() * sizeof(GateTask), hipMemcpyHostToDevice, stream_), "upload tasks");
+    hip_check(hipMemsetAsync(dflags, 0, ((size_t)ntasks + CTRL_WORDS) * sizeof(int32_t), stream_), "clear flags");
+    if (kernel_timing) hip_check(hipEventRecord(ev_[0], stream_), "event");
+    launch_gate_dataflow(stream_, key->dp, key->key, pool->data(), dtasks, ntasks, dflags, dflags + ntasks,
+                         cu_count_ * (key->dp.N == 1024 ? 2 : 1));
+    if (kernel_timing) hip_check(hipEventRecord(ev_[1], stream_), "event");
+    hip_check(hipGetLastError(), "dataflow launch");
+    if (std::getenv("TFHE_HIP_DF_DEBUG")) {
+        // watchdog for development: poll progress words from a second stream, give up after 20 s
+        hipStream_t s2;
+        hip_check(hipStreamCreateWithFlags(&s2, hipStreamNonBlocking), "debug stream");
+        hipEvent_t evd;
+        hip_check(hipEventCreate(&evd), "debug event");
+        hip_check(hipEventRecord(evd, stream_), "debug event record");
+        for (int sec = 0; sec < 20 && hipEventQuery(evd) == hipErrorNotReady; ++sec) {
+            int32_t w[CTRL_WORDS];
+            hip_check(hipMemcpyAsync(w, dflags + ntasks, sizeof w, hipMemcpyDeviceToHost, s2), "debug copy");
+            hip_check(hipStreamSynchronize(s2), "debug sync");
+            std::fprintf(stderr, "[df %2ds] ntasks %d next %d err %d marks:", sec, ntasks, w[0], w[1]);
+            for (int k = 0; k < 8; ++k) std::fprintf(stderr, " %d:%d", w[4 + k] >> 8, w[4 + k] & 255);
+            std::fprintf(stderr, "\n");
+            std::fflush(stderr);
+            struct timespec ts = {1, 0};
+            nanosleep(&ts, nullptr);
+        }
+        if (hipEventQuery(evd) == hipErrorNotReady) { std::fprintf(stderr, "[df] still running after 20 s, exiting\n"); _exit(3); }
+    }
+    int32_t ctrl[2] = {0, 0};
+    hip_check(hipMemcpyAsync(ctrl, dflags + ntasks, sizeof ctrl, hipMemcpyDeviceToHost, stream_), "read ctrl");
+    hip_check(hipStreamSynchronize(stream_), "dataflow execution");
+    if (ctrl[1] != 0) fatal("dataflow executor: a workgroup timed out waiting for a producer (results are invalid)");
+    if (kernel_timing) {
+        float ms = 0;
+        hip_check(hipEventElapsedTime(&ms, ev_[0], ev_[1]), "elapsed");
+        stats.ms_blind_rotate += ms;      // fused kernel: blind rotations + key switches
+    }
+    for (const GateTask &t : tasks) {
+        if (t.kind == TASK_NOT) ++stats.linear_ops;
+        else { stats.blind_rotates += t.kind == TASK_MUX ? 2 : 1; ++stats.keyswitches; }
+    }
+    ++stats.br_launches;
+    stats.levels += (uint64_t)depth;
     ++stats.flushes;
     stats.ms_flush_wall += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
 }

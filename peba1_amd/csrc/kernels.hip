@@ -331,35 +331,40 @@ __device__ unsigned long long g_stamps[4][8];
 // inverse NTT for output polynomial u, and shares the CRT with wave (1-q,u).
 // Three workgroup barriers per step.  N = 1024: 2 workgroups per CU; N = 2048: 1.
 // ---------------------------------------------------------------------------
+// LDS of one 4-wave workgroup
 template <int LOGN>
-__global__ __launch_bounds__(256, LOGN == 10 ? 2 : 1) void blind_rotate4_kernel(
-    DevParams p, DevKey key, const int32_t *__restrict__ pool, const RotDesc *__restrict__ rots,
-    int32_t *__restrict__ u_buf, int32_t *__restrict__ acc_dbg) {
+struct Br4Lds {
+    using NTT = WaveNtt<LOGN>;
+    uint32_t acc[2][NTT::N];                       // the accumulator, resident for all n steps
+    uint32_t scr[4][NTT::SCRATCH_WORDS];           // wave-private NTT transposes
+    uint32_t x1[4][NTT::SCRATCH_WORDS];            // partial sums of the partner's output poly
+    uint32_t x2[4][NTT::N / 2];                    // residues of the half the partner recombines
+    uint16_t bar[1024 + 8];                        // modulus-switched mask and body
+};
+
+// prelude + modulus switch + the n-step blind rotation of one descriptor; the result is left
+// in sh.acc (complete for every thread on return)
+template <int LOGN>
+__device__ __forceinline__ void blind_rotate4_body(const DevParams &p, const DevKey &key,
+                                                   const int32_t *__restrict__ pool, const RotDesc &rd,
+                                                   Br4Lds<LOGN> &sh, int tid) {
     using NTT = WaveNtt<LOGN>;
     constexpr int N = NTT::N, REGS = NTT::REGS, HALF = REGS / 2;
-    __shared__ __align__(16) uint32_t lds_acc[2][N];
-    __shared__ __align__(16) uint32_t lds_scr[4][NTT::SCRATCH_WORDS];
-    __shared__ __align__(16) uint32_t lds_x1[4][NTT::SCRATCH_WORDS];  // partial sums of the partner's output poly
-    __shared__ __align__(16) uint32_t lds_x2[4][N / 2];               // residues of the half the partner recombines
-    __shared__ uint16_t lds_bar[1024 + 8];
-
-    const int tid = threadIdx.x;
     const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int q = wv & 1, u = wv >> 1;
     const int lane = tid & 63;
     const PrimeCtx c = make_ctx(q, key.tw, N);
-    uint32_t *scr = lds_scr[wv];
-    const RotDesc rd = rots[blockIdx.x];
+    uint32_t *scr = sh.scr[wv];
     const int n = p.n;
 
-    prelude_modswitch<LOGN, 256>(p, rd, pool, lds_bar, tid);
+    prelude_modswitch<LOGN, 256>(p, rd, pool, sh.bar, tid);
     __syncthreads();
     if (q == 0) {
-        const int barb = lds_bar[n];
+        const int barb = sh.bar[n];
 #pragma unroll
         for (int r = 0; r < REGS; ++r) {
             const int j = r * 64 + lane;
-            lds_acc[u][j] = u == 0 ? 0u : testvector_coef<LOGN>(j, barb, p.mu);
+            sh.acc[u][j] = u == 0 ? 0u : testvector_coef<LOGN>(j, barb, p.mu);
         }
     }
     __syncthreads();
@@ -368,7 +373,7 @@ __global__ __launch_bounds__(256, LOGN == 10 ? 2 : 1) void blind_rotate4_kernel(
     STAMP_DECL;
 
     for (int i = 0; i < n; ++i) {
-        const int abar = __builtin_amdgcn_readfirstlane((int)lds_bar[i]);
+        const int abar = __builtin_amdgcn_readfirstlane((int)sh.bar[i]);
         if (abar == 0) continue;
         STAMP(0);
 
@@ -376,7 +381,7 @@ __global__ __launch_bounds__(256, LOGN == 10 ? 2 : 1) void blind_rotate4_kernel(
 #pragma unroll
         for (int r = 0; r < REGS; ++r) { acc0[r] = 0; acc1[r] = 0; }
         // acc0 accumulates output poly u (kept), acc1 output poly 1-u (sent to wave (q,1-u))
-        forward_poly<LOGN>(p, key, c, sc, lds_acc[u], scr, lane, q, i, u, abar, u != 0, acc0, acc1);
+        forward_poly<LOGN>(p, key, c, sc, sh.acc[u], scr, lane, q, i, u, abar, u != 0, acc0, acc1);
         STAMP(1);
 
         int32_t t[REGS], send[REGS];
@@ -385,13 +390,13 @@ __global__ __launch_bounds__(256, LOGN == 10 ? 2 : 1) void blind_rotate4_kernel(
             t[r] = mont_redc(acc0[r], c.P, c.pinv);                // l rows: |.| < 1.6P
             send[r] = mont_redc(acc1[r], c.P, c.pinv);
         }
-        NTT::write_row(send, lds_x1[wv], lane);
+        NTT::write_row(send, sh.x1[wv], lane);
         STAMP(2);
         __syncthreads();
         STAMP(3);
         {
             int32_t other[REGS];
-            NTT::read_row(other, lds_x1[wv ^ 2], lane);
+            NTT::read_row(other, sh.x1[wv ^ 2], lane);
 #pragma unroll
             for (int r = 0; r < REGS; ++r) t[r] += other[r];       // |.| < 3.1P
         }
@@ -402,27 +407,230 @@ __global__ __launch_bounds__(256, LOGN == 10 ? 2 : 1) void blind_rotate4_kernel(
         STAMP(4);
 
         // CRT of output poly u is split with wave (1-q,u): wave q recombines registers [q*HALF, (q+1)*HALF)
-        const uint32_t *ox = lds_x2[wv ^ 1];
+        const uint32_t *ox = sh.x2[wv ^ 1];
         if (q == 0) {
 #pragma unroll
-            for (int r = 0; r < HALF; ++r) lds_x2[wv][r * 64 + lane] = y[HALF + r];
+            for (int r = 0; r < HALF; ++r) sh.x2[wv][r * 64 + lane] = y[HALF + r];
             __syncthreads();
 #pragma unroll
-            for (int r = 0; r < HALF; ++r) lds_acc[u][r * 64 + lane] += crt_to_torus(y[r], ox[r * 64 + lane]);
+            for (int r = 0; r < HALF; ++r) sh.acc[u][r * 64 + lane] += crt_to_torus(y[r], ox[r * 64 + lane]);
         } else {
 #pragma unroll
-            for (int r = 0; r < HALF; ++r) lds_x2[wv][r * 64 + lane] = y[r];
+            for (int r = 0; r < HALF; ++r) sh.x2[wv][r * 64 + lane] = y[r];
             __syncthreads();
 #pragma unroll
             for (int r = 0; r < HALF; ++r)
-                lds_acc[u][(HALF + r) * 64 + lane] += crt_to_torus(ox[r * 64 + lane], y[HALF + r]);
+                sh.acc[u][(HALF + r) * 64 + lane] += crt_to_torus(ox[r * 64 + lane], y[HALF + r]);
         }
         STAMP(5);
         __syncthreads();
         STAMP(6);
     }
     STAMP_FLUSH;
-    extract_sample<LOGN, 256>(p, rd, lds_acc, u_buf, acc_dbg, tid);
+}
+
+template <int LOGN>
+__global__ __launch_bounds__(256, LOGN == 10 ? 2 : 1) void blind_rotate4_kernel(
+    DevParams p, DevKey key, const int32_t *__restrict__ pool, const RotDesc *__restrict__ rots,
+    int32_t *__restrict__ u_buf, int32_t *__restrict__ acc_dbg) {
+    __shared__ __align__(16) Br4Lds<LOGN> sh;
+    const RotDesc rd = rots[blockIdx.x];
+    blind_rotate4_body<LOGN>(p, key, pool, rd, sh, threadIdx.x);
+    extract_sample<LOGN, 256>(p, rd, sh.acc, u_buf, acc_dbg, threadIdx.x);
+}
+
+// ---------------------------------------------------------------------------
+// Dataflow executor: ONE launch runs a whole recorded gate DAG.  `tasks` is sorted in a
+// topological priority order (scheduler.cpp); every workgroup repeatedly takes the next
+// index, waits until the producers of its operands have published, runs the gate entirely
+// inside the workgroup (prelude, blind rotation(s), sample extract, key switch with the
+// extracted sample still in LDS) and publishes a done flag.
+//  * No co-residency is assumed: a workgroup only ever waits for tasks with smaller indices,
+//    which were taken by workgroups that are already running, so any number of resident
+//    workgroups makes progress (no grid barrier, no deadlock).
+//  * Hand-off follows the agent-scope release/acquire recipe: every storing wave drains its
+//    stores, workgroup barrier, lane 0 release fence + drain + relaxed agent flag store;
+//    the consumer polls the flag relaxed, ONE acquire fence, drain, barrier, plain loads.
+//  * Every spin is bounded; on timeout the error word is set and all workgroups leave.
+// ---------------------------------------------------------------------------
+template <int LOGN>
+__device__ __forceinline__ void keyswitch_in_wg(const DevParams &p, const DevKey &key, Br4Lds<LOGN> &sh,
+                                                const uint32_t *lds_u, int32_t *__restrict__ dst, int tid) {
+    // 4 waves x a quarter of the input coefficients; a lane owns columns lane + 64 m of the row
+    constexpr int NCOL = LOGN == 10 ? 3 : 5;       // ceil(ct_stride/4 / 64) for n <= 767 / n <= 1279
+    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int lane = tid & 63;
+    const int nin = p.k * (1 << LOGN);
+    const int nvec = p.ct_stride >> 2;
+    const int t = p.ks_t, bb = p.ks_basebit;
+    const uint32_t mask = (1u << bb) - 1u;
+    const uint4 *ksk = reinterpret_cast<const uint4 *>(key.ksk);
+    const uint4 *zero_row = reinterpret_cast<const uint4 *>(key.ksk_zero);
+    uint4 acc[NCOL];
+#pragma unroll
+    for (int m = 0; m < NCOL; ++m) acc[m] = make_uint4(0, 0, 0, 0);
+    const int i0 = nin * wv / 4, i1 = nin * (wv + 1) / 4;
+    // KT digits of one coefficient are handled together: all their row loads are issued
+    // before the first subtraction, so 8 x NCOL 16-byte loads are in flight per lane
+    constexpr int KT = 8;
+    if (t == KT) {
+        for (int i = i0; i < i1; ++i) {
+            const uint32_t aibar = lds_u[i] + p.ks_prec_offset;
+            uint4 v[KT][NCOL];
+#pragma unroll
+            for (int j = 0; j < KT; ++j) {
+                const uint32_t aij = (aibar >> (32 - (j + 1) * bb)) & mask;
+                // digit 0 subtracts nothing: read a row of zeros instead of branching
+                const uint4 *row = aij ? ksk + ((size_t)(i * KT + j) * mask + (aij - 1)) * (size_t)nvec : zero_row;
+#pragma unroll
+                for (int m = 0; m < NCOL; ++m) {
+                    const int col = lane + 64 * m;
+                    v[j][m] = col < nvec ? row[col] : make_uint4(0, 0, 0, 0);
+                }
+            }
+#pragma unroll
+            for (int j = 0; j < KT; ++j)
+#pragma unroll
+                for (int m = 0; m < NCOL; ++m) {
+                    acc[m].x -= v[j][m].x; acc[m].y -= v[j][m].y; acc[m].z -= v[j][m].z; acc[m].w -= v[j][m].w;
+                }
+        }
+    } else {
+        for (int i = i0; i < i1; ++i) {
+            const uint32_t aibar = lds_u[i] + p.ks_prec_offset;
+            for (int j = 0; j < t; ++j) {
+                const uint32_t aij = (aibar >> (32 - (j + 1) * bb)) & mask;
+                if (aij == 0) continue;
+                const uint4 *row = ksk + ((size_t)(i * t + j) * mask + (aij - 1)) * (size_t)nvec;
+#pragma unroll
+                for (int m = 0; m < NCOL; ++m) {
+                    const int col = lane + 64 * m;
+                    if (col < nvec) {
+                        const uint4 r = row[col];
+                        acc[m].x -= r.x; acc[m].y -= r.y; acc[m].z -= r.z; acc[m].w -= r.w;
+                    }
+                }
+            }
+        }
+    }
+    uint4 *part = reinterpret_cast<uint4 *>(sh.scr[wv]);       // >= ct_stride words per wave
+#pragma unroll
+    for (int m = 0; m < NCOL; ++m)
+        if (lane + 64 * m < nvec) part[lane + 64 * m] = acc[m];
+    __syncthreads();
+    for (int col = tid; col < nvec; col += 256) {
+        uint4 s = reinterpret_cast<const uint4 *>(sh.scr[0])[col];
+#pragma unroll
+        for (int w = 1; w < 4; ++w) {
+            const uint4 v = reinterpret_cast<const uint4 *>(sh.scr[w])[col];
+            s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
+        }
+        uint32_t o[4] = {s.x, s.y, s.z, s.w};
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const int wi = 4 * col + e;
+            if (wi == p.n) o[e] += lds_u[nin];
+            if (wi > p.n) o[e] = 0;
+        }
+        reinterpret_cast<uint4 *>(dst)[col] = make_uint4(o[0], o[1], o[2], o[3]);
+    }
+}
+
+template <int LOGN>
+__global__ __launch_bounds__(256, LOGN == 10 ? 2 : 1) void gate_dataflow_kernel(
+    DevParams p, DevKey key, int32_t *__restrict__ pool, const GateTask *__restrict__ tasks, int ntasks,
+    int32_t *__restrict__ done, int32_t *__restrict__ ctrl /* [0] next task, [1] error, [2..] debug */) {
+    constexpr int N = 1 << LOGN;
+    __shared__ __align__(16) Br4Lds<LOGN> sh;
+    __shared__ __align__(16) uint32_t lds_u[N + 8];           // extracted sample(s): kN mask words, body
+    __shared__ int32_t s_task;
+    const int tid = threadIdx.x;
+
+    // Loop shape matters: the condition is a scalar (readfirstlane) value, and the only
+    // single-lane block that touches the loop-carried state (publish + take the next task)
+    // sits between two barriers INSIDE the iteration.  With `if (tid == 0)` blocks on both
+    // sides of the back-edge the compiler's CFG structuriser parks lane 0 and sends the other
+    // lanes around the loop again (observed: the same task re-executed forever).
+    auto take_task = [&]() -> int32_t {
+        int32_t t = __hip_atomic_fetch_add(&ctrl[0], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (__hip_atomic_load(&ctrl[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) t = ntasks;
+        return t;
+    };
+    if (tid == 0) s_task = take_task();
+    __syncthreads();
+    int ti = __builtin_amdgcn_readfirstlane(s_task);
+    while (ti < ntasks) {
+        GateTask task;
+        {
+            const int32_t *tw = reinterpret_cast<const int32_t *>(tasks + ti);
+            int32_t *dw = reinterpret_cast<int32_t *>(&task);
+#pragma unroll
+            for (int f = 0; f < (int)(sizeof(GateTask) / 4); ++f) dw[f] = __builtin_amdgcn_readfirstlane(tw[f]);
+        }
+#ifdef TFHE_HIP_STAMPS   // progress words for the TFHE_HIP_DF_DEBUG watchdog (diagnostic build only)
+#define DF_MARK(code) do { if (tid == 0) __hip_atomic_store(&ctrl[4 + (blockIdx.x & 63)], (ti << 8) | (code), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); } while (0)
+#else
+#define DF_MARK(code)
+#endif
+        DF_MARK(1);
+
+        // ---- wait for the producers (tasks with smaller indices), then one acquire ----
+        if (tid == 0) {
+            const int32_t deps[3] = {task.dep_a, task.dep_b, task.dep_c};
+            for (int d = 0; d < 3; ++d) {
+                if (deps[d] < 0) continue;
+                unsigned spins = 0;
+                while (__hip_atomic_load(&done[deps[d]], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0) {
+                    __builtin_amdgcn_s_sleep(32);
+                    if (++spins > (1u << 22)) {                 // ~seconds: something is wrong, leave
+                        __hip_atomic_store(&ctrl[1], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        break;
+                    }
+                }
+            }
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
+        __syncthreads();
+        DF_MARK(2);
+
+        int32_t *dst = pool + (size_t)task.dst_slot * p.ct_stride;
+        if (task.kind == TASK_NOT) {
+            const int32_t *src = pool + (size_t)task.slot_a * p.ct_stride;
+            for (int i = tid; i < p.ct_stride; i += 256) dst[i] = (int32_t)(0u - (uint32_t)src[i]);
+        } else {
+            // first (or only) blind rotation, sample extract into LDS
+            const RotDesc r0{task.slot_a, task.slot_b, task.sa, task.sb, task.c0, 0};
+            blind_rotate4_body<LOGN>(p, key, pool, r0, sh, tid);
+            DF_MARK(3);
+            for (int j = tid; j < N; j += 256) lds_u[j] = j == 0 ? sh.acc[0][0] : 0u - sh.acc[0][N - j];
+            if (tid == 0) lds_u[N] = sh.acc[1][0];
+            __syncthreads();
+            if (task.kind == TASK_MUX) {
+                // tfhe bootsMUX: second rotation on (-1/8 - a + c), then u1 + u2 + (0, 1/8)
+                const RotDesc r1{task.slot_a, task.slot_c, -1, 1, task.c0, 0};
+                blind_rotate4_body<LOGN>(p, key, pool, r1, sh, tid);
+                for (int j = tid; j < N; j += 256) lds_u[j] += j == 0 ? sh.acc[0][0] : 0u - sh.acc[0][N - j];
+                if (tid == 0) lds_u[N] += sh.acc[1][0] + (uint32_t)p.mu;
+                __syncthreads();
+            }
+            DF_MARK(4);
+            keyswitch_in_wg<LOGN>(p, key, sh, lds_u, dst, tid);
+            DF_MARK(5);
+        }
+
+        // ---- publish, and take the next task in the same single-lane block ----
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (tid == 0) {
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __hip_atomic_store(&done[ti], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            s_task = take_task();
+        }
+        __syncthreads();
+        ti = __builtin_amdgcn_readfirstlane(s_task);
+    }
 }
 
 // ---------------------------------------------------------------------------
@@ -565,6 +773,16 @@ void launch_blind_rotate4(hipStream_t s, const DevParams &p, const DevKey &key, 
         hipLaunchKernelGGL(blind_rotate4_kernel<11>, dim3(count), dim3(256), 0, s, p, key, pool, rots, u_buf, acc_dbg);
     else
         hipLaunchKernelGGL(blind_rotate4_kernel<10>, dim3(count), dim3(256), 0, s, p, key, pool, rots, u_buf, acc_dbg);
+}
+
+void launch_gate_dataflow(hipStream_t s, const DevParams &p, const DevKey &key, int32_t *pool, const GateTask *tasks,
+                          int ntasks, int32_t *done, int32_t *ctrl, int max_blocks) {
+    if (ntasks <= 0) return;
+    const int grid = ntasks < max_blocks ? ntasks : max_blocks;
+    if (p.N == 2048)
+        hipLaunchKernelGGL(gate_dataflow_kernel<11>, dim3(grid), dim3(256), 0, s, p, key, pool, tasks, ntasks, done, ctrl);
+    else
+        hipLaunchKernelGGL(gate_dataflow_kernel<10>, dim3(grid), dim3(256), 0, s, p, key, pool, tasks, ntasks, done, ctrl);
 }
 
 void launch_keyswitch(hipStream_t s, const DevParams &p, const DevKey &key, const int32_t *u_buf,

@@ -20,6 +20,7 @@ struct DevParams {
 struct DevKey {
     const uint32_t *bk_img;  // [n][kpl][prime 2][w 2][N] NTT image, Montgomery form, x N^-1
     const int32_t *ksk;      // [kN][t][base-1][ct_stride]
+    const int32_t *ksk_zero; // one more row of ct_stride zeros (digit 0 of the key switch)
     const uint32_t *tw;      // [prime 2][fwd, inv][N] twiddles, Montgomery form
 };
 
@@ -41,6 +42,19 @@ struct KsDesc {
 
 struct NotDesc { int32_t src_slot, dst_slot; };
 
+// One node of a recorded gate DAG for the dataflow executor.  kind TASK_GATE2:
+// dst = KS(BR((0,c0) + sa*a + sb*b)); TASK_MUX: tfhe bootsMUX(a, b, c) (c0 = -1/8);
+// TASK_NOT: dst = -a.  dep_x = index of the task that produces slot_x in this launch, or -1.
+enum : int32_t { TASK_GATE2 = 0, TASK_MUX = 1, TASK_NOT = 2 };
+struct GateTask {
+    int32_t kind;
+    int32_t dst_slot;
+    int32_t slot_a, slot_b, slot_c;
+    int32_t sa, sb, c0;
+    int32_t dep_a, dep_b, dep_c;
+    int32_t pad;
+};
+
 void launch_bk_transform(hipStream_t s, const DevParams &p, const int32_t *raw_polys, uint32_t *img,
                          const uint32_t *tw, int npoly_per_w, int nw, const uint32_t scale[2]);
 void launch_blind_rotate(hipStream_t s, const DevParams &p, const DevKey &key, const int32_t *pool,
@@ -56,6 +70,11 @@ void launch_not(hipStream_t s, const DevParams &p, const NotDesc *descs, int cou
 // res[c] = ip[c] * (poly whose image is img[c]) through the device NTT
 void launch_negacyclic(hipStream_t s, const DevParams &p, const uint32_t *tw, const int32_t *ip,
                        const uint32_t *img, int32_t *res, int count);
+
+// whole-DAG launch; `done` (ntasks words) and `ctrl` (2 words) must be zero; at most
+// max_blocks workgroups are started (any number makes progress)
+void launch_gate_dataflow(hipStream_t s, const DevParams &p, const DevKey &key, int32_t *pool, const GateTask *tasks,
+                          int ntasks, int32_t *done, int32_t *ctrl, int max_blocks);
 
 void launch_gather_slots(hipStream_t s, const int32_t *pool, int stride, int words, const int32_t *slots, int count,
                          int32_t *packed);

@@ -14,11 +14,26 @@ struct HeapItem {
 };
 }  // namespace
 
+void priority_order(const std::vector<PendingOp> &ops, const std::vector<int32_t> &lvl,
+                    const std::vector<int32_t> &alap, std::vector<int32_t> &order) {
+    const int n = (int)ops.size();
+    order.resize(n);
+    for (int i = 0; i < n; ++i) order[i] = i;
+    std::stable_sort(order.begin(), order.end(), [&](int32_t x, int32_t y) {
+        if (lvl[x] != lvl[y]) return lvl[x] < lvl[y];
+        const bool nx = ops[x].kind == OP_NOT, ny = ops[y].kind == OP_NOT;
+        if (nx != ny) return ny;                 // gates of a level before the NOTs riding on it
+        if (alap[x] != alap[y]) return alap[x] < alap[y];
+        return x < y;
+    });
+}
+
 int schedule_levels(const std::vector<PendingOp> &ops, int asap_depth, bool balance, int unit,
-                    std::vector<int32_t> &lvl) {
+                    std::vector<int32_t> &lvl, std::vector<int32_t> *alap_out) {
     const int n = (int)ops.size();
     lvl.resize(n);
     for (int i = 0; i < n; ++i) lvl[i] = ops[i].level;
+    if (alap_out) *alap_out = lvl;
     if (!balance || asap_depth <= 2 || n < 4 * unit) return asap_depth;
 
     // producer of each pending slot (destinations are unique: SSA)
@@ -55,6 +70,8 @@ int schedule_levels(const std::vector<PendingOp> &ops, int asap_depth, bool bala
             a = std::min(a, need);
         }
     }
+
+    if (alap_out) *alap_out = alap;
 
     // list scheduling, least slack first
     long long remaining = 0;

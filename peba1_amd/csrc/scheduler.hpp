@@ -29,7 +29,14 @@ inline int op_rotations(const PendingOp &op) { return op.kind == OP_NOT ? 0 : (o
 // full pass of the latency kernel holds (the CU count); levels are filled to 1, 2
 // or 4 units depending on how much work is left per remaining level.  With
 // balance == false, or for trivial DAGs, lvl = ASAP.  Returns the depth.
+// If alap_out is given it receives each op's ALAP level (== lvl when not balancing).
 int schedule_levels(const std::vector<PendingOp> &ops, int asap_depth, bool balance, int unit,
-                    std::vector<int32_t> &lvl);
+                    std::vector<int32_t> &lvl, std::vector<int32_t> *alap_out = nullptr);
+
+// Execution order for the dataflow executor: a topological order of the DAG in which
+// more urgent gates come first (balanced level, then ALAP level, then recording order;
+// a NOT directly after the gates of its level).  order[k] = index into ops.
+void priority_order(const std::vector<PendingOp> &ops, const std::vector<int32_t> &lvl,
+                    const std::vector<int32_t> &alap, std::vector<int32_t> &order);
 
 }  // namespace tfhe_hip

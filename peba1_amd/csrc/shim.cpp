@@ -81,12 +81,14 @@ struct Recorder {
     Rng enc_rng{0x5EBA1};
     uint64_t keygen_counter = 0;
     bool balance_levels = true;   // slack-aware level filling (scheduler.hpp)
+    bool dataflow = false;        // opt-in: one dataflow launch per flush instead of per-level launches
     std::unordered_map<int32_t, int32_t> not_origin;   // pending NOT output slot -> its operand slot
 };
 Recorder &rec() {
     static Recorder r;
     static bool init = [] {
         if (const char *e = std::getenv("TFHE_HIP_DEFERRED")) r.deferred = std::atoi(e) != 0;
+        if (const char *e = std::getenv("TFHE_HIP_DATAFLOW")) r.dataflow = std::atoi(e) != 0;
         return true;
     }();
     (void)init;
@@ -182,10 +184,49 @@ int flush_locked() {
     Recorder &r = rec();
     if (r.ops.empty()) return 0;
     SlotPool *pool = r.pool;
-    LevelPlan plan;
     // level of every op: ASAP, or slack-aware balanced (same depth, fuller narrow levels)
-    std::vector<int32_t> lvl;
-    const int levels = schedule_levels(r.ops, r.max_level, r.balance_levels, Engine::get().cu_count(), lvl);
+    std::vector<int32_t> lvl, alap;
+    const int levels = schedule_levels(r.ops, r.max_level, r.balance_levels, Engine::get().cu_count(), lvl, &alap);
+    if (r.dataflow) {
+        // one launch for the whole DAG: tasks in topological priority order, each naming the
+        // tasks that produce its operands
+        std::vector<int32_t> order;
+        priority_order(r.ops, lvl, alap, order);
+        std::unordered_map<int32_t, int32_t> task_of_slot;
+        task_of_slot.reserve(r.ops.size() * 2);
+        std::vector<GateTask> tasks(r.ops.size());
+        const int32_t mu = 1 << 29;
+        auto dep = [&](int32_t slot) {
+            if (slot < 0) return (int32_t)-1;
+            auto it = task_of_slot.find(slot);
+            return it == task_of_slot.end() ? (int32_t)-1 : it->second;
+        };
+        for (size_t k = 0; k < order.size(); ++k) {
+            const PendingOp &op = r.ops[order[k]];
+            GateTask t{};
+            t.dst_slot = op.dst;
+            t.slot_a = op.a; t.slot_b = op.b >= 0 ? op.b : op.a; t.slot_c = op.c >= 0 ? op.c : op.a;
+            t.dep_a = dep(op.a); t.dep_b = dep(op.b); t.dep_c = dep(op.c);
+            if (op.kind == OP_NOT) { t.kind = TASK_NOT; }
+            else if (op.kind == OP_MUX) { t.kind = TASK_MUX; t.sa = 1; t.sb = 1; t.c0 = -mu; }
+            else { const GateLin &gl = GATE_LIN[op.kind]; t.kind = TASK_GATE2; t.sa = gl.sa; t.sb = gl.sb; t.c0 = gl.c8 * mu; }
+            tasks[k] = t;
+            task_of_slot.emplace(op.dst, (int32_t)k);
+        }
+        Engine::get().execute_dataflow(r.key->bk->dev, pool, tasks, levels);
+        for (const PendingOp &op : r.ops) {
+            pool->level[op.dst] = 0;
+            pool->release(op.dst);
+            pool->release(op.a);
+            if (op.b >= 0) pool->release(op.b);
+            if (op.c >= 0) pool->release(op.c);
+        }
+        r.ops.clear();
+        r.not_origin.clear();
+        r.max_level = 0;
+        return levels;
+    }
+    LevelPlan plan;
     // counting sort by level
     std::vector<int32_t> nrot(levels + 2, 0), nks(levels + 2, 0), nnot(levels + 2, 0);
     for (size_t i = 0; i < r.ops.size(); ++i) {
@@ -607,6 +648,7 @@ int tfhe_hip_set_tuning(const char *name, int64_t value) {
     if (name && std::strcmp(name, "br4_max_rotations") == 0) { Engine::get().br4_max_rotations = (int)value; return 0; }
     if (name && std::strcmp(name, "ks_target_blocks") == 0) { Engine::get().ks_target_blocks = (int)value; return 0; }
     if (name && std::strcmp(name, "balance_levels") == 0) { rec().balance_levels = value != 0; return 0; }
+    if (name && std::strcmp(name, "dataflow") == 0) { rec().dataflow = value != 0; return 0; }
     set_error(std::string("tfhe_hip_set_tuning: unknown name ") + (name ? name : "(null)"));
     return -1;
 }
