@@ -60,7 +60,8 @@ def cpu_baseline(seed):
     oks.gate_batch("AND", a[:2], b[:2], nthreads=1)
     single = 2.0 / (time.perf_counter() - t1)
     return {"value": count / dt, "unit": "bootstrapped gates/s", "cores": cores, "kind": "port",
-            "sample": f"{count} independent bootsAND (P128) on {cores} threads, oracle exact-integer NTT; "
+            "sample": f"{count} independent bootsAND (P128) on {cores} threads, oracle exact-integer two-prime NTT "
+                      f"(scalar C; upstream TFHE's fp64-FFT path is roughly 5-10x faster per core); "
                       f"1 thread: {single:.2f} gates/s"}
 
 
@@ -188,7 +189,7 @@ def main():
                                    f"{int(rot_per_match)} blind rotations per match, bit-exact vs CPU oracle",
                        "parallelism": f"1 match per GPU x {world}", "levels_per_match": int(st["levels"] / max(1, args.steps))},
             "match_ms": elapsed * 1e3 / max(1, args.steps),
-            "roofline": {"bound": "hbm", "kernel": "blind_rotate_kernel", "achieved": br_gbps, "peak": HBM_PEAK_GBPS,
+            "roofline": {"bound": "hbm", "kernel": "blind_rotate4_kernel", "achieved": br_gbps, "peak": HBM_PEAK_GBPS,
                          "unit": "GB/s", "frac": br_gbps / HBM_PEAK_GBPS, "traffic": traffic,
                          "launches": int(st["br_launches"]),
                          "avg_launch_ms": st["ms_blind_rotate"] / max(1, st["br_launches"]),

@@ -168,9 +168,10 @@ class KeySet:
         return lib().orc_phase(self.h, _p(np.ascontiguousarray(ct, dtype=np.int32)))
 
     def gate(self, name, ca, cb, use_ntt=True):
+        """use_ntt: False/0 schoolbook, True/1 Goldilocks NTT, 2 two-prime evaluator (same words)."""
         out = np.zeros(self.n + 1, dtype=np.int32)
         lib().orc_gate2(self.h, GATES[name], _p(out), _p(np.ascontiguousarray(ca)), _p(np.ascontiguousarray(cb)),
-                        1 if use_ntt else 0)
+                        int(use_ntt))
         return out
 
     def gate_batch(self, name, ca, cb, nthreads=1):
@@ -183,7 +184,7 @@ class KeySet:
     def mux(self, a, b, c, use_ntt=True):
         out = np.zeros(self.n + 1, dtype=np.int32)
         lib().orc_mux(self.h, _p(out), _p(np.ascontiguousarray(a)), _p(np.ascontiguousarray(b)),
-                      _p(np.ascontiguousarray(c)), 1 if use_ntt else 0)
+                      _p(np.ascontiguousarray(c)), int(use_ntt))
         return out
 
     def gate_not(self, a):

@@ -8,12 +8,13 @@
  * /root/reference/CMakeLists.txt:9-15); the algorithm follows SURVEY.md
  * Appendix A.  Each function names the upstream routine it restates.
  *
- * The negacyclic product is exact mod 2^32.  Two interchangeable evaluators:
- *   - schoolbook in wrapping 32-bit arithmetic (the definition), and
+ * The negacyclic product is exact mod 2^32.  Three interchangeable evaluators:
+ *   - schoolbook in wrapping 32-bit arithmetic (the definition),
  *   - a 64-bit Goldilocks (p = 2^64-2^32+1) NTT, exact because
- *     |sum| < (k+1) l N (Bg/2) 2^31 <= 2^52 < p/2  (SURVEY.md Appendix A.5).
- * The GPU path uses neither (two 27-bit primes + CRT), so agreement of all
- * three is a meaningful check.
+ *     |sum| < (k+1) l N (Bg/2) 2^31 <= 2^52 < p/2  (SURVEY.md Appendix A.5), and
+ *   - two 27-bit primes + CRT in plain vectorisable loops (the arithmetic the GPU
+ *     uses; here for a CPU baseline that is not handicapped by 128-bit products).
+ * tests/test_host_cpu.py checks that all three give the same words.
  */
 #include "tfhe_oracle.h"
 
@@ -242,6 +243,113 @@ void orc_negacyclic_ntt(Torus32 *res, const int32_t *ip, const Torus32 *tp, int3
 }
 
 /* ------------------------------------------------------------------ */
+/* Third evaluator of the exact negacyclic product: two 27-bit primes    */
+/* (the same pair the GPU uses) with 32-bit Montgomery arithmetic and    */
+/* CRT.  Plain loops over uint32_t that gcc vectorises; it exists so     */
+/* that the cpu_baseline is not handicapped by 128-bit scalar products.  */
+/* Exact for |sum| < P0*P1/2 ~ 2^53 (checked at key generation).         */
+/* ------------------------------------------------------------------ */
+#define FP0 134111233u
+#define FP1 134176769u
+static const uint32_t FP[2] = {FP0, FP1};
+static const uint32_t FGEN[2] = {10u, 3u};        /* primitive roots */
+
+typedef struct FastTab {
+    int32_t N;
+    uint32_t pinv[2];          /* -P^-1 mod 2^32 */
+    uint32_t *wf[2], *wi[2];   /* psi^{+-brv(i)} * R mod P */
+    uint32_t scale[2];         /* N^-1 * R mod P (folded into the key image) */
+    uint32_t p0inv_mont;       /* P0^-1 mod P1, Montgomery form */
+} FastTab;
+static FastTab g_ftabs[4];
+static int g_nftabs = 0;
+
+static uint64_t powmod64(uint64_t a, uint64_t e, uint64_t p) {
+    uint64_t r = 1; a %= p;
+    while (e) { if (e & 1) r = r * a % p; a = a * a % p; e >>= 1; }
+    return r;
+}
+static inline uint32_t fmont(uint32_t a, uint32_t b, uint32_t P, uint32_t pinv) {
+    const uint64_t T = (uint64_t)a * b;
+    const uint32_t m = (uint32_t)T * pinv;
+    const uint32_t r = (uint32_t)((T + (uint64_t)m * P) >> 32);   /* < 2P for a,b < P... a < 2^32 */
+    return r >= P ? r - P : r;
+}
+static const FastTab *fast_tab(int32_t N) {
+    pthread_mutex_lock(&g_tab_mtx);
+    for (int i = 0; i < g_nftabs; ++i)
+        if (g_ftabs[i].N == N) { pthread_mutex_unlock(&g_tab_mtx); return &g_ftabs[i]; }
+    FastTab *t = &g_ftabs[g_nftabs];
+    int logn = 0; while ((1 << logn) < N) ++logn;
+    t->N = N;
+    for (int q = 0; q < 2; ++q) {
+        const uint64_t P = FP[q], R = (UINT64_C(1) << 32) % P;
+        uint32_t x = (uint32_t)P;                     /* Newton: P^-1 mod 2^32 */
+        for (int i = 0; i < 5; ++i) x *= 2u - (uint32_t)P * x;
+        t->pinv[q] = 0u - x;
+        const uint64_t psi = powmod64(FGEN[q], (P - 1) / (uint64_t)(2 * N), P), ipsi = powmod64(psi, P - 2, P);
+        t->wf[q] = (uint32_t *)malloc(sizeof(uint32_t) * N);
+        t->wi[q] = (uint32_t *)malloc(sizeof(uint32_t) * N);
+        uint64_t a = 1, b = 1;
+        for (int32_t i = 0; i < N; ++i) {
+            const uint32_t j = bitrev((uint32_t)i, logn);
+            t->wf[q][j] = (uint32_t)(a * R % P);
+            t->wi[q][j] = (uint32_t)(b * R % P);
+            a = a * psi % P; b = b * ipsi % P;
+        }
+        t->scale[q] = (uint32_t)(powmod64((uint64_t)N, P - 2, P) * R % P);
+    }
+    t->p0inv_mont = (uint32_t)(powmod64(FP0, FP1 - 2, FP1) * ((UINT64_C(1) << 32) % FP1) % FP1);
+    ++g_nftabs;
+    pthread_mutex_unlock(&g_tab_mtx);
+    return t;
+}
+/* forward / inverse transforms on canonical residues [0,P).  target_clones: gcc emits an
+ * AVX2 and a baseline version and picks at load time, so the .so still runs anywhere. */
+#define ORC_MULTIVERSION __attribute__((target_clones("avx2", "default")))
+ORC_MULTIVERSION static void fast_fwd(uint32_t *a, const FastTab *t, int q) {
+    const uint32_t P = FP[q], pinv = t->pinv[q];
+    const int32_t N = t->N;
+    for (int32_t m = 1, len = N / 2; m < N; m <<= 1, len >>= 1)
+        for (int32_t i = 0; i < m; ++i) {
+            const uint32_t w = t->wf[q][m + i];
+            uint32_t *x = a + 2 * i * len, *y = x + len;
+            for (int32_t j = 0; j < len; ++j) {
+                const uint32_t u = x[j], v = fmont(y[j], w, P, pinv);
+                uint32_t s = u + v, d = u + P - v;
+                x[j] = s >= P ? s - P : s;
+                y[j] = d >= P ? d - P : d;
+            }
+        }
+}
+ORC_MULTIVERSION static void fast_inv(uint32_t *a, const FastTab *t, int q) {
+    const uint32_t P = FP[q], pinv = t->pinv[q];
+    const int32_t N = t->N;
+    for (int32_t m = N / 2, len = 1; m >= 1; m >>= 1, len <<= 1)
+        for (int32_t i = 0; i < m; ++i) {
+            const uint32_t w = t->wi[q][m + i];
+            uint32_t *x = a + 2 * i * len, *y = x + len;
+            for (int32_t j = 0; j < len; ++j) {
+                const uint32_t u = x[j], v = y[j];
+                uint32_t s = u + v;
+                x[j] = s >= P ? s - P : s;
+                y[j] = fmont(u + P - v, w, P, pinv);
+            }
+        }
+}
+/* sum[j] += x[j] * b[j] over one polynomial */
+ORC_MULTIVERSION static void fast_mac(uint64_t *sum, const uint32_t *x, const uint32_t *b, int32_t N) {
+    for (int32_t j = 0; j < N; ++j) sum[j] += (uint64_t)x[j] * b[j];
+}
+static inline uint32_t fast_from_i32(int32_t v, uint32_t P) { int32_t m = v % (int32_t)P; return (uint32_t)(m < 0 ? m + (int32_t)P : m); }
+/* CRT of canonical residues, centred, mod 2^32 */
+static inline Torus32 fast_crt(uint32_t r0, uint32_t r1, const FastTab *t) {
+    const uint32_t tt = fmont(r1 + FP1 - r0, t->p0inv_mont, FP1, t->pinv[1]);
+    const uint64_t v = (uint64_t)FP0 * tt + r0, M = (uint64_t)FP0 * FP1;
+    return (Torus32)(uint32_t)(v > (M - 1) / 2 ? v - M : v);
+}
+
+/* ------------------------------------------------------------------ */
 /* key generation (tfhe: new_random_gate_bootstrapping_secret_keyset,   */
 /* tGswSymEncryptInt, lweCreateKeySwitchKey) with this repo's PRNG.     */
 /* Draw order is part of the shared specification:                      */
@@ -304,6 +412,20 @@ OrcKeySet *orc_keygen(const OrcParams *p, uint64_t seed) {
                 row[n] = (Torus32)b;
             }
 
+    /* image for the two-prime evaluator: [poly][prime][N], Montgomery form times N^-1 */
+    {
+        const FastTab *ft = fast_tab(N);
+        const size_t npoly_f = (size_t)n * kpl * (k + 1);
+        ks->bk_fast = (uint32_t *)malloc(sizeof(uint32_t) * npoly_f * 2 * N);
+        for (size_t qq = 0; qq < npoly_f; ++qq)
+            for (int pr = 0; pr < 2; ++pr) {
+                uint32_t *dst = ks->bk_fast + (qq * 2 + pr) * N;
+                const Torus32 *src = ks->bk + qq * N;
+                for (int32_t j = 0; j < N; ++j) dst[j] = fast_from_i32(src[j], FP[pr]);
+                fast_fwd(dst, ft, pr);
+                for (int32_t j = 0; j < N; ++j) dst[j] = (uint32_t)((uint64_t)dst[j] * ft->scale[pr] % FP[pr]);
+            }
+    }
     /* evaluation-domain image of BK (tfhe: LweBootstrappingKeyFFT) */
     const NttTab *tab = ntt_tab(N);
     const size_t npoly = (size_t)n * kpl * (k + 1);
@@ -319,7 +441,7 @@ OrcKeySet *orc_keygen(const OrcParams *p, uint64_t seed) {
 
 void orc_keyset_free(OrcKeySet *ks) {
     if (!ks) return;
-    free(ks->lwe_key); free(ks->tlwe_key); free(ks->bk); free(ks->ksk); free(ks->bk_ntt);
+    free(ks->lwe_key); free(ks->tlwe_key); free(ks->bk); free(ks->ksk); free(ks->bk_ntt); free(ks->bk_fast);
     free(ks);
 }
 
@@ -399,7 +521,40 @@ void orc_cmux_rotate(const OrcKeySet *ks, int32_t i, int32_t barai, Torus32 *acc
         mul_xai_minus_one(d + (size_t)u * N, barai, acc + (size_t)u * N, N);
         orc_decompose(dig + (size_t)u * l * N, d + (size_t)u * N, p);
     }
-    if (use_ntt) {
+    if (use_ntt == 2) {
+        const FastTab *ft = fast_tab(N);
+        uint32_t *dn = (uint32_t *)malloc(sizeof(uint32_t) * (size_t)(kpl + 2 * (k + 1)) * N);
+        uint32_t *res = dn + (size_t)kpl * N;                 /* [prime][k+1][N] canonical residues */
+        uint64_t *sum = (uint64_t *)malloc(sizeof(uint64_t) * N);
+        for (int pr = 0; pr < 2; ++pr) {
+            const uint32_t P = FP[pr], pinv = ft->pinv[pr];
+            for (int32_t q = 0; q < kpl; ++q) {               /* kpl forward transforms */
+                uint32_t *x = dn + (size_t)q * N;
+                for (int32_t j = 0; j < N; ++j) x[j] = fast_from_i32(dig[(size_t)q * N + j], P);
+                fast_fwd(x, ft, pr);
+            }
+            for (int32_t w = 0; w <= k; ++w) {                /* MAC against the key image, inverse */
+                for (int32_t j = 0; j < N; ++j) sum[j] = 0;
+                for (int32_t q = 0; q < kpl; ++q) {
+                    const uint32_t *bkq = ks->bk_fast + ((((size_t)i * kpl + q) * (k + 1) + w) * 2 + pr) * N;
+                    const uint32_t *x = dn + (size_t)q * N;
+                    fast_mac(sum, x, bkq, N);                                             /* < kpl * P^2 < 2^57 */
+                }
+                uint32_t *r = res + ((size_t)pr * (k + 1) + w) * N;
+                for (int32_t j = 0; j < N; ++j) {
+                    const uint32_t m = (uint32_t)sum[j] * pinv;
+                    r[j] = (uint32_t)((sum[j] + (uint64_t)m * P) >> 32) % P;
+                }
+                fast_inv(r, ft, pr);
+            }
+        }
+        for (int32_t w = 0; w <= k; ++w) {
+            uint32_t *a = (uint32_t *)(acc + (size_t)w * N);
+            const uint32_t *r0 = res + (size_t)w * N, *r1 = res + ((size_t)(k + 1) + w) * N;
+            for (int32_t j = 0; j < N; ++j) a[j] += (uint32_t)fast_crt(r0[j], r1[j], ft);
+        }
+        free(dn); free(sum);
+    } else if (use_ntt) {
         const NttTab *tab = ntt_tab(N);
         uint64_t *dn = (uint64_t *)malloc(sizeof(uint64_t) * (size_t)(kpl + k + 1) * N);
         uint64_t *sum = dn + (size_t)kpl * N;
@@ -563,7 +718,7 @@ static void *batch_worker(void *arg) {
     BatchJob *j = (BatchJob *)arg;
     const size_t w = (size_t)j->ks->p.n + 1;
     for (int32_t g = j->begin; g < j->end; ++g)
-        orc_gate2(j->ks, j->gate, j->out + g * w, j->ca + g * w, j->cb + g * w, 1);
+        orc_gate2(j->ks, j->gate, j->out + g * w, j->ca + g * w, j->cb + g * w, 2);
     return NULL;
 }
 
@@ -571,7 +726,7 @@ void orc_gate2_batch(const OrcKeySet *ks, int gate, Torus32 *out, const Torus32 
                      int32_t count, int32_t nthreads) {
     if (nthreads < 1) nthreads = 1;
     if (nthreads > count) nthreads = count > 0 ? count : 1;
-    (void)ntt_tab(ks->p.N);
+    (void)fast_tab(ks->p.N);
     pthread_t *th = (pthread_t *)malloc(sizeof(pthread_t) * nthreads);
     BatchJob *jobs = (BatchJob *)malloc(sizeof(BatchJob) * nthreads);
     for (int32_t t = 0; t < nthreads; ++t) {

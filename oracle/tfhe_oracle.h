@@ -69,6 +69,7 @@ typedef struct OrcKeySet {
     Torus32  *bk;        /* [n][(k+1)l][k+1][N]  TGSW(s_i), torus domain     */
     Torus32  *ksk;       /* [kN][t][base][n+1]   row 0 of each digit is zero */
     uint64_t *bk_ntt;    /* [n][(k+1)l][k+1][N]  Goldilocks NTT image of bk  */
+    uint32_t *bk_fast;   /* [n][(k+1)l][k+1][2][N] two-prime Montgomery image  */
 } OrcKeySet;
 
 OrcKeySet *orc_keygen(const OrcParams *p, uint64_t seed);
@@ -84,6 +85,8 @@ int32_t orc_decrypt_bit(const OrcKeySet *ks, const Torus32 *ct);
 /* ---- pieces of one bootstrapped gate ---- */
 int32_t orc_modswitch(Torus32 x, int32_t Msize);              /* step 2 */
 Torus32 orc_modswitch_to_torus(int32_t mu, int32_t Msize);
+/* use_ntt arguments below: 0 = schoolbook, 1 = Goldilocks NTT, 2 = two 27-bit primes + CRT
+ * (vectorisable; used by the cpu_baseline).  All three give the same words. */
 /* exact negacyclic product res = ip * tp mod (X^N+1) mod 2^32, schoolbook */
 void orc_negacyclic_schoolbook(Torus32 *res, const int32_t *ip, const Torus32 *tp, int32_t N);
 /* same product through the Goldilocks NTT (must equal the schoolbook)      */

@@ -37,6 +37,8 @@ def test_oracle_matches_golden_digests(oracle, oks, golden):
     cts = oks.encrypt(oracle.Rng(golden["encrypt_seed"]), [0, 1, 1, 0, 1, 1])
     assert sha(cts) == golden["encryptions_011011"]
     assert sha(oks.gate("AND", cts[1], cts[2])) == golden["gates"]["AND_1_2"]
+    assert sha(oks.gate("AND", cts[1], cts[2], use_ntt=2)) == golden["gates"]["AND_1_2"]     # fast evaluator, same words
+    assert sha(oks.gate_batch("XOR", cts[0:1], cts[1:2])[0]) == golden["gates"]["XOR_0_1"]    # threaded batch path
     assert sha(oks.mux(cts[1], cts[0], cts[2])) == golden["gates"]["MUX_1_0_2"]
     assert list(oks.decrypt(cts)) == [0, 1, 1, 0, 1, 1]
 
@@ -85,13 +87,16 @@ def test_oracle_truth_tables_small_params(oracle):
             for b in (0, 1):
                 ca, cb = ks.encrypt(r, [a, b])
                 o = ks.gate(name, ca, cb, use_ntt=True)
-                assert (o == ks.gate(name, ca, cb, use_ntt=False)).all()
+                assert (o == ks.gate(name, ca, cb, use_ntt=False)).all()      # Goldilocks == schoolbook
+                assert (o == ks.gate(name, ca, cb, use_ntt=2)).all()          # == two-prime evaluator
                 assert ks.decrypt(o)[0] == f(a, b)
     for a in (0, 1):
         for b in (0, 1):
             for c in (0, 1):
                 ca, cb, cc = ks.encrypt(r, [a, b, c])
-                assert ks.decrypt(ks.mux(ca, cb, cc))[0] == (b if a else c)
+                m = ks.mux(ca, cb, cc)
+                assert (m == ks.mux(ca, cb, cc, use_ntt=2)).all()
+                assert ks.decrypt(m)[0] == (b if a else c)
     one = ks.encrypt(r, [1])[0]
     assert ks.decrypt(ks.gate_not(one))[0] == 0
     assert ks.decrypt(ks.constant(1))[0] == 1 and ks.decrypt(ks.constant(0))[0] == 0
