@@ -160,7 +160,8 @@ static uint64_t gl_pow(uint64_t a, uint64_t e) {
 }
 
 typedef struct NttTab { int32_t N; uint64_t *psi_br; uint64_t *ipsi_br; uint64_t ninv; } NttTab;
-static NttTab g_tabs[4];
+#define ORC_MAX_TABS 16
+static NttTab g_tabs[ORC_MAX_TABS];
 static int g_ntabs = 0;
 static pthread_mutex_t g_tab_mtx = PTHREAD_MUTEX_INITIALIZER;
 
@@ -174,6 +175,7 @@ static const NttTab *ntt_tab(int32_t N) {
     pthread_mutex_lock(&g_tab_mtx);
     for (int i = 0; i < g_ntabs; ++i)
         if (g_tabs[i].N == N) { pthread_mutex_unlock(&g_tab_mtx); return &g_tabs[i]; }
+    if (g_ntabs >= ORC_MAX_TABS) abort();        /* more distinct ring degrees than this test helper expects */
     NttTab *t = &g_tabs[g_ntabs];
     int logn = 0; while ((1 << logn) < N) ++logn;
     /* 7 generates the multiplicative group; psi = primitive 2N-th root */
@@ -261,7 +263,7 @@ typedef struct FastTab {
     uint32_t scale[2];         /* N^-1 * R mod P (folded into the key image) */
     uint32_t p0inv_mont;       /* P0^-1 mod P1, Montgomery form */
 } FastTab;
-static FastTab g_ftabs[4];
+static FastTab g_ftabs[ORC_MAX_TABS];
 static int g_nftabs = 0;
 
 static uint64_t powmod64(uint64_t a, uint64_t e, uint64_t p) {
@@ -279,6 +281,7 @@ static const FastTab *fast_tab(int32_t N) {
     pthread_mutex_lock(&g_tab_mtx);
     for (int i = 0; i < g_nftabs; ++i)
         if (g_ftabs[i].N == N) { pthread_mutex_unlock(&g_tab_mtx); return &g_ftabs[i]; }
+    if (g_nftabs >= ORC_MAX_TABS) abort();
     FastTab *t = &g_ftabs[g_nftabs];
     int logn = 0; while ((1 << logn) < N) ++logn;
     t->N = N;
