@@ -1,0 +1,80 @@
+#!/usr/bin/env python3
+"""Writes tests/golden/function_f_digest.json: SHA-256 of the 24 output ciphertexts of a complete
+2-slot Function_f (3,438 bootstrapped gates) evaluated on the CPU ORACLE through this repo's
+circuit library (oracle/liboracle_boots.so), from fixed seeds.  The GPU test
+tests/test_gpu_circuits.py::test_function_f_ciphertexts_match_oracle_digest regenerates the same
+keys and inputs with the product and must reproduce the digest bit for bit.
+Takes ~10 CPU-minutes (0.17 s per gate, single thread)."""
+import ctypes as C
+import hashlib
+import json
+import os
+import subprocess
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, ROOT)
+from oracle import pyoracle as O  # noqa: E402
+
+KEY_SEED, ENC_SEED = 0x5EBA2, 777
+TEMPLATE, PROBE, BOUND, BITS = [37, 200], [40, 190], 100, 8
+
+
+def main():
+    subprocess.check_call(["make", "-s", "-C", os.path.join(ROOT, "oracle")])
+    B = C.CDLL(os.path.join(ROOT, "oracle", "liboracle_boots.so"))
+    V = C.c_void_p
+    B.orc_keygen.restype = V
+    B.orc_keygen.argtypes = [C.POINTER(O.OrcParams), C.c_uint64]
+    B.orc_boots_bind.argtypes = [V, C.c_uint64]
+    B.orc_boots_params.restype = V
+    B.orc_boots_cloud.restype = V
+    B.orc_boots_gate_count.restype = C.c_longlong
+    B.new_gate_bootstrapping_ciphertext_array.restype = V
+    B.new_gate_bootstrapping_ciphertext_array.argtypes = [C.c_int32, V]
+    B.bootsSymEncrypt.argtypes = [V, C.c_int32, V]
+    B.bootsSymDecrypt.argtypes = [V, V]
+    B.orc_boots_export.argtypes = [V, C.c_int32, V]
+    B.peba1_function_f.argtypes = [V, V, V, C.c_int, V, C.c_int, V]
+    p = O.params("P128")
+    ks = B.orc_keygen(C.byref(p), KEY_SEED)
+    B.orc_boots_bind(ks, ENC_SEED)
+    params = B.orc_boots_params()
+    cloud = B.orc_boots_cloud()
+    SZ = 24
+
+    def enc(v, bits):
+        a = B.new_gate_bootstrapping_ciphertext_array(bits, params)
+        for i in range(bits):
+            B.bootsSymEncrypt(a + i * SZ, (v >> i) & 1, None)
+        return a
+
+    # encryption order is part of the fixture: per slot template then probe, then the bound
+    T, S = [], []
+    for t, s in zip(TEMPLATE, PROBE):
+        T.append(enc(t, BITS))
+        S.append(enc(s, BITS))
+    bound = enc(BOUND, 3 * BITS)
+    rb = B.new_gate_bootstrapping_ciphertext_array(3 * BITS, params)
+    t0 = time.time()
+    B.peba1_function_f(rb, (V * len(S))(*S), (V * len(T))(*T), len(S), bound, BITS, cloud)
+    words = np.zeros((3 * BITS, p.n + 1), dtype=np.int32)
+    B.orc_boots_export(rb, 3 * BITS, words.ctypes.data_as(V))
+    bit = B.bootsSymDecrypt(rb, None)
+    d = sum((a - b) ** 2 for a, b in zip(PROBE, TEMPLATE))
+    assert bit == (1 if d > BOUND else 0)
+    out = {"params": "P128", "key_seed": KEY_SEED, "encrypt_seed": ENC_SEED, "template": TEMPLATE, "probe": PROBE,
+           "bound": BOUND, "bits": BITS, "blind_rotates": int(B.orc_boots_gate_count()), "match_bit": int(bit),
+           "result_b_sha256": hashlib.sha256(words.tobytes()).hexdigest(),
+           "result_b0_sha256": hashlib.sha256(words[0].tobytes()).hexdigest(),
+           "oracle_seconds": round(time.time() - t0, 1)}
+    with open(os.path.join(ROOT, "tests", "golden", "function_f_digest.json"), "w") as f:
+        json.dump(out, f, indent=1)
+    print(json.dumps(out, indent=1))
+
+
+if __name__ == "__main__":
+    main()

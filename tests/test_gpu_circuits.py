@@ -106,3 +106,40 @@ def test_sharded_match_over_rccl_world1(p128_keys):
     finally:
         api.set_deferred(False)
         dist.destroy_process_group()
+
+
+def test_function_f_ciphertexts_match_oracle_digest(p128_keys):
+    """Whole-circuit ciphertext parity: a complete 2-slot Function_f (3,438 bootstrapped gates,
+    incl. 24 XNOR + 48 MUX) on the GPU reproduces, bit for bit, the SHA-256 of the 24 output
+    ciphertexts that the CPU oracle produced through the same circuit library
+    (tests/golden/make_function_f_digest.py, ~10 CPU-minutes)."""
+    import hashlib
+    import json
+    from types import SimpleNamespace
+    from peba1_amd import api, circuits, lib
+    pp, ks, _ = p128_keys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    with open(os.path.join(root, "tests", "golden", "function_f_digest.json")) as f:
+        g = json.load(f)
+    assert g["key_seed"] == 0x5EBA2                      # the session keyset of conftest.py
+    L = lib.load()
+    L.tfhe_hip_set_encrypt_seed(g["encrypt_seed"])
+    bits = g["bits"]
+    T, S = [], []
+    for t, s in zip(g["template"], g["probe"]):          # encryption order is part of the fixture
+        T.append(circuits.encrypt_number(pp, t, bits, ks))
+        S.append(circuits.encrypt_number(pp, s, bits, ks))
+    bound = circuits.encrypt_number(pp, g["bound"], 3 * bits, ks)
+    rb = api.CiphertextArray(pp, 3 * bits)
+    api.reset_stats()
+    api.set_deferred(True)
+    try:
+        circuits.function_f(rb, SimpleNamespace(slots=S), SimpleNamespace(slots=T), bound, bits, ks)
+        api.flush()
+    finally:
+        api.set_deferred(False)
+    assert api.stats()["blind_rotates"] == g["blind_rotates"]
+    words = rb.words()
+    assert hashlib.sha256(words[0].tobytes()).hexdigest() == g["result_b0_sha256"]
+    assert hashlib.sha256(words.tobytes()).hexdigest() == g["result_b_sha256"]
+    assert rb.decrypt(ks)[0] == g["match_bit"]

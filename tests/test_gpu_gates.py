@@ -245,3 +245,31 @@ def test_dataflow_executor_gives_identical_ciphertexts(p128_keys, oracle):
         assert circuits.decrypt_number(prod, ks, 23) == 9 * 14
         assert circuits.decrypt_number(mn, ks) == 9 and bit.decrypt(ks)[0] == 0 and neg.decrypt(ks)[0] == 1
     assert (results[0] == results[1]).all()
+
+
+def test_random_gate_sweep_matches_oracle(p128_keys, oracle):
+    """256 random gate instances over all ten two-input gate types, inputs that are fresh
+    encryptions, trivial constants and previous gate outputs: every output word equals the oracle's."""
+    from peba1_amd import api, lib
+    pp, ks, oks = p128_keys
+    L = lib.load()
+    rng = np.random.default_rng(2026)
+    L.tfhe_hip_set_encrypt_seed(2026)
+    nin = 24
+    bits = rng.integers(0, 2, nin)
+    x = api.CiphertextArray(pp, nin).encrypt(bits, ks)
+    L.bootsCONSTANT(x.at(0), 1, ks.cloud)                    # two trivial inputs: every blind-rotate step is skipped
+    L.bootsCONSTANT(x.at(1), 0, ks.cloud)
+    wx = x.words()
+    names = list(api.GATE_CODES)
+    per_type = 26
+    for name in names[:10]:
+        ia = rng.integers(0, nin, per_type)
+        ib = rng.integers(0, nin, per_type)
+        A = api.CiphertextArray(pp, per_type).set_words(wx[ia])
+        B = api.CiphertextArray(pp, per_type).set_words(wx[ib])
+        R = api.CiphertextArray(pp, per_type)
+        api.gate_batch(name, R, A, B, ks)
+        got = R.words()
+        want = oks.gate_batch(name, wx[ia], wx[ib], nthreads=16)
+        assert (got == want).all(), name
