@@ -23,12 +23,37 @@ def last_error():
     return _l.load().tfhe_hip_last_error().decode()
 
 
+class _CFile:
+    """A C FILE* for the tfhe_io.h entry points."""
+    _libc = None
+
+    def __init__(self, path, mode):
+        if _CFile._libc is None:
+            libc = C.CDLL(None)
+            libc.fopen.restype = C.c_void_p
+            libc.fopen.argtypes = [C.c_char_p, C.c_char_p]
+            libc.fclose.argtypes = [C.c_void_p]
+            _CFile._libc = libc
+        self.fp = _CFile._libc.fopen(str(path).encode(), mode.encode())
+        if not self.fp:
+            raise OSError("cannot open %s" % path)
+
+    def __enter__(self):
+        return self.fp
+
+    def __exit__(self, *exc):
+        _CFile._libc.fclose(self.fp)
+        self.fp = None
+
+
 class ParameterSet:
     """new_default_gate_bootstrapping_parameters (main.cpp:21) or an explicit tuple."""
 
-    def __init__(self, minimum_lambda=128, custom=None, p2048=False):
+    def __init__(self, minimum_lambda=128, custom=None, p2048=False, _ptr=None):
         L = _l.load()
-        if custom is not None:
+        if _ptr is not None:
+            self.ptr = _ptr
+        elif custom is not None:
             self.ptr = L.tfhe_hip_new_parameters(*custom)
         elif p2048:
             self.ptr = L.tfhe_hip_new_p2048_parameters()
@@ -44,18 +69,46 @@ class ParameterSet:
         self.ks_t, self.ks_basebit = self.ptr.contents.ks_t, self.ptr.contents.ks_basebit
         self.words = self.n + 1
 
+    def save(self, path):
+        with _CFile(path, "wb") as fp:
+            _l.load().export_tfheGateBootstrappingParameterSet_toFile(fp, self.ptr)
+
+    @classmethod
+    def load(cls, path):
+        with _CFile(path, "rb") as fp:
+            return cls(_ptr=_l.load().new_tfheGateBootstrappingParameterSet_fromFile(fp))
+
 
 class SecretKeySet:
     """new_random_gate_bootstrapping_secret_keyset (main.cpp:22) with an explicit seed."""
 
-    def __init__(self, params, seed, device=True):
+    def __init__(self, params, seed, device=True, _ptr=None):
         L = _l.load()
         self.params = params
-        f = L.tfhe_hip_new_secret_keyset_seeded if device else L.tfhe_hip_new_secret_keyset_seeded_host
-        self.ptr = f(params.ptr, seed)
+        if _ptr is not None:
+            self.ptr = _ptr
+        else:
+            f = L.tfhe_hip_new_secret_keyset_seeded if device else L.tfhe_hip_new_secret_keyset_seeded_host
+            self.ptr = f(params.ptr, seed)
         if not self.ptr:
             raise RuntimeError("keygen failed: " + last_error())
         self.cloud = C.pointer(self.ptr.contents.cloud)   # &key->cloud, main.cpp:23
+
+    def save(self, path):
+        """export_tfheGateBootstrappingSecretKeySet_toFile (tfhe_io.h)."""
+        with _CFile(path, "wb") as fp:
+            _l.load().export_tfheGateBootstrappingSecretKeySet_toFile(fp, self.ptr)
+
+    def save_cloud(self, path):
+        """export_tfheGateBootstrappingCloudKeySet_toFile of &key->cloud: what the server gets."""
+        with _CFile(path, "wb") as fp:
+            _l.load().export_tfheGateBootstrappingCloudKeySet_toFile(fp, self.cloud)
+
+    @classmethod
+    def load(cls, path):
+        with _CFile(path, "rb") as fp:
+            ptr = _l.load().new_tfheGateBootstrappingSecretKeySet_fromFile(fp)
+        return cls(ParameterSet(_ptr=C.cast(ptr.contents.params, _l.PS)), None, _ptr=ptr)
 
     def close(self):
         if self.ptr:
@@ -78,6 +131,37 @@ class SecretKeySet:
 
     def ksk(self):
         return self._arr(_l.load().tfhe_hip_key_ksk, self.cloud)
+
+
+class CloudKeySet(SecretKeySet):
+    """A cloud keyset on its own (new_tfheGateBootstrappingCloudKeySet_fromFile): evaluates
+    gates, cannot encrypt or decrypt."""
+
+    def __init__(self, ptr):
+        self.ptr = None
+        self.cloud = ptr
+        self.params = ParameterSet(_ptr=C.cast(ptr.contents.params, _l.PS))
+
+    @classmethod
+    def load(cls, path):
+        with _CFile(path, "rb") as fp:
+            return cls(_l.load().new_tfheGateBootstrappingCloudKeySet_fromFile(fp))
+
+    def save(self, path):
+        with _CFile(path, "wb") as fp:
+            _l.load().export_tfheGateBootstrappingCloudKeySet_toFile(fp, self.cloud)
+
+    save_cloud = save
+
+    def close(self):
+        if self.cloud:
+            _l.load().delete_gate_bootstrapping_cloud_keyset(self.cloud)
+            self.cloud = None
+
+    def lwe_key(self):
+        raise TypeError("a cloud keyset holds no secret key")
+
+    tlwe_key = lwe_key
 
 
 class CiphertextArray:
@@ -110,6 +194,20 @@ class CiphertextArray:
     def decrypt(self, key):
         L = _l.load()
         return np.array([L.bootsSymDecrypt(self.at(i), key.ptr) for i in range(self.count)], dtype=np.int32)
+
+    def save(self, path):
+        """count x export_gate_bootstrapping_ciphertext_toFile into one file."""
+        L = _l.load()
+        with _CFile(path, "wb") as fp:
+            for i in range(self.count):
+                L.export_gate_bootstrapping_ciphertext_toFile(fp, self.at(i), self.params.ptr)
+
+    def load(self, path):
+        L = _l.load()
+        with _CFile(path, "rb") as fp:
+            for i in range(self.count):
+                L.import_gate_bootstrapping_ciphertext_fromFile(fp, self.at(i), self.params.ptr)
+        return self
 
     def words(self):
         out = np.zeros((self.count, self.params.words), dtype=np.int32)

@@ -13,8 +13,9 @@ $CXX $HOSTFLAGS -c host_keys.cpp -o host_keys.o &
 $CXX $HOSTFLAGS -c engine.cpp -o engine.o &
 $CXX $HOSTFLAGS -c shim.cpp -o shim.o &
 $CXX $HOSTFLAGS -c scheduler.cpp -o scheduler.o &
-wait -n; wait -n; wait -n; wait -n; wait -n
-$HIPCC -shared -o $OUT kernels.o host_keys.o engine.o shim.o scheduler.o
+$CXX $HOSTFLAGS -c io.cpp -o io.o &
+wait -n; wait -n; wait -n; wait -n; wait -n; wait -n
+$HIPCC -shared -o $OUT kernels.o host_keys.o engine.o shim.o scheduler.o io.o
 echo "built $(realpath $OUT)"
 # circuits: calls only the public tfhe API; symbols resolve at load time against
 # whichever provider is loaded first (libtfhe-hip.so, or the tests' plain mock)

@@ -1,0 +1,155 @@
+// io.cpp -- key / ciphertext files behind the tfhe_io.h entry points.
+// Container: {"TFHP", u32 version, u32 kind, u32 reserved, u64 payload bytes} (24 bytes) + payload,
+// little endian.
+#include <cstdio>
+#include <cstring>
+#include <mutex>
+#include <set>
+#include <string>
+#include <vector>
+
+#include "engine.hpp"
+#include "../../include/tfhe/tfhe.h"
+#include "../../include/tfhe/tfhe_io.h"
+
+using namespace tfhe_hip;
+
+namespace {
+
+enum : uint32_t { KIND_PARAMS = 1, KIND_CLOUD = 2, KIND_SECRET = 3, KIND_SAMPLE = 4 };
+constexpr uint32_t VERSION = 1;
+
+struct Header { char magic[4]; uint32_t version, kind, reserved; uint64_t bytes; };
+static_assert(sizeof(Header) == 24, "file header layout");
+
+void put(FILE *F, const void *p, size_t n) {
+    if (n && std::fwrite(p, 1, n, F) != n) fatal("tfhe_io: short write");
+}
+void get(FILE *F, void *p, size_t n) {
+    if (n && std::fread(p, 1, n, F) != n) fatal("tfhe_io: short read (truncated or foreign file)");
+}
+void put_header(FILE *F, uint32_t kind, uint64_t bytes) {
+    Header h{{'T', 'F', 'H', 'P'}, VERSION, kind, 0, bytes};
+    put(F, &h, sizeof h);
+}
+uint64_t get_header(FILE *F, uint32_t kind) {
+    Header h;
+    get(F, &h, sizeof h);
+    if (std::memcmp(h.magic, "TFHP", 4) != 0) fatal("tfhe_io: not a libtfhe-hip file (upstream tfhe files are not interchangeable)");
+    if (h.version != VERSION) fatal("tfhe_io: unsupported file version " + std::to_string(h.version));
+    if (h.kind != kind) fatal("tfhe_io: file holds object kind " + std::to_string(h.kind) + ", expected " + std::to_string(kind));
+    return h.bytes;
+}
+
+struct ParamsRecord { int32_t n, N, k, l, Bgbit, ks_t, ks_basebit, pad; double ks_stdev, bk_stdev, max_stdev; };
+ParamsRecord to_record(const Params &p) { return {p.n, p.N, p.k, p.l, p.Bgbit, p.ks_t, p.ks_basebit, 0, p.ks_stdev, p.bk_stdev, p.max_stdev}; }
+Params from_record(const ParamsRecord &r) { return Params{r.n, r.N, r.k, r.l, r.Bgbit, r.ks_t, r.ks_basebit, r.ks_stdev, r.bk_stdev, r.max_stdev}; }
+
+void put_params(FILE *F, const Params &p) { const ParamsRecord r = to_record(p); put(F, &r, sizeof r); }
+Params get_params(FILE *F) {
+    ParamsRecord r;
+    get(F, &r, sizeof r);
+    const Params p = from_record(r);
+    if (p.n <= 0 || p.N <= 0 || (p.N & (p.N - 1)) || p.k < 1 || p.l < 1 || p.l * p.Bgbit > 32 || p.ks_t * p.ks_basebit > 31)
+        fatal("tfhe_io: corrupt parameter record");
+    return p;
+}
+
+template <typename T>
+void put_vec(FILE *F, const std::vector<T> &v) { put(F, v.data(), v.size() * sizeof(T)); }
+template <typename T>
+void get_vec(FILE *F, std::vector<T> &v, size_t count) { v.resize(count); get(F, v.data(), count * sizeof(T)); }
+
+// keysets created by the loaders own their parameter bundle (and, for cloud keysets, themselves)
+std::mutex g_mtx;
+std::set<const void *> g_owned_cloud, g_owned_secret;
+
+void put_cloud_payload(FILE *F, const TfheHipCloudKey &ck) { put_params(F, ck.p); put_vec(F, ck.bk); put_vec(F, ck.ksk); }
+TfheHipCloudKey *get_cloud_payload(FILE *F) {
+    auto *ck = new TfheHipCloudKey();
+    ck->p = get_params(F);
+    get_vec(F, ck->bk, ck->p.bk_words());
+    get_vec(F, ck->ksk, ck->p.ksk_words());
+    return ck;
+}
+uint64_t cloud_bytes(const Params &p) { return sizeof(ParamsRecord) + (p.bk_words() + p.ksk_words()) * sizeof(Torus32); }
+
+}  // namespace
+
+namespace tfhe_hip {
+// called by the delete_* functions of shim.cpp: true if the keyset came from a loader
+bool io_forget_owned_cloud(const void *ks) { std::lock_guard<std::mutex> g(g_mtx); return g_owned_cloud.erase(ks) != 0; }
+bool io_forget_owned_secret(const void *ks) { std::lock_guard<std::mutex> g(g_mtx); return g_owned_secret.erase(ks) != 0; }
+}  // namespace tfhe_hip
+
+extern "C" {
+
+void export_tfheGateBootstrappingParameterSet_toFile(FILE *F, const TFheGateBootstrappingParameterSet *params) {
+    put_header(F, KIND_PARAMS, sizeof(ParamsRecord));
+    put_params(F, params_of(params));
+}
+TFheGateBootstrappingParameterSet *new_tfheGateBootstrappingParameterSet_fromFile(FILE *F) {
+    get_header(F, KIND_PARAMS);
+    return &make_param_bundle(get_params(F))->set;
+}
+
+void export_tfheGateBootstrappingCloudKeySet_toFile(FILE *F, const TFheGateBootstrappingCloudKeySet *keyset) {
+    put_header(F, KIND_CLOUD, cloud_bytes(keyset->bk->p));
+    put_cloud_payload(F, *keyset->bk);
+}
+TFheGateBootstrappingCloudKeySet *new_tfheGateBootstrappingCloudKeySet_fromFile(FILE *F) {
+    get_header(F, KIND_CLOUD);
+    TfheHipCloudKey *ck = get_cloud_payload(F);
+    auto *ks = new TFheGateBootstrappingCloudKeySet();
+    ks->params = &make_param_bundle(ck->p)->set;
+    ks->bk = ck;
+    ks->bkFFT = ck;
+    std::lock_guard<std::mutex> g(g_mtx);
+    g_owned_cloud.insert(ks);
+    return ks;
+}
+
+void export_tfheGateBootstrappingSecretKeySet_toFile(FILE *F, const TFheGateBootstrappingSecretKeySet *keyset) {
+    const TfheHipSecretKey &sk = *keyset->lwe_key;
+    put_header(F, KIND_SECRET, cloud_bytes(sk.p) + (sk.lwe_key.size() + sk.tlwe_key.size()) * sizeof(int32_t));
+    put_cloud_payload(F, *keyset->cloud.bk);
+    put_vec(F, sk.lwe_key);
+    put_vec(F, sk.tlwe_key);
+}
+TFheGateBootstrappingSecretKeySet *new_tfheGateBootstrappingSecretKeySet_fromFile(FILE *F) {
+    get_header(F, KIND_SECRET);
+    TfheHipCloudKey *ck = get_cloud_payload(F);
+    auto *sk = new TfheHipSecretKey();
+    sk->p = ck->p;
+    get_vec(F, sk->lwe_key, (size_t)ck->p.n);
+    get_vec(F, sk->tlwe_key, (size_t)ck->p.k * ck->p.N);
+    auto *ks = new TFheGateBootstrappingSecretKeySet();
+    ks->params = &make_param_bundle(ck->p)->set;
+    ks->lwe_key = sk;
+    ks->tgsw_key = sk;
+    ks->cloud.params = ks->params;
+    ks->cloud.bk = ck;
+    ks->cloud.bkFFT = ck;
+    std::lock_guard<std::mutex> g(g_mtx);
+    g_owned_secret.insert(ks);
+    return ks;
+}
+
+void export_gate_bootstrapping_ciphertext_toFile(FILE *F, const LweSample *sample,
+                                                 const TFheGateBootstrappingParameterSet *params) {
+    const int32_t words = tfhe_hip_sample_words(params);
+    std::vector<Torus32> w((size_t)words);
+    if (tfhe_hip_export_samples(sample, 1, params, w.data()) != 0) fatal("tfhe_io: cannot read ciphertext");
+    put_header(F, KIND_SAMPLE, (uint64_t)words * sizeof(Torus32));
+    put_vec(F, w);
+}
+void import_gate_bootstrapping_ciphertext_fromFile(FILE *F, LweSample *sample,
+                                                   const TFheGateBootstrappingParameterSet *params) {
+    const int32_t words = tfhe_hip_sample_words(params);
+    if (get_header(F, KIND_SAMPLE) != (uint64_t)words * sizeof(Torus32)) fatal("tfhe_io: ciphertext of a different LWE dimension");
+    std::vector<Torus32> w;
+    get_vec(F, w, (size_t)words);
+    if (tfhe_hip_import_samples(sample, 1, params, w.data()) != 0) fatal("tfhe_io: cannot store ciphertext");
+}
+
+}  // extern "C"

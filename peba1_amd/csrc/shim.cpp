@@ -29,6 +29,8 @@ using namespace tfhe_hip;
 
 namespace tfhe_hip {
 const std::string &last_error_ref();
+bool io_forget_owned_cloud(const void *ks);     // io.cpp: keysets created by the file loaders
+bool io_forget_owned_secret(const void *ks);
 }
 
 namespace {
@@ -97,7 +99,9 @@ Recorder &rec() {
 
 SlotPool *pool_of_key(const TFheGateBootstrappingCloudKeySet *bk) {
     if (!bk || !bk->bk) fatal("null cloud key");
-    if (!bk->bk->dev) fatal("this keyset is host-only (no device key image); gates need the GPU");
+    // keysets made host-only or loaded from a file get their device image at first use
+    // (aborts with a clear message when there is no GPU: gates are never evaluated on the CPU)
+    if (!bk->bk->dev) bk->bk->dev = Engine::get().upload_key(*bk->bk);
     return Engine::get().pool_for(bk->bk->p);
 }
 
@@ -351,11 +355,23 @@ void delete_gate_bootstrapping_secret_keyset(TFheGateBootstrappingSecretKeySet *
         delete keyset->cloud.bk;
     }
     delete keyset->lwe_key;
+    if (io_forget_owned_secret(keyset)) delete_gate_bootstrapping_parameters(const_cast<TFheGateBootstrappingParameterSet *>(keyset->params));
     delete keyset;
 }
 
-void delete_gate_bootstrapping_cloud_keyset(TFheGateBootstrappingCloudKeySet *) {
-    // the cloud key is embedded in the secret keyset in this library (as at main.cpp:23); nothing to free
+void delete_gate_bootstrapping_cloud_keyset(TFheGateBootstrappingCloudKeySet *keyset) {
+    // A cloud keyset embedded in a secret keyset (&key->cloud, main.cpp:23) goes with its owner;
+    // only one created by new_tfheGateBootstrappingCloudKeySet_fromFile is released here.
+    if (!keyset || !io_forget_owned_cloud(keyset)) return;
+    Recorder &r = rec();
+    std::lock_guard<std::recursive_mutex> g(r.mtx);
+    if (r.key == keyset) { flush_locked(); r.key = nullptr; }
+    if (keyset->bk) {
+        Engine::get().free_key(keyset->bk->dev);
+        delete keyset->bk;
+    }
+    delete_gate_bootstrapping_parameters(const_cast<TFheGateBootstrappingParameterSet *>(keyset->params));
+    delete keyset;
 }
 
 LweSample *new_gate_bootstrapping_ciphertext_array(int32_t nbelems, const TFheGateBootstrappingParameterSet *params) {
@@ -681,18 +697,21 @@ int tfhe_hip_test_schedule(const int32_t *ops5, int32_t count, int32_t unit, int
 
 int tfhe_hip_kernel_negacyclic(const TFheGateBootstrappingCloudKeySet *bk, const int32_t *ip, const Torus32 *tp,
                                Torus32 *res, int32_t count) {
-    if (!bk || !bk->bk || !bk->bk->dev) { set_error("negacyclic: keyset has no device image"); return -1; }
+    if (!bk || !bk->bk) { set_error("negacyclic: null keyset"); return -1; }
+    pool_of_key(bk);
     Engine::get().run_negacyclic(bk->bk->dev, ip, tp, res, count);
     return 0;
 }
 int tfhe_hip_kernel_bootstrap_woks(const TFheGateBootstrappingCloudKeySet *bk, const Torus32 *lin, int32_t count,
                                    Torus32 *u_out, Torus32 *acc_out) {
-    if (!bk || !bk->bk || !bk->bk->dev) { set_error("bootstrap_woks: keyset has no device image"); return -1; }
+    if (!bk || !bk->bk) { set_error("bootstrap_woks: null keyset"); return -1; }
+    pool_of_key(bk);
     Engine::get().run_bootstrap_woks(bk->bk->dev, lin, count, u_out, acc_out);
     return 0;
 }
 int tfhe_hip_kernel_keyswitch(const TFheGateBootstrappingCloudKeySet *bk, const Torus32 *u, int32_t count, Torus32 *out) {
-    if (!bk || !bk->bk || !bk->bk->dev) { set_error("keyswitch: keyset has no device image"); return -1; }
+    if (!bk || !bk->bk) { set_error("keyswitch: null keyset"); return -1; }
+    pool_of_key(bk);
     Engine::get().run_keyswitch(bk->bk->dev, u, count, out);
     return 0;
 }

@@ -78,6 +78,14 @@ SIGNATURES = {
     "bootsSymDecrypt": (C.c_int32, [LS, SK]),
     "modSwitchFromTorus32": (C.c_int32, [C.c_int32, C.c_int32]),
     "modSwitchToTorus32": (C.c_int32, [C.c_int32, C.c_int32]),
+    "export_tfheGateBootstrappingParameterSet_toFile": (None, [C.c_void_p, PS]),
+    "new_tfheGateBootstrappingParameterSet_fromFile": (PS, [C.c_void_p]),
+    "export_tfheGateBootstrappingCloudKeySet_toFile": (None, [C.c_void_p, CK]),
+    "new_tfheGateBootstrappingCloudKeySet_fromFile": (CK, [C.c_void_p]),
+    "export_tfheGateBootstrappingSecretKeySet_toFile": (None, [C.c_void_p, SK]),
+    "new_tfheGateBootstrappingSecretKeySet_fromFile": (SK, [C.c_void_p]),
+    "export_gate_bootstrapping_ciphertext_toFile": (None, [C.c_void_p, LS, PS]),
+    "import_gate_bootstrapping_ciphertext_fromFile": (None, [C.c_void_p, LS, PS]),
     "tfhe_hip_last_error": (C.c_char_p, []),
     "tfhe_hip_clear_error": (None, []),
     "tfhe_hip_set_device": (C.c_int, [C.c_int]),

@@ -273,3 +273,45 @@ def test_random_gate_sweep_matches_oracle(p128_keys, oracle):
         got = R.words()
         want = oks.gate_batch(name, wx[ia], wx[ib], nthreads=16)
         assert (got == want).all(), name
+
+
+def test_server_side_evaluation_from_files(p128_keys, oracle, tmp_path):
+    """the client writes the cloud keyset and ciphertexts, the evaluating side
+    loads only those (no secret key), and the result file decrypts and matches the oracle."""
+    from peba1_amd import api, lib
+    pp, ks, oks = p128_keys
+    L = lib.load()
+    L.tfhe_hip_set_encrypt_seed(77)
+    abits, bbits = [0, 1, 1, 0, 1, 0], [1, 1, 0, 0, 1, 0]
+    a = api.CiphertextArray(pp, 6).encrypt(abits, ks)
+    b = api.CiphertextArray(pp, 6).encrypt(bbits, ks)
+    wa, wb = a.words(), b.words()
+    ks.save_cloud(tmp_path / "cloud.key")
+    a.save(tmp_path / "a.ct")
+    b.save(tmp_path / "b.ct")
+
+    cloud = api.CloudKeySet.load(tmp_path / "cloud.key")        # device image built at first gate
+    assert cloud.params.n == pp.n and cloud.params.N == pp.N
+    sa = api.CiphertextArray(cloud.params, 6).load(tmp_path / "a.ct")
+    sb = api.CiphertextArray(cloud.params, 6).load(tmp_path / "b.ct")
+    res = api.CiphertextArray(cloud.params, 6)
+    api.set_deferred(True)
+    try:
+        for i in range(6):
+            L.bootsXOR(res.at(i), sa.at(i), sb.at(i), cloud.cloud)
+            L.bootsAND(res.at(i), res.at(i), sa.at(i), cloud.cloud)
+        res.save(tmp_path / "res.ct")                            # flushes what feeds the samples
+    finally:
+        api.set_deferred(False)
+    sa.close(); sb.close(); res.close()
+    cloud.close()
+
+    back = api.CiphertextArray(pp, 6).load(tmp_path / "res.ct")
+    got = back.words()
+    for i in range(6):
+        want = oks.gate("AND", oks.gate("XOR", wa[i], wb[i]), wa[i])
+        assert (got[i] == want).all(), i
+    assert back.decrypt(ks).tolist() == [(x ^ y) & x for x, y in zip(abits, bbits)]
+    # the session keyset still works after the loaded one is released
+    api.gate_batch("OR", back, a, b, ks)
+    assert back.decrypt(ks).tolist() == [x | y for x, y in zip(abits, bbits)]

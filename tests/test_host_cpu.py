@@ -154,7 +154,7 @@ def test_product_modswitch_helpers(oracle):
 def _declared_symbols(header):
     txt = open(os.path.join(ROOT, "include", header)).read()
     txt = re.sub(r"/\*.*?\*/", "", txt, flags=re.S)
-    return set(re.findall(r"\b((?:boots|new_|delete_|tfhe_hip_|modSwitch|peba1_)\w*)\s*\(", txt))
+    return set(re.findall(r"\b((?:boots|new_|delete_|export_|import_|tfhe_hip_|modSwitch|peba1_)\w*)\s*\(", txt))
 
 
 def _exported(so):
@@ -166,7 +166,8 @@ def test_libtfhe_hip_exports_every_declared_symbol():
     from peba1_amd import lib
     lib.load()                                                # also binds every entry of lib.SIGNATURES
     declared = (_declared_symbols("tfhe/tfhe_gate_bootstrapping_functions.h") | _declared_symbols("tfhe_hip.h")
-                | _declared_symbols("tfhe/tfhe_core.h"))
+                | _declared_symbols("tfhe/tfhe_core.h") | _declared_symbols("tfhe/tfhe_io.h"))
+    assert len(_declared_symbols("tfhe/tfhe_io.h")) == 8
     missing = declared - _exported("libtfhe-hip.so")
     assert not missing, missing
     # the 16 symbols the reference's objects import

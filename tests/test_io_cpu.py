@@ -1,0 +1,80 @@
+"""tfhe_io.h entry points: parameter / key / ciphertext files round-trip
+bit-exactly, a foreign file is refused.  No GPU: loaded keysets build their device image at
+the first gate only."""
+import ctypes as C
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+from peba1_amd import api
+
+
+@pytest.fixture(scope="module")
+def small_key():
+    params = api.ParameterSet(custom=(32, 1024, 1, 2, 8, 4, 2, 2.0 ** -30, 2.0 ** -40, 2.0 ** -6))
+    return params, api.SecretKeySet(params, 0xF11E, device=False)
+
+
+def test_parameter_set_roundtrip(tmp_path):
+    for ps in (api.ParameterSet(128), api.ParameterSet(80), api.ParameterSet(p2048=True)):
+        ps.save(tmp_path / "p.bin")
+        q = api.ParameterSet.load(tmp_path / "p.bin")
+        assert (q.n, q.N, q.k, q.l, q.Bgbit, q.ks_t, q.ks_basebit) == (ps.n, ps.N, ps.k, ps.l, ps.Bgbit, ps.ks_t, ps.ks_basebit)
+        a, b = ps.ptr.contents, q.ptr.contents
+        assert a.in_out_params.contents.alpha_min == b.in_out_params.contents.alpha_min
+        assert a.tgsw_params.contents.tlwe_params.contents.alpha_min == b.tgsw_params.contents.tlwe_params.contents.alpha_min
+
+
+def test_secret_and_cloud_keyset_roundtrip(small_key, tmp_path):
+    params, key = small_key
+    key.save(tmp_path / "secret.key")
+    key.save_cloud(tmp_path / "cloud.key")
+    sk = api.SecretKeySet.load(tmp_path / "secret.key")
+    ck = api.CloudKeySet.load(tmp_path / "cloud.key")
+    assert np.array_equal(sk.lwe_key(), key.lwe_key())
+    assert np.array_equal(sk.tlwe_key(), key.tlwe_key())
+    for k2 in (sk, ck):
+        assert np.array_equal(k2.bk(), key.bk())
+        assert np.array_equal(k2.ksk(), key.ksk())
+        assert k2.params.n == params.n and k2.params.N == params.N
+    # the cloud file is the secret file minus the two secret vectors
+    assert (tmp_path / "secret.key").stat().st_size - (tmp_path / "cloud.key").stat().st_size == 4 * (params.n + params.N)
+    with pytest.raises(TypeError):
+        ck.lwe_key()
+    # a ciphertext made under the original key decrypts under the reloaded one
+    ct = api.CiphertextArray(params, 8).encrypt([1, 0, 1, 1, 0, 0, 1, 0], key)
+    assert ct.decrypt(sk).tolist() == [1, 0, 1, 1, 0, 0, 1, 0]
+    ck.save(tmp_path / "cloud2.key")
+    assert (tmp_path / "cloud2.key").read_bytes() == (tmp_path / "cloud.key").read_bytes()
+    sk.close()
+    ck.close()
+
+
+def test_ciphertext_roundtrip(small_key, tmp_path):
+    params, key = small_key
+    bits = [1, 0, 0, 1, 1]
+    ct = api.CiphertextArray(params, len(bits)).encrypt(bits, key)
+    ct.save(tmp_path / "ct.bin")
+    assert (tmp_path / "ct.bin").stat().st_size == len(bits) * (24 + 4 * params.words)
+    back = api.CiphertextArray(params, len(bits)).load(tmp_path / "ct.bin")
+    assert np.array_equal(back.words(), ct.words())
+    assert back.decrypt(key).tolist() == bits
+
+
+def test_foreign_or_truncated_file_is_refused(small_key, tmp_path):
+    """fatal conditions abort with a message (the gate API returns void, as upstream)."""
+    params, key = small_key
+    key.save_cloud(tmp_path / "cloud.key")
+    blob = (tmp_path / "cloud.key").read_bytes()
+    (tmp_path / "foreign.key").write_bytes(b"\x00" * 64)
+    (tmp_path / "short.key").write_bytes(blob[: len(blob) // 2])
+    (tmp_path / "params.bin").write_bytes(blob)      # a cloud key where a parameter set is expected
+    for name, loader, needle in (("foreign.key", "CloudKeySet", "not a libtfhe-hip file"),
+                                 ("short.key", "CloudKeySet", "short read"),
+                                 ("params.bin", "ParameterSet", "expected 1")):
+        r = subprocess.run([sys.executable, "-c",
+                            "from peba1_amd import api; api.%s.load(%r)" % (loader, str(tmp_path / name))],
+                           capture_output=True, text=True)
+        assert r.returncode != 0 and needle in r.stderr, (name, r.stderr[-300:])

@@ -16,7 +16,8 @@ WIDE_STREAM = ("blind_rotate_kernel", "blind_rotate4_kernel", "keyswitch_kernel"
 
 def short(name):
     base = name.replace("(anonymous namespace)::", "").split("(")[0]
-    return base.split("::")[-1]
+    base = base.split("<")[0]                      # template arguments (kernel<10>)
+    return base.split("::")[-1].split()[-1]        # "void ns::kernel" -> "kernel"
 
 
 def collect(path, counter):
