@@ -89,6 +89,9 @@ int tfhe_hip_gate_batch(int gate, LweSample *result, const LweSample *a, const L
  * "ks_target_blocks": a launch's key switches are each cut into 2^s <= 32 ranges of
  * input coefficients until about this many workgroups exist (default 32768, env
  * TFHE_HIP_KS_BLOCKS); 0 disables splitting.
+ * "ks_tile": 16 (default) or 32 = launches of at least 2*tile key switches use the tiled
+ * kernel (a workgroup streams the KSK rows of one range once for `tile` gates); 0 = always
+ * one workgroup per (gate, range); env TFHE_HIP_KS_TILE.
  * "balance_levels": 1 (default) = slack-aware level filling at flush, 0 = plain ASAP
  * levels.
  * "dataflow": 0 (default) = one blind-rotate + one key-switch launch per level; 1 (env

@@ -1,6 +1,7 @@
 // engine.cpp -- device memory, key upload and batched level execution.
 #include "engine.hpp"
 
+#include <algorithm>
 #include <chrono>
 #include <ctime>
 #include <unistd.h>
@@ -79,6 +80,7 @@ void Engine::ensure_init() {
     if (const char *env = std::getenv("TFHE_HIP_BR4_MAX")) br4_max_rotations = std::atoi(env);
     if (const char *env = std::getenv("TFHE_HIP_KS_BLOCKS")) ks_target_blocks = std::atoi(env);
     if (const char *env = std::getenv("TFHE_HIP_KS_MAX_SPLITS")) ks_max_splits = std::atoi(env);
+    if (const char *env = std::getenv("TFHE_HIP_KS_TILE")) ks_tile = std::atoi(env);
     hip_check(hipSetDevice(device_), "hipSetDevice");
     {
         hipDeviceProp_t prop;
@@ -271,11 +273,21 @@ void Engine::launch_br(const DeviceKeyImage *key, const int32_t *pool, const Rot
 
 void Engine::launch_ks(const DeviceKeyImage *key, const int32_t *u_buf, const KsDesc *descs, int count, int32_t *pool) {
     if (count <= 0) return;
-    int splits = 1;
-    while (splits < ks_max_splits && count * splits * 2 <= ks_target_blocks) splits *= 2;
-    int32_t *partial = nullptr;
-    if (splits > 1) partial = static_cast<int32_t *>(scratch(10, (size_t)count * splits * key->dp.ct_stride * 4));
-    launch_keyswitch(stream_, key->dp, key->key, u_buf, descs, count, pool, splits, partial);
+    const DevParams &dp = key->dp;
+    const int nin = dp.k * dp.N;
+    // tiled kernel: wide launches, ranges of at most 64 input coefficients
+    const bool tiled = ks_tile > 0 && count >= 2 * ks_tile && dp.ks_t == 8 && dp.ks_basebit == 2 && ks_max_splits > 1 &&
+                       (nin + ks_max_splits - 1) / ks_max_splits <= 64;
+    const int chunk = tiled ? 8192 : count;              // bounds the partial-sum buffer (0.66 GB at P128)
+    for (int done = 0; done < count; done += chunk) {
+        const int cnt = std::min(chunk, count - done);
+        int splits = 1;
+        if (tiled && cnt >= 2 * ks_tile) splits = ks_max_splits;
+        else while (splits < ks_max_splits && cnt * splits * 2 <= ks_target_blocks) splits *= 2;
+        int32_t *partial = nullptr;
+        if (splits > 1) partial = static_cast<int32_t *>(scratch(10, (size_t)cnt * splits * dp.ct_stride * 4));
+        launch_keyswitch(stream_, dp, key->key, u_buf, descs + done, cnt, pool, splits, partial, tiled ? ks_tile : 0);
+    }
 }
 
 void Engine::execute(const DeviceKeyImage *key, SlotPool *pool, const LevelPlan &plan) {

@@ -99,6 +99,8 @@ public:
     // KSK sub-table small enough for an XCD's L2 (measured optimum: 32 splits)
     int ks_target_blocks = 32768;
     int ks_max_splits = 32;
+    // gates per workgroup of the tiled key switch (16 or 32; 0 = per-gate kernel only)
+    int ks_tile = 16;
     void launch_ks(const DeviceKeyImage *key, const int32_t *u_buf, const KsDesc *descs, int count, int32_t *pool);
     void launch_br(const DeviceKeyImage *key, const int32_t *pool, const RotDesc *rots, int count, int32_t *u_buf,
                    int32_t *acc_dbg);

@@ -703,6 +703,103 @@ __global__ __launch_bounds__(KS_MAX_THREADS) void ks_reduce_kernel(DevParams p, 
     reinterpret_cast<uint4 *>(pool + (size_t)descs[blockIdx.x].dst_slot * p.ct_stride)[tid] = acc;
 }
 
+// Tiled form for wide launches.  grid (ceil(gates / G), splits), THREADS = ct_stride/4 rounded
+// up to a wave.  A workgroup key-switches G gates over one range of input coefficients:
+// it streams the range's KSK rows ONCE (12 rows = four digit positions of one coefficient
+// per stage, prefetched a stage ahead) and applies each row to every gate of the tile
+// whose digit selects it.  The per-gate form above fetches 15.5 MB of rows per gate (from
+// L2, which is what bounds it); here the fetch is shared by G gates.  A thread only ever
+// needs its own 16-byte column of a row, so the staged rows sit in a thread-private LDS
+// strip (LDS because the row is picked by a run-time digit) and the stage loop has no
+// barrier.  Strips are laid out [digit position][digit 0..3]; digit 0 is a strip of zeros,
+// so the inner loop is branch-free (address = digit bits, one 16-byte LDS read, four
+// subtractions) and the reads of a stage can be in flight together.  Digits come from one
+// LDS word per (gate, coefficient), the same for all lanes.  Needs ks_t = 8,
+// ks_basebit = 2 (every built-in parameter set) and at most 64 coefficients per range;
+// partial sums go through ks_reduce_kernel as above.
+template <int THREADS, int G>
+__global__ __launch_bounds__(THREADS) void keyswitch_tile_kernel(DevParams p, DevKey key, const int32_t *__restrict__ u_buf,
+                                                              const KsDesc *__restrict__ descs, int count,
+                                                              int32_t *__restrict__ partial) {
+    constexpr int JB = 4, ROWS = JB * 3, MAXR = 64;
+    __shared__ uint4 rows[JB * 4 * THREADS];
+    __shared__ uint32_t su[G][MAXR];
+    __shared__ uint32_t sbody[G];
+    const int tid = threadIdx.x;
+    const int nin = p.k * p.N;
+    const int splits = gridDim.y, split = blockIdx.y;
+    const int i0 = (int)((long long)nin * split / splits), i1 = (int)((long long)nin * (split + 1) / splits);
+    const int range = i1 - i0;
+    const int g0 = blockIdx.x * G;
+    for (int e = tid; e < G * range; e += THREADS) {
+        const int g = e / range, ii = e - g * range;
+        uint32_t v = 0;                                  // gates past the end: every digit 0
+        if (g0 + g < count) {
+            const KsDesc d = descs[g0 + g];
+            v = (uint32_t)u_buf[(size_t)d.u0 * p.u_stride + i0 + ii] + p.ks_prec_offset;
+            if (d.u1 >= 0) v += (uint32_t)u_buf[(size_t)d.u1 * p.u_stride + i0 + ii];
+        }
+        su[g][ii] = v;
+    }
+    if (tid < G && g0 + tid < count) {
+        const KsDesc d = descs[g0 + tid];
+        uint32_t b = (uint32_t)u_buf[(size_t)d.u0 * p.u_stride + nin] + (uint32_t)d.add_b;
+        if (d.u1 >= 0) b += (uint32_t)u_buf[(size_t)d.u1 * p.u_stride + nin];
+        sbody[tid] = b;
+    }
+#pragma unroll
+    for (int jj = 0; jj < JB; ++jj) rows[(jj * 4) * THREADS + tid] = make_uint4(0, 0, 0, 0);
+    __syncthreads();
+    const int nvec = p.ct_stride >> 2;
+    if (tid >= nvec) return;                             // no barrier below
+    const uint4 *ksk = reinterpret_cast<const uint4 *>(key.ksk) + tid;
+    uint4 acc[G];
+#pragma unroll
+    for (int g = 0; g < G; ++g) acc[g] = make_uint4(0, 0, 0, 0);
+    const int nst = range * 2;                           // stage = (coefficient, half of its 8 digits)
+    const uint4 *src = ksk + (size_t)(i0 * 8) * 3 * nvec;
+#pragma unroll
+    for (int r = 0; r < ROWS; ++r) rows[(r / 3 * 4 + r % 3 + 1) * THREADS + tid] = src[(size_t)r * nvec];
+    const uint4 *strip = rows + tid;
+    for (int st = 0; st < nst; ++st) {
+        // next stage's rows: loads issued before this stage's arithmetic, stored after it
+        // (the strip is private to the thread and a wave's LDS operations stay in order).
+        // Unconditional, the last stage re-reads itself: a conditional load keeps the array
+        // in scratch memory with this compiler.
+        uint4 pre[ROWS];
+        if (st + 1 < nst) src += (size_t)ROWS * nvec;
+#pragma unroll
+        for (int r = 0; r < ROWS; ++r) pre[r] = src[(size_t)r * nvec];
+        const int ii = st >> 1;
+        const int sh0 = 24 - 8 * (st & 1);               // digit j sits at bits [31-2j, 30-2j]
+#pragma unroll
+        for (int g = 0; g < G; ++g) {
+            const uint32_t x = su[g][ii] >> sh0;         // this stage's four digits in the low byte
+#pragma unroll
+            for (int jj = 0; jj < JB; ++jj) {
+                const uint32_t d = (x >> (6 - 2 * jj)) & 3u;
+                const uint4 row = strip[(jj * 4 + (int)d) * THREADS];
+                acc[g].x -= row.x; acc[g].y -= row.y; acc[g].z -= row.z; acc[g].w -= row.w;
+            }
+        }
+#pragma unroll
+        for (int r = 0; r < ROWS; ++r) rows[(r / 3 * 4 + r % 3 + 1) * THREADS + tid] = pre[r];
+    }
+#pragma unroll
+    for (int g = 0; g < G; ++g) {
+        if (g0 + g >= count) break;
+        uint32_t o[4] = {acc[g].x, acc[g].y, acc[g].z, acc[g].w};
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const int wi = 4 * tid + e;
+            if (wi == p.n && split == 0) o[e] += sbody[g];
+            if (wi > p.n) o[e] = 0;
+        }
+        reinterpret_cast<uint4 *>(partial + ((size_t)(g0 + g) * splits + split) * p.ct_stride)[tid] =
+            make_uint4(o[0], o[1], o[2], o[3]);
+    }
+}
+
 // K5: bootsNOT
 __global__ __launch_bounds__(256) void not_kernel(DevParams p, const NotDesc *__restrict__ descs, int32_t *__restrict__ pool) {
     const NotDesc d = descs[blockIdx.x];
@@ -786,14 +883,28 @@ void launch_gate_dataflow(hipStream_t s, const DevParams &p, const DevKey &key, 
 }
 
 void launch_keyswitch(hipStream_t s, const DevParams &p, const DevKey &key, const int32_t *u_buf,
-                      const KsDesc *descs, int count, int32_t *pool, int splits, int32_t *partial) {
+                      const KsDesc *descs, int count, int32_t *pool, int splits, int32_t *partial, int tile) {
     if (count <= 0) return;
     const int threads = ((p.ct_stride / 4 + 63) / 64) * 64;      // one 16-byte lane per 4 output words
     if (splits <= 1 || !partial) {
         hipLaunchKernelGGL(keyswitch_kernel, dim3(count, 1), dim3(threads), 0, s, p, key, u_buf, descs, pool, nullptr);
         return;
     }
-    hipLaunchKernelGGL(keyswitch_kernel, dim3(count, splits), dim3(threads), 0, s, p, key, u_buf, descs, pool, partial);
+    const int range = (p.k * p.N + splits - 1) / splits;
+    if (tile > 0 && count >= 2 * tile && p.ks_t == 8 && p.ks_basebit == 2 && range <= 64 && (tile == 16 || tile == 32)) {
+        const dim3 grid((count + tile - 1) / tile, splits);
+#define KS_TILE(T, GT) hipLaunchKernelGGL((keyswitch_tile_kernel<T, GT>), grid, dim3(T), 0, s, p, key, u_buf, descs, count, partial)
+        if (tile == 16) {
+            if (threads == 128) KS_TILE(128, 16); else if (threads == 192) KS_TILE(192, 16); else if (threads == 320) KS_TILE(320, 16); else tile = 0;
+        } else {
+            if (threads == 128) KS_TILE(128, 32); else if (threads == 192) KS_TILE(192, 32); else if (threads == 320) KS_TILE(320, 32); else tile = 0;
+        }
+#undef KS_TILE
+    } else {
+        tile = 0;
+    }
+    if (tile == 0)
+        hipLaunchKernelGGL(keyswitch_kernel, dim3(count, splits), dim3(threads), 0, s, p, key, u_buf, descs, pool, partial);
     hipLaunchKernelGGL(ks_reduce_kernel, dim3(count), dim3(threads), 0, s, p, descs, splits, partial, pool);
 }
 

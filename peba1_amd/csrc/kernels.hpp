@@ -63,9 +63,11 @@ void launch_blind_rotate(hipStream_t s, const DevParams &p, const DevKey &key, c
 void launch_blind_rotate4(hipStream_t s, const DevParams &p, const DevKey &key, const int32_t *pool,
                           const RotDesc *rots, int count, int32_t *u_buf, int32_t *acc_dbg);
 // splits > 1: each gate's key switch is cut into `splits` ranges of input coefficients
-// (partial sums in `partial[count][splits][ct_stride]`, then a reduce launch)
+// (partial sums in `partial[count][splits][ct_stride]`, then a reduce launch).  tile = 16 or
+// 32: launches of at least 2*tile gates use the tiled kernel (one pass over the KSK rows of
+// a range serves `tile` gates); 0 = always one workgroup per (gate, range)
 void launch_keyswitch(hipStream_t s, const DevParams &p, const DevKey &key, const int32_t *u_buf,
-                      const KsDesc *descs, int count, int32_t *pool, int splits, int32_t *partial);
+                      const KsDesc *descs, int count, int32_t *pool, int splits, int32_t *partial, int tile);
 void launch_not(hipStream_t s, const DevParams &p, const NotDesc *descs, int count, int32_t *pool);
 // res[c] = ip[c] * (poly whose image is img[c]) through the device NTT
 void launch_negacyclic(hipStream_t s, const DevParams &p, const uint32_t *tw, const int32_t *ip,

@@ -663,6 +663,11 @@ int tfhe_hip_gate_batch(int gate, LweSample *result, const LweSample *a, const L
 int tfhe_hip_set_tuning(const char *name, int64_t value) {
     if (name && std::strcmp(name, "br4_max_rotations") == 0) { Engine::get().br4_max_rotations = (int)value; return 0; }
     if (name && std::strcmp(name, "ks_target_blocks") == 0) { Engine::get().ks_target_blocks = (int)value; return 0; }
+    if (name && std::strcmp(name, "ks_tile") == 0) {
+        if (value != 0 && value != 16 && value != 32) { set_error("ks_tile must be 0, 16 or 32"); return -1; }
+        Engine::get().ks_tile = (int)value;
+        return 0;
+    }
     if (name && std::strcmp(name, "balance_levels") == 0) { rec().balance_levels = value != 0; return 0; }
     if (name && std::strcmp(name, "dataflow") == 0) { rec().dataflow = value != 0; return 0; }
     set_error(std::string("tfhe_hip_set_tuning: unknown name ") + (name ? name : "(null)"));

@@ -104,6 +104,29 @@ def test_keyswitch_matches_oracle(p128_keys, oracle, ks_blocks):
         assert (got[c] == oks.keyswitch(u[c])).all(), f"sample {c}"
 
 
+@pytest.mark.parametrize("tile,count", [(16, 32), (16, 45), (32, 64), (32, 77)])
+def test_tiled_keyswitch_matches_oracle(p128_keys, oracle, tile, count):
+    """a17, wide launches: one pass over a range's KSK rows serves a tile of gates; full and
+    ragged last tiles, all-zero and all-three digits, against the oracle and the per-gate kernel."""
+    from peba1_amd import api
+    pp, ks, oks = p128_keys
+    rng = np.random.default_rng(1000 + count)
+    u = rng.integers(-2**31, 2**31, (count, pp.N + 1), dtype=np.int64).astype(np.int32)
+    u[0, :] = 0
+    u[1, :-1] = -1
+    u[count - 1, :-1] = 0x40000000   # digit 1 at the first position only
+    api.set_tuning("ks_tile", tile)
+    try:
+        got = api.kernel_keyswitch(ks, u)
+        api.set_tuning("ks_tile", 0)
+        per_gate = api.kernel_keyswitch(ks, u)
+    finally:
+        api.set_tuning("ks_tile", 16)
+    assert (got == per_gate).all()
+    for c in list(range(4)) + [count // 2, count - 2, count - 1]:
+        assert (got[c] == oks.keyswitch(u[c])).all(), f"sample {c}"
+
+
 # ---------------------------------------------------------------- BASELINE configs[4]: N = 2048
 @pytest.fixture(scope="module")
 def p2048_keys(oracle):
@@ -138,6 +161,11 @@ def test_p2048_negacyclic_and_gates(p2048_keys, oracle):
     assert (acc[0] == want_acc).all()
     assert (u[0] == oks.sample_extract(want_acc)).all()
     assert (api.kernel_keyswitch(ks, u)[0] == oks.keyswitch(u[0])).all()
+    # wide launch: tiled key switch (320 threads, ranges of 64 coefficients)
+    uw = rng.integers(-2**31, 2**31, (40, 2048 + 1), dtype=np.int64).astype(np.int32)
+    gw = api.kernel_keyswitch(ks, uw)
+    for c in (0, 17, 39):
+        assert (gw[c] == oks.keyswitch(uw[c])).all(), c
     # gates through the public API
     L = lib.load()
     L.tfhe_hip_set_encrypt_seed(9)
@@ -151,3 +179,57 @@ def test_p2048_negacyclic_and_gates(p2048_keys, oracle):
     m = api.CiphertextArray(pp, 1)
     L.bootsMUX(m.at(0), a.at(2), b.at(1), b.at(0), ks.cloud)
     assert (m.words()[0] == oks.mux(wa[2], wb[1], wb[0])).all() and m.decrypt(ks)[0] == 1
+
+
+# ---------------------------------------------------------------- the lambda<=80 set (n=500, l=2, Bg=2^10)
+def test_p80_blind_rotate_keyswitch_and_gates(oracle):
+    """new_default_gate_bootstrapping_parameters(80): gadget length and base are run-time
+    values in the kernels; the widest digits (|d| <= 512) stay inside the two-prime bound."""
+    from peba1_amd import api, lib
+    seed = 0x80
+    pp = api.ParameterSet(80)
+    assert (pp.n, pp.N, pp.l, pp.Bgbit) == (500, 1024, 2, 10)
+    ks = api.SecretKeySet(pp, seed, device=True)
+    oks = oracle.KeySet(oracle.params("P80"), seed)
+    try:
+        assert (ks.bk() == oks.bk()).all() and (ks.ksk() == oks.ksk()).all()
+        rng = np.random.default_rng(80)
+        ip = rng.integers(-512, 512, (2, 1024), dtype=np.int64).astype(np.int32)
+        tp = rng.integers(-2**31, 2**31, (2, 1024), dtype=np.int64).astype(np.int32)
+        ip[0, :] = -512; tp[0, :] = -2**31
+        got = api.kernel_negacyclic(ks, ip, tp)
+        for c in range(2):
+            assert (got[c] == oracle.negacyclic(ip[c], tp[c], ntt=False)).all(), c
+        r = oracle.Rng(6)
+        cts = oks.encrypt(r, [1, 1, 0])
+        lin = np.stack([oks.prelude("AND", cts[0], cts[1]), oks.prelude("XNOR", cts[1], cts[2])])
+        u, acc = api.kernel_bootstrap_woks(ks, lin, want_acc=True)
+        for c in range(2):
+            bar = oks.modswitch_ct(lin[c])
+            want_acc = oks.blind_rotate(bar[:-1], bar[-1])
+            assert (acc[c] == want_acc).all(), c
+            assert (u[c] == oks.sample_extract(want_acc)).all(), c
+        ksw = api.kernel_keyswitch(ks, u)
+        for c in range(2):
+            assert (ksw[c] == oks.keyswitch(u[c])).all(), c
+        uw = rng.integers(-2**31, 2**31, (35, 1024 + 1), dtype=np.int64).astype(np.int32)   # tiled kernel, 128 threads
+        gw = api.kernel_keyswitch(ks, uw)
+        for c in (0, 16, 34):
+            assert (gw[c] == oks.keyswitch(uw[c])).all(), c
+        L = lib.load()
+        L.tfhe_hip_set_encrypt_seed(8)
+        a = api.CiphertextArray(pp, 4).encrypt([0, 0, 1, 1], ks)
+        b = api.CiphertextArray(pp, 4).encrypt([0, 1, 0, 1], ks)
+        res = api.CiphertextArray(pp, 4)
+        wa, wb = a.words(), b.words()
+        for name, want in (("XOR", [0, 1, 1, 0]), ("OR", [0, 1, 1, 1])):
+            api.gate_batch(name, res, a, b, ks)
+            got = res.words()
+            for i in range(4):
+                assert (got[i] == oks.gate(name, wa[i], wb[i])).all(), (name, i)
+            assert list(res.decrypt(ks)) == want
+        m = api.CiphertextArray(pp, 1)
+        L.bootsMUX(m.at(0), a.at(1), b.at(1), b.at(0), ks.cloud)
+        assert (m.words()[0] == oks.mux(wa[1], wb[1], wb[0])).all() and m.decrypt(ks)[0] == 0
+    finally:
+        ks.close()
