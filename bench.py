@@ -232,6 +232,19 @@ def main():
             assert int(rbh.decrypt(ks)[0]) == (1 if bin(ta ^ tb).count("1") > 40 else 0)
             out["hamming128_match"] = {"match_ms": th * 1e3, "blind_rotates": int(sh["blind_rotates"]),
                                        "levels": int(sh["levels"]), "gates_per_s": sh["blind_rotates"] / th}
+        if world == 1 and args.batched_extra > 0:
+            # extra: the same match through the optimised DAG (peba1_function_f_fast; not the
+            # reference's gate sequence) -- same match bit, fewer and shallower gates
+            api.reset_stats()
+            tf = time.perf_counter()
+            rbf = api.CiphertextArray(pp, 3 * bitsize)
+            circuits.function_f_fast(rbf, probe, tmpl, bound, bitsize, ks)
+            api.flush()
+            tf = time.perf_counter() - tf
+            sf = api.stats()
+            assert int(rbf.decrypt(ks)[0]) == bit
+            out["optimised_dag_match"] = {"match_ms": tf * 1e3, "blind_rotates": int(sf["blind_rotates"]),
+                                          "levels": int(sf["levels"]), "gates_per_s": sf["blind_rotates"] / tf}
         if world == 1 and not args.no_cpu_baseline:
             api.set_deferred(False)
             out["cpu_baseline"] = cpu_baseline(seed)

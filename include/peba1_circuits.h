@@ -57,6 +57,17 @@ void peba1_function_f(LweSample *result_b, LweSample *const *a, LweSample *const
 void peba1_function_g(LweSample *result, LweSample *result_b, LweSample *r0, LweSample *r1, int bitsize,
                       const TFheGateBootstrappingCloudKeySet *ck);
 
+/* Optimised variants -- NOT the reference's gate sequence: the same inputs
+ * and the same decrypted outputs through a different, much smaller and shallower DAG
+ * (|a-b| by borrow chain, squarer partial products, one carry-save column compressor for all
+ * slots, parallel-prefix adder and comparator; circuits_fast.cpp).  128 slots x 8 bit: about
+ * 27,000 bootstraps at depth about 75 instead of 215,544 at depth 377.  result / result_b
+ * have 3*bitsize samples; arithmetic modulo 2^(3*bitsize) as in the reference. */
+void peba1_euclidean_distance_fast(LweSample *result, LweSample *const *a, LweSample *const *b, int nslots,
+                                   int bitsize, const TFheGateBootstrappingCloudKeySet *ck);
+void peba1_function_f_fast(LweSample *result_b, LweSample *const *a, LweSample *const *b, int nslots,
+                           LweSample *bound_match, int bitsize, const TFheGateBootstrappingCloudKeySet *ck);
+
 /* Slot-sharded variant of the distance for multi-GPU runs: the
  * partial sum of squares over slots [0, nslots) of this rank, 24 samples, with
  * the accumulator explicitly zeroed first. */

@@ -84,6 +84,12 @@ void bootsAND(LweSample *r, const LweSample *a, const LweSample *b, const TFheGa
 void bootsOR(LweSample *r, const LweSample *a, const LweSample *b, const TFheGateBootstrappingCloudKeySet *k) { (void)k; gate2(ORC_OR, r, a, b); }
 void bootsXOR(LweSample *r, const LweSample *a, const LweSample *b, const TFheGateBootstrappingCloudKeySet *k) { (void)k; gate2(ORC_XOR, r, a, b); }
 void bootsXNOR(LweSample *r, const LweSample *a, const LweSample *b, const TFheGateBootstrappingCloudKeySet *k) { (void)k; gate2(ORC_XNOR, r, a, b); }
+void bootsNAND(LweSample *r, const LweSample *a, const LweSample *b, const TFheGateBootstrappingCloudKeySet *k) { (void)k; gate2(ORC_NAND, r, a, b); }
+void bootsNOR(LweSample *r, const LweSample *a, const LweSample *b, const TFheGateBootstrappingCloudKeySet *k) { (void)k; gate2(ORC_NOR, r, a, b); }
+void bootsANDNY(LweSample *r, const LweSample *a, const LweSample *b, const TFheGateBootstrappingCloudKeySet *k) { (void)k; gate2(ORC_ANDNY, r, a, b); }
+void bootsANDYN(LweSample *r, const LweSample *a, const LweSample *b, const TFheGateBootstrappingCloudKeySet *k) { (void)k; gate2(ORC_ANDYN, r, a, b); }
+void bootsORNY(LweSample *r, const LweSample *a, const LweSample *b, const TFheGateBootstrappingCloudKeySet *k) { (void)k; gate2(ORC_ORNY, r, a, b); }
+void bootsORYN(LweSample *r, const LweSample *a, const LweSample *b, const TFheGateBootstrappingCloudKeySet *k) { (void)k; gate2(ORC_ORYN, r, a, b); }
 void bootsMUX(LweSample *r, const LweSample *a, const LweSample *b, const LweSample *c, const TFheGateBootstrappingCloudKeySet *k) {
     (void)k;
     const size_t nw = (size_t)g_ks->p.n + 1;

@@ -234,6 +234,10 @@ def set_deferred(on):
     _l.load().tfhe_hip_set_deferred(1 if on else 0)
 
 
+def get_deferred():
+    return bool(_l.load().tfhe_hip_get_deferred())
+
+
 def flush():
     return _l.load().tfhe_hip_flush()
 

@@ -33,6 +33,8 @@ def load():
             "peba1_euclidean_distance": [LS, LSP, LSP, C.c_int, C.c_int, CK],
             "peba1_function_f": [LS, LSP, LSP, C.c_int, LS, C.c_int, CK],
             "peba1_function_g": [LS, LS, LS, LS, C.c_int, CK],
+            "peba1_euclidean_distance_fast": [LS, LSP, LSP, C.c_int, C.c_int, CK],
+            "peba1_function_f_fast": [LS, LSP, LSP, C.c_int, LS, C.c_int, CK],
             "peba1_partial_distance": [LS, LSP, LSP, C.c_int, C.c_int, CK],
             "peba1_combine_and_compare": [LS, LSP, C.c_int, LS, CK],
             "peba1_hamming_distance": [LS, LS, LS, C.c_int, CK],
@@ -87,6 +89,24 @@ def function_f(result_b, sample, template, bound, bitsize, key):
     """Function_f(result_b, a=sample, b=template, bound, bitsize, cloud_key), Math.cpp:379."""
     load().peba1_function_f(result_b.ptr, _ptr_array(sample.slots), _ptr_array(template.slots), len(sample.slots),
                             bound.ptr, bitsize, key.cloud)
+
+
+def function_f_fast(result_b, sample, template, bound, bitsize, key):
+    """Same result as function_f through the optimised DAG of circuits_fast.cpp (not the
+    reference's gate sequence; about 8x fewer bootstraps, 5x less depth)."""
+    load().peba1_function_f_fast(result_b.ptr, _ptr_array(sample.slots), _ptr_array(template.slots),
+                                 len(sample.slots), bound.ptr, bitsize, key.cloud)
+
+
+def euclidean_distance_fast(result, sample, template, bitsize, key):
+    load().peba1_euclidean_distance_fast(result.ptr, _ptr_array(sample.slots), _ptr_array(template.slots),
+                                         len(sample.slots), bitsize, key.cloud)
+
+
+def function_g(result, result_b, r0, r1, bitsize, key):
+    """Function_g(result, result_b, r0, r1, bitsize, cloud_key), Math.cpp:390: (1-b)*r0 + b*r1 on
+    `bitsize`-sample numbers (the reference's heap overflow, SURVEY D4, fixed)."""
+    load().peba1_function_g(result.ptr, result_b.ptr, r0.ptr, r1.ptr, bitsize, key.cloud)
 
 
 def euclidean_distance(result, sample, template, bitsize, key):

@@ -19,5 +19,5 @@ $HIPCC -shared -o $OUT kernels.o host_keys.o engine.o shim.o scheduler.o io.o
 echo "built $(realpath $OUT)"
 # circuits: calls only the public tfhe API; symbols resolve at load time against
 # whichever provider is loaded first (libtfhe-hip.so, or the tests' plain mock)
-$CXX $FLAGS -I../../include -shared -o ../libpeba1-circuits.so circuits.cpp
+$CXX $FLAGS -I../../include -shared -o ../libpeba1-circuits.so circuits.cpp circuits_fast.cpp
 echo "built $(realpath ../libpeba1-circuits.so)"

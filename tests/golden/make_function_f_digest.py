@@ -4,7 +4,10 @@
 circuit library (oracle/liboracle_boots.so), from fixed seeds.  The GPU test
 tests/test_gpu_circuits.py::test_function_f_ciphertexts_match_oracle_digest regenerates the same
 keys and inputs with the product and must reproduce the digest bit for bit.
-Takes ~10 CPU-minutes (0.17 s per gate, single thread)."""
+Takes ~10 CPU-minutes (0.17 s per gate, single thread).
+
+With --fast it writes function_f_fast_digest.json instead: the same inputs through the optimised
+DAG (peba1_function_f_fast, circuits_fast.cpp; a few hundred gates, ~1 minute)."""
 import ctypes as C
 import hashlib
 import json
@@ -24,6 +27,7 @@ TEMPLATE, PROBE, BOUND, BITS = [37, 200], [40, 190], 100, 8
 
 
 def main():
+    fast = "--fast" in sys.argv[1:]
     subprocess.check_call(["make", "-s", "-C", os.path.join(ROOT, "oracle")])
     B = C.CDLL(os.path.join(ROOT, "oracle", "liboracle_boots.so"))
     V = C.c_void_p
@@ -39,6 +43,7 @@ def main():
     B.bootsSymDecrypt.argtypes = [V, V]
     B.orc_boots_export.argtypes = [V, C.c_int32, V]
     B.peba1_function_f.argtypes = [V, V, V, C.c_int, V, C.c_int, V]
+    B.peba1_function_f_fast.argtypes = [V, V, V, C.c_int, V, C.c_int, V]
     p = O.params("P128")
     ks = B.orc_keygen(C.byref(p), KEY_SEED)
     B.orc_boots_bind(ks, ENC_SEED)
@@ -60,7 +65,7 @@ def main():
     bound = enc(BOUND, 3 * BITS)
     rb = B.new_gate_bootstrapping_ciphertext_array(3 * BITS, params)
     t0 = time.time()
-    B.peba1_function_f(rb, (V * len(S))(*S), (V * len(T))(*T), len(S), bound, BITS, cloud)
+    (B.peba1_function_f_fast if fast else B.peba1_function_f)(rb, (V * len(S))(*S), (V * len(T))(*T), len(S), bound, BITS, cloud)
     words = np.zeros((3 * BITS, p.n + 1), dtype=np.int32)
     B.orc_boots_export(rb, 3 * BITS, words.ctypes.data_as(V))
     bit = B.bootsSymDecrypt(rb, None)
@@ -71,7 +76,8 @@ def main():
            "result_b_sha256": hashlib.sha256(words.tobytes()).hexdigest(),
            "result_b0_sha256": hashlib.sha256(words[0].tobytes()).hexdigest(),
            "oracle_seconds": round(time.time() - t0, 1)}
-    with open(os.path.join(ROOT, "tests", "golden", "function_f_digest.json"), "w") as f:
+    out["circuit"] = "peba1_function_f_fast" if fast else "peba1_function_f"
+    with open(os.path.join(ROOT, "tests", "golden", "function_f_fast_digest.json" if fast else "function_f_digest.json"), "w") as f:
         json.dump(out, f, indent=1)
     print(json.dumps(out, indent=1))
 

@@ -88,6 +88,20 @@ void bootsAND(LweSample *r, const LweSample *a, const LweSample *b, const TFheGa
 void bootsOR(LweSample *r, const LweSample *a, const LweSample *b, const TFheGateBootstrappingCloudKeySet *) { ++g_counts[C_OR]; ev(C_OR, r, a, b, 0); wr(r, rd(a) | rd(b)); }
 void bootsXOR(LweSample *r, const LweSample *a, const LweSample *b, const TFheGateBootstrappingCloudKeySet *) { ++g_counts[C_XOR]; ev(C_XOR, r, a, b, 0); wr(r, rd(a) ^ rd(b)); }
 void bootsXNOR(LweSample *r, const LweSample *a, const LweSample *b, const TFheGateBootstrappingCloudKeySet *) { ++g_counts[C_XNOR]; ev(C_XNOR, r, a, b, 0); wr(r, 1 - (rd(a) ^ rd(b))); }
+// the other upstream two-input gates (used by the optimised circuits, not by the reference)
+#define MOCK_OTHER(NAME, CODE, EXPR)                                                                                   \
+    void NAME(LweSample *r, const LweSample *a, const LweSample *b, const TFheGateBootstrappingCloudKeySet *) {        \
+        ++g_counts[C_OTHER]; ev(CODE, r, a, b, 0);                                                                     \
+        const int32_t x = rd(a), y = rd(b);                                                                            \
+        wr(r, EXPR);                                                                                                   \
+    }
+MOCK_OTHER(bootsNAND, 20, 1 - (x & y))
+MOCK_OTHER(bootsNOR, 21, 1 - (x | y))
+MOCK_OTHER(bootsANDNY, 22, (1 - x) & y)
+MOCK_OTHER(bootsANDYN, 23, x & (1 - y))
+MOCK_OTHER(bootsORNY, 24, (1 - x) | y)
+MOCK_OTHER(bootsORYN, 25, x | (1 - y))
+#undef MOCK_OTHER
 void bootsMUX(LweSample *r, const LweSample *a, const LweSample *b, const LweSample *c, const TFheGateBootstrappingCloudKeySet *) {
     ++g_counts[C_MUX]; ev(C_MUX, r, a, b, c);
     const int32_t va = rd(a), vb = rd(b), vc = rd(c);

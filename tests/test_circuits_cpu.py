@@ -24,7 +24,7 @@ def built(tmp_path_factory):
     # this repo's circuits, compiled from source against the mock (no HIP needed)
     subprocess.check_call(["g++", "-O1", "-std=gnu++17", "-I" + inc,
                            os.path.join(ROOT, "tests/refcompat/driver.cpp"),
-                           os.path.join(ROOT, "peba1_amd/csrc/circuits.cpp"),
+                           os.path.join(ROOT, "peba1_amd/csrc/circuits.cpp"), os.path.join(ROOT, "peba1_amd/csrc/circuits_fast.cpp"),
                            "-o", t + "/driver_mine", "-L" + t, "-lplain_tfhe", "-Wl,-rpath," + t])
     return t
 

@@ -108,6 +108,49 @@ for parts in (1, 2, 3, 5):
         rb = arr(24)
         circ.peba1_combine_and_compare(rb, (V * parts)(*partials), parts, enc(bound, 24), cloud)
         assert dec(rb, 24) == (1 if d > bound else 0), (parts, bound)
+
+# optimised Function_f (circuits_fast.cpp): same decrypted outputs as the reference's circuit and
+# as the plaintext rule, through a different DAG
+circ.peba1_function_f.argtypes = [V, V, V, C.c_int, V, C.c_int, V]
+circ.peba1_function_f_fast.argtypes = [V, V, V, C.c_int, V, C.c_int, V]
+circ.peba1_euclidean_distance_fast.argtypes = [V, V, V, C.c_int, C.c_int, V]
+def vec(vals, bits):
+    return (V * len(vals))(*[enc(v, bits) for v in vals])
+rnd = random.Random(11)
+cases = [([0], [0]), ([255], [0]), ([0], [255]), ([255] * 5, [0] * 5), ([7, 200, 13], [7, 200, 13])]
+for n in (1, 2, 3, 8, 17):
+    cases.append(([rnd.randrange(256) for _ in range(n)], [rnd.randrange(256) for _ in range(n)]))
+for probe, tmpl in cases:
+    d = sum((x - y) ** 2 for x, y in zip(probe, tmpl))
+    r = arr(24)
+    circ.peba1_euclidean_distance_fast(r, vec(probe, 8), vec(tmpl, 8), len(probe), 8, cloud)
+    assert dec(r, 24) == d, (probe, tmpl, dec(r, 24), d)
+    for bound in sorted({0, max(d - 1, 0), d, d + 1, (1 << 24) - 1}):
+        rb, rb_ref = arr(24), arr(24)
+        circ.peba1_function_f_fast(rb, vec(probe, 8), vec(tmpl, 8), len(probe), enc(bound, 24), 8, cloud)
+        assert dec(rb, 24) == (1 if d > bound else 0), (probe, tmpl, bound)
+        # the reference's own circuit agrees wherever its subtraction is right: bootsSUBNbit
+        # mishandles a zero subtrahend (Math.cpp:137-138), which in HE_EuclideanDistance is
+        # the sample value (it computes b - a): (0 - 255)^2 comes out as 1
+        if len(probe) <= 3 and 0 not in probe and 0 not in tmpl:
+            circ.peba1_function_f(rb_ref, vec(probe, 8), vec(tmpl, 8), len(probe), enc(bound, 24), 8, cloud)
+            assert dec(rb_ref, 24) == dec(rb, 24)
+# other bit sizes (4-bit slots: 12-bit arithmetic; sums wrap modulo 2^12 as in the reference)
+for probe, tmpl in (([15, 0, 9], [0, 15, 3]), ([15] * 20, [0] * 20)):
+    d = sum((x - y) ** 2 for x, y in zip(probe, tmpl)) % (1 << 12)
+    r = arr(12)
+    circ.peba1_euclidean_distance_fast(r, vec(probe, 4), vec(tmpl, 4), len(probe), 4, cloud)
+    assert dec(r, 12) == d, (probe, tmpl, dec(r, 12), d)
+# the full-size match: 128 slots x 8 bit (SURVEY 8c inputs), gate count of the optimised DAG
+tmpl = [(37 * i + 11) % 255 for i in range(128)]
+for probe, want in (([t + 1 for t in tmpl], 0), ([(91 * i + 5) % 256 for i in range(128)], 1)):
+    rb = arr(24)
+    gate.mock_reset()
+    circ.peba1_function_f_fast(rb, vec(probe, 8), vec(tmpl, 8), 128, enc(256, 24), 8, cloud)
+    assert dec(rb, 24) == want
+    nb = gate.mock_bootstraps()
+print("function_f_fast bootstraps", nb)
+assert nb < 40000
 print("OK")
 '''
 
@@ -119,7 +162,7 @@ def built(tmp_path_factory):
     subprocess.check_call(["g++", "-O1", "-std=gnu++11", "-fPIC", "-shared", "-I" + inc,
                            os.path.join(ROOT, "tests/mock/plain_tfhe.cpp"), "-o", t + "/libplain_tfhe.so"])
     subprocess.check_call(["g++", "-O1", "-std=gnu++17", "-fPIC", "-shared", "-I" + inc,
-                           os.path.join(ROOT, "peba1_amd/csrc/circuits.cpp"), "-o", t + "/libcircuits_test.so"])
+                           os.path.join(ROOT, "peba1_amd/csrc/circuits.cpp"), os.path.join(ROOT, "peba1_amd/csrc/circuits_fast.cpp"), "-o", t + "/libcircuits_test.so"])
     with open(t + "/worker.py", "w") as f:
         f.write(WORKER)
     return t

@@ -61,7 +61,7 @@ def built(tmp_path_factory):
     subprocess.check_call(["g++", "-O1", "-std=gnu++11", "-fPIC", "-shared", "-I" + inc,
                            os.path.join(ROOT, "tests/mock/plain_tfhe.cpp"), "-o", t + "/libplain_tfhe.so"])
     subprocess.check_call(["g++", "-O1", "-std=gnu++17", "-fPIC", "-shared", "-I" + inc,
-                           os.path.join(ROOT, "peba1_amd/csrc/circuits.cpp"), "-o", t + "/libcircuits_test.so"])
+                           os.path.join(ROOT, "peba1_amd/csrc/circuits.cpp"), os.path.join(ROOT, "peba1_amd/csrc/circuits_fast.cpp"), "-o", t + "/libcircuits_test.so"])
     with open(t + "/worker.py", "w") as f:
         f.write(WORKER)
     return t

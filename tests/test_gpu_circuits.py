@@ -77,6 +77,34 @@ def test_small_euclidean_match_and_hamming_match(p128_keys):
         assert rb.decrypt(ks)[0] == (1 if hd > bound else 0), bound
 
 
+def _sub_ref(a, b, bits):
+    """The reference's bootsSUBNbit including its forced sign bit for a zero subtrahend
+    (Math.cpp:137-138; DESIGN.md section 2, reference defects)."""
+    tb = (((~b) & ((1 << bits) - 1)) + 1) & ((1 << bits) - 1) | (1 << bits)
+    s = a + tb
+    carry = (s >> (bits + 1)) & 1
+    s &= (1 << (bits + 1)) - 1
+    return s if carry else (-s) & ((1 << (bits + 1)) - 1)
+
+
+def test_protocol_p1_driver(p128_keys):
+    """SURVEY 8f.3: Function_f then Function_g as main.cpp:533-586 strings them together;
+    the decrypted y follows the reference's arithmetic (its |1 - 0| = 255 included), and the
+    client is 'authenticated' exactly when y == r1."""
+    from peba1_amd import protocol
+    pp, ks, _ = p128_keys
+    template = [12, 200, 77]
+    for sample, bound in (([13, 201, 78], 256), ([90, 3, 250], 256), ([13, 201, 78], 2)):
+        d = sum((a - b) ** 2 for a, b in zip(sample, template))
+        out = protocol.run_p1(pp, ks, sample, template, bound, r0=17, r1=99)
+        b = 1 if d > bound else 0
+        want_y = ((((_sub_ref(1, b, 8) & 255) * 17) & 255) + ((b * 99) & 255)) & 255
+        assert out["match_bit"] == b, (sample, bound)
+        assert out["y"] == want_y, (sample, bound, out)
+        assert out["authenticated"] == (want_y == 99)
+        assert out["levels"]["function_f"] > 100 and out["levels"]["function_g"] > 10
+
+
 def test_sharded_match_over_rccl_world1(p128_keys):
     """peba1_amd/dist.py on the GPU with the nccl (RCCL) backend at world size 1: exercises the
     device-pointer export/import of ciphertexts and the gather; 2 slots."""
@@ -108,18 +136,21 @@ def test_sharded_match_over_rccl_world1(p128_keys):
         dist.destroy_process_group()
 
 
-def test_function_f_ciphertexts_match_oracle_digest(p128_keys):
+@pytest.mark.parametrize("fixture,circuit", [("function_f_digest.json", "function_f"),
+                                             ("function_f_fast_digest.json", "function_f_fast")])
+def test_function_f_ciphertexts_match_oracle_digest(p128_keys, fixture, circuit):
     """Whole-circuit ciphertext parity: a complete 2-slot Function_f (3,438 bootstrapped gates,
     incl. 24 XNOR + 48 MUX) on the GPU reproduces, bit for bit, the SHA-256 of the 24 output
     ciphertexts that the CPU oracle produced through the same circuit library
-    (tests/golden/make_function_f_digest.py, ~10 CPU-minutes)."""
+    (tests/golden/make_function_f_digest.py, ~10 CPU-minutes).  Same for the optimised DAG
+    (542 blind rotations incl. ANDNY/ANDYN and MUX full adders)."""
     import hashlib
     import json
     from types import SimpleNamespace
     from peba1_amd import api, circuits, lib
     pp, ks, _ = p128_keys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    with open(os.path.join(root, "tests", "golden", "function_f_digest.json")) as f:
+    with open(os.path.join(root, "tests", "golden", fixture)) as f:
         g = json.load(f)
     assert g["key_seed"] == 0x5EBA2                      # the session keyset of conftest.py
     L = lib.load()
@@ -134,7 +165,7 @@ def test_function_f_ciphertexts_match_oracle_digest(p128_keys):
     api.reset_stats()
     api.set_deferred(True)
     try:
-        circuits.function_f(rb, SimpleNamespace(slots=S), SimpleNamespace(slots=T), bound, bits, ks)
+        getattr(circuits, circuit)(rb, SimpleNamespace(slots=S), SimpleNamespace(slots=T), bound, bits, ks)
         api.flush()
     finally:
         api.set_deferred(False)
@@ -143,3 +174,31 @@ def test_function_f_ciphertexts_match_oracle_digest(p128_keys):
     assert hashlib.sha256(words[0].tobytes()).hexdigest() == g["result_b0_sha256"]
     assert hashlib.sha256(words.tobytes()).hexdigest() == g["result_b_sha256"]
     assert rb.decrypt(ks)[0] == g["match_bit"]
+
+
+def test_optimised_match_full_size(p128_keys):
+    """peba1_function_f_fast on the full 128 x 8 bit match (SURVEY 8c inputs): genuine -> 0,
+    impostor -> 1, as the plaintext rule and the reference's circuit give; about 7x fewer
+    blind rotations and 5x fewer levels than the reference's DAG."""
+    from peba1_amd import api, circuits, lib
+    pp, ks, _ = p128_keys
+    lib.load().tfhe_hip_set_encrypt_seed(128)
+    tmpl = [(37 * i + 11) % 255 for i in range(128)]
+    T = circuits.EncryptedVector(pp, tmpl, 8, ks)
+    bound = circuits.encrypt_number(pp, 256, 24, ks)
+    api.set_deferred(True)
+    try:
+        for probe, want in (([t + 1 for t in tmpl], 0), ([(91 * i + 5) % 256 for i in range(128)], 1)):
+            S = circuits.EncryptedVector(pp, probe, 8, ks)
+            rb = api.CiphertextArray(pp, 24)
+            api.reset_stats()
+            circuits.function_f_fast(rb, S, T, bound, 8, ks)
+            levels = api.flush()
+            st = api.stats()
+            assert rb.decrypt(ks).tolist() == [want] + [0] * 23
+            assert st["blind_rotates"] == 29536 and levels < 110, (st["blind_rotates"], levels)
+        dist = api.CiphertextArray(pp, 24)
+        circuits.euclidean_distance_fast(dist, S, T, 8, ks)
+        assert circuits.decrypt_number(dist, ks) == 1400950          # SURVEY 8c known answer
+    finally:
+        api.set_deferred(False)
