@@ -2,6 +2,7 @@
 decrypted results against plaintext arithmetic, and ciphertext words against the CPU oracle
 evaluating the same gate sequence where that is cheap."""
 import ctypes as C
+import datetime
 import os
 
 import numpy as np
@@ -116,7 +117,9 @@ def test_sharded_match_over_rccl_world1(p128_keys):
     L = lib.load()
     os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
     os.environ.setdefault("MASTER_PORT", "29611")
-    dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+    os.environ.setdefault("NCCL_SOCKET_IFNAME", "lo")      # one rank: the bootstrap needs no real interface
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0),
+                            timeout=datetime.timedelta(seconds=120))
     try:
         L.tfhe_hip_set_encrypt_seed(47)
         tmpl_v, probe_v = [100, 3], [90, 7]
