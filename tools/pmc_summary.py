@@ -11,7 +11,7 @@ import csv
 import json
 import sys
 
-WIDE_STREAM = ("blind_rotate_kernel", "blind_rotate4_kernel", "keyswitch_kernel")
+WIDE_STREAM = ("blind_rotate_kernel", "blind_rotate4_kernel", "keyswitch_kernel", "keyswitch_tile_kernel")
 
 
 def short(name):
