@@ -98,6 +98,10 @@ int tfhe_hip_gate_batch(int gate, LweSample *result, const LweSample *a, const L
  * TFHE_HIP_DATAFLOW) = experimental: a flush runs as ONE launch in which workgroups take
  * gates in priority order, wait on done flags of their producers and do the key switch
  * inside the workgroup (measured slower than the default on MI355X).
+ * "lanes": 1 (default) = one level sequence on one stream; 2 (env TFHE_HIP_LANES) =
+ * experimental: gates with at most "tight_slack" levels of slack (default 64, env
+ * TFHE_HIP_TIGHT_SLACK) and the rest run as two level sequences on two HIP streams, ordered
+ * by events only where the DAG requires it (measured slower on the match).
  * Returns 0, or -1 for an unknown name. */
 int tfhe_hip_set_tuning(const char *name, int64_t value);
 
@@ -112,16 +116,24 @@ typedef struct TfheHipStats {
     double   ms_blind_rotate;   /* device time, HIP events on the engine stream */
     double   ms_keyswitch;
     double   ms_flush_wall;     /* host wall time inside flush */
+    double   ms_blind_rotate_busy; /* time during which at least one blind-rotate launch was running
+                                      (== ms_blind_rotate with one lane; less when two lanes overlap) */
 } TfheHipStats;
 void tfhe_hip_get_stats(TfheHipStats *out);
 void tfhe_hip_reset_stats(void);
-/* when on, every kernel launch is bracketed by HIP events (adds sync points) */
+/* when on, every kernel launch is bracketed by HIP events, read back after the flush */
 void tfhe_hip_set_kernel_timing(int on);
 
 /* ---- host-logic test entry: levelise a DAG given as count x {kind, dst, a, b, c} slot
  * records (kind: gate code 0..9, 16 = MUX, 17 = NOT; absent operands -1) without
  * touching the device; writes the level of each op, returns the depth ---- */
 int tfhe_hip_test_schedule(const int32_t *ops5, int32_t count, int32_t unit, int32_t balance, int32_t *levels_out);
+/* same input; writes the execution lane (0 urgent, 1 background) of each op for two-lane execution */
+int tfhe_hip_test_assign_lanes(const int32_t *ops5, int32_t count, int32_t unit, int32_t tight_slack, int32_t *lanes_out);
+/* Diagnostic (tools/lane_probe.py): `levels` rounds of (blind rotate + key switch) over `width`
+ * random gates, issued as `lanes` independent chains on `lanes` HIP streams; returns the wall
+ * time in ms (negative on error).  Measures what overlapping level-synchronous chains could gain. */
+double tfhe_hip_test_lane_probe(const TFheGateBootstrappingCloudKeySet *bk, int32_t lanes, int32_t levels, int32_t width);
 
 /* ---- kernel-level entry points (K2/K3 parity tests against the oracle) ---- */
 /* exact negacyclic products res[c] = ip[c] * tp[c] mod (X^N+1) mod 2^32 through

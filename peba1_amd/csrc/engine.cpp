@@ -2,6 +2,8 @@
 #include "engine.hpp"
 
 #include <algorithm>
+#include <utility>
+#include <vector>
 #include <chrono>
 #include <ctime>
 #include <unistd.h>
@@ -87,7 +89,12 @@ void Engine::ensure_init() {
         hip_check(hipGetDeviceProperties(&prop, device_), "hipGetDeviceProperties");
         cu_count_ = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
     }
-    hip_check(hipStreamCreateWithFlags(&stream_, hipStreamNonBlocking), "hipStreamCreate");
+    {
+        int least = 0, greatest = 0;
+        hip_check(hipDeviceGetStreamPriorityRange(&least, &greatest), "priority range");
+        hip_check(hipStreamCreateWithPriority(&stream_, hipStreamNonBlocking, greatest), "hipStreamCreate");
+    }
+    if (const char *env = std::getenv("TFHE_HIP_LANE_PRIO")) lane_prio = std::atoi(env);
     for (auto &e : ev_) hip_check(hipEventCreate(&e), "hipEventCreate");
     inited_ = true;
 }
@@ -141,6 +148,7 @@ static DevParams make_dev_params(const Params &p) {
     d.kpl = p.kpl(); d.ct_stride = p.ct_stride(); d.u_stride = p.u_stride();
     d.decomp_offset = p.decomp_offset(); d.ks_prec_offset = p.ks_prec_offset();
     d.mu = 1 << 29;
+    d.wave_prio = 0;
     return d;
 }
 
@@ -261,18 +269,23 @@ void Engine::read_slots_packed(SlotPool *pool, const int32_t *slots, int count, 
 }
 
 void Engine::launch_br(const DeviceKeyImage *key, const int32_t *pool, const RotDesc *rots, int count, int32_t *u_buf,
-                       int32_t *acc_dbg) {
+                       int32_t *acc_dbg, hipStream_t stream, int wave_prio) {
+    if (!stream) stream = stream_;
     if (count <= br4_max_rotations) {
-        launch_blind_rotate4(stream_, key->dp, key->key, pool, rots, count, u_buf, acc_dbg);
+        DevParams dp = key->dp;
+        dp.wave_prio = wave_prio;
+        launch_blind_rotate4(stream, dp, key->key, pool, rots, count, u_buf, acc_dbg);
         return;
     }
     // (splitting a short last round off to the latency kernel was measured: the kernel
     // boundary costs more overlap than the faster tail gains -- match 3.99 s -> 4.15 s)
-    launch_blind_rotate(stream_, key->dp, key->key, pool, rots, count, u_buf, acc_dbg);
+    launch_blind_rotate(stream, key->dp, key->key, pool, rots, count, u_buf, acc_dbg);
 }
 
-void Engine::launch_ks(const DeviceKeyImage *key, const int32_t *u_buf, const KsDesc *descs, int count, int32_t *pool) {
+void Engine::launch_ks(const DeviceKeyImage *key, const int32_t *u_buf, const KsDesc *descs, int count, int32_t *pool,
+                       hipStream_t stream, int lane) {
     if (count <= 0) return;
+    if (!stream) stream = stream_;
     const DevParams &dp = key->dp;
     const int nin = dp.k * dp.N;
     // tiled kernel: wide launches, ranges of at most 64 input coefficients
@@ -285,18 +298,24 @@ void Engine::launch_ks(const DeviceKeyImage *key, const int32_t *u_buf, const Ks
         if (tiled && cnt >= 2 * ks_tile) splits = ks_max_splits;
         else while (splits < ks_max_splits && cnt * splits * 2 <= ks_target_blocks) splits *= 2;
         int32_t *partial = nullptr;
-        if (splits > 1) partial = static_cast<int32_t *>(scratch(10, (size_t)cnt * splits * dp.ct_stride * 4));
-        launch_keyswitch(stream_, dp, key->key, u_buf, descs + done, cnt, pool, splits, partial, tiled ? ks_tile : 0);
+        if (splits > 1) partial = static_cast<int32_t *>(scratch(10 + (size_t)lane, (size_t)cnt * splits * dp.ct_stride * 4));
+        launch_keyswitch(stream, dp, key->key, u_buf, descs + done, cnt, pool, splits, partial, tiled ? ks_tile : 0);
     }
 }
 
 void Engine::execute(const DeviceKeyImage *key, SlotPool *pool, const LevelPlan &plan) {
     const auto t0 = std::chrono::steady_clock::now();
-    const int levels = (int)plan.rot_off.size() - 1;
+    const int levels = plan.levels, K = plan.lanes;
     RotDesc *drots = static_cast<RotDesc *>(scratch(0, plan.rots.size() * sizeof(RotDesc) + 16));
     KsDesc *dks = static_cast<KsDesc *>(scratch(1, plan.kss.size() * sizeof(KsDesc) + 16));
     NotDesc *dnots = static_cast<NotDesc *>(scratch(2, plan.nots.size() * sizeof(NotDesc) + 16));
-    int32_t *u_buf = static_cast<int32_t *>(scratch(5, (size_t)(plan.max_rots_per_level + 1) * key->dp.u_stride * 4));
+    // per lane: extract buffer and key-switch partial sums, sized for the lane's widest group
+    // before anything runs (scratch() may reallocate, which must not happen under a running lane)
+    int32_t *u_buf[2] = {nullptr, nullptr};
+    for (int s = 0; s < K; ++s) {
+        u_buf[s] = static_cast<int32_t *>(scratch(s == 0 ? 5 : 20 + (size_t)s, (size_t)(plan.max_rots[s] + 1) * key->dp.u_stride * 4));
+        (void)scratch(10 + (size_t)s, (size_t)std::min(plan.max_rots[s] + 1, 8192) * ks_max_splits * key->dp.ct_stride * 4);
+    }
     if (!plan.rots.empty())
         hip_check(hipMemcpyAsync(drots, plan.rots.data(), plan.rots.size() * sizeof(RotDesc), hipMemcpyHostToDevice, stream_), "upload rots");
     if (!plan.kss.empty())
@@ -304,34 +323,103 @@ void Engine::execute(const DeviceKeyImage *key, SlotPool *pool, const LevelPlan 
     if (!plan.nots.empty())
         hip_check(hipMemcpyAsync(dnots, plan.nots.data(), plan.nots.size() * sizeof(NotDesc), hipMemcpyHostToDevice, stream_), "upload nots");
 
-    // nots of level 0 (inputs already materialised) come first: not_off[0..1]
-    launch_not(stream_, key->dp, dnots + plan.not_off[0], plan.not_off[1] - plan.not_off[0], pool->data());
-    for (int L = 0; L < levels; ++L) {
-        const int nrot = plan.rot_off[L + 1] - plan.rot_off[L];
-        const int nks = plan.ks_off[L + 1] - plan.ks_off[L];
-        const int nnot = plan.not_off[L + 2] - plan.not_off[L + 1];
-        if (kernel_timing) hip_check(hipEventRecord(ev_[0], stream_), "event");
-        launch_br(key, pool->data(), drots + plan.rot_off[L], nrot, u_buf, nullptr);
-        if (kernel_timing) hip_check(hipEventRecord(ev_[1], stream_), "event");
-        launch_ks(key, u_buf, dks + plan.ks_off[L], nks, pool->data());
-        if (kernel_timing) hip_check(hipEventRecord(ev_[2], stream_), "event");
-        launch_not(stream_, key->dp, dnots + plan.not_off[L + 1], nnot, pool->data());
-        if (kernel_timing) {
-            hip_check(hipEventSynchronize(ev_[2]), "event sync");
-            float ms_br = 0, ms_ks = 0;
-            hip_check(hipEventElapsedTime(&ms_br, ev_[0], ev_[1]), "elapsed");
-            hip_check(hipEventElapsedTime(&ms_ks, ev_[1], ev_[2]), "elapsed");
-            stats.ms_blind_rotate += ms_br;
-            stats.ms_keyswitch += ms_ks;
+    lane_stream_[0] = stream_;
+    const size_t ngroups = ((size_t)levels + 1) * K;
+    if (K > 1) {
+        if (!lane_stream_[1]) {
+            // the background lane: lowest queue priority, so freed workgroup slots go to the urgent lane first
+            int least = 0, greatest = 0;
+            hip_check(hipDeviceGetStreamPriorityRange(&least, &greatest), "priority range");
+            hip_check(hipStreamCreateWithPriority(&lane_stream_[1], hipStreamNonBlocking, least), "lane stream");
         }
-        stats.blind_rotates += (uint64_t)nrot;
-        stats.keyswitches += (uint64_t)nks;
-        stats.linear_ops += (uint64_t)nnot;
-        if (nrot) ++stats.br_launches;
+        while (order_events_.size() < ngroups + 1) {
+            hipEvent_t e;
+            hip_check(hipEventCreateWithFlags(&e, hipEventDisableTiming), "order event");
+            order_events_.push_back(e);
+        }
+        // lane 1 starts after the descriptor upload (enqueued on lane 0's stream)
+        hip_check(hipEventRecord(order_events_[ngroups], stream_), "upload event");
+        hip_check(hipStreamWaitEvent(lane_stream_[1], order_events_[ngroups], 0), "wait upload");
     }
-    stats.linear_ops += (uint64_t)(plan.not_off[1] - plan.not_off[0]);
+    size_t nt = 0;                                       // timing events used: base, then 3 per group
+    auto timing_event = [&]() {
+        if (nt == timing_events_.size()) {
+            hipEvent_t e;
+            hip_check(hipEventCreate(&e), "timing event");
+            timing_events_.push_back(e);
+        }
+        return timing_events_[nt++];
+    };
+    struct Timed { hipEvent_t e0, e1, e2; };
+    std::vector<Timed> timed;
+    hipEvent_t base = nullptr;
+    if (kernel_timing) {
+        base = timing_event();
+        hip_check(hipEventRecord(base, stream_), "event");
+        timed.reserve(ngroups);
+    }
+    int waited[2][2] = {{0, 0}, {0, 0}};                 // waited[s][o]: lane s already waits for lane o up to this level+1
+    int last_group[2] = {-1, -1};
+    for (int L = 0; L <= levels; ++L) {
+        for (int s = 0; s < K; ++s) {
+            const size_t gn = (size_t)L * K + s;                     // NOT / need index
+            const size_t gg = L > 0 ? (size_t)(L - 1) * K + s : 0;   // gate index
+            const int nrot = L > 0 ? plan.rot_off[gg + 1] - plan.rot_off[gg] : 0;
+            const int nks = L > 0 ? plan.ks_off[gg + 1] - plan.ks_off[gg] : 0;
+            const int nnot = plan.not_off[gn + 1] - plan.not_off[gn];
+            if (nrot == 0 && nks == 0 && nnot == 0) continue;
+            hipStream_t st = lane_stream_[s];
+            if (K > 1) {
+                const int o = 1 - s;
+                const int w = plan.need[gn * K + o];
+                if (w > waited[s][o]) {
+                    hip_check(hipStreamWaitEvent(st, order_events_[(size_t)(w - 1) * K + o], 0), "lane wait");
+                    waited[s][o] = w;
+                }
+            }
+            Timed t{nullptr, nullptr, nullptr};
+            if (kernel_timing) { t.e0 = timing_event(); hip_check(hipEventRecord(t.e0, st), "event"); }
+            if (nrot) launch_br(key, pool->data(), drots + plan.rot_off[gg], nrot, u_buf[s], nullptr, st, K > 1 && s == 0 ? lane_prio : 0);
+            if (kernel_timing) { t.e1 = timing_event(); hip_check(hipEventRecord(t.e1, st), "event"); }
+            if (nks) launch_ks(key, u_buf[s], dks + plan.ks_off[gg], nks, pool->data(), st, s);
+            if (kernel_timing) { t.e2 = timing_event(); hip_check(hipEventRecord(t.e2, st), "event"); timed.push_back(t); }
+            launch_not(st, key->dp, dnots + plan.not_off[gn], nnot, pool->data());
+            if (K > 1) hip_check(hipEventRecord(order_events_[gn], st), "lane event");
+            last_group[s] = (int)gn;
+            stats.blind_rotates += (uint64_t)nrot;
+            stats.keyswitches += (uint64_t)nks;
+            stats.linear_ops += (uint64_t)nnot;
+            if (nrot) ++stats.br_launches;
+        }
+    }
     hip_check(hipGetLastError(), "kernel launch");
+    if (K > 1 && last_group[1] >= 0) hip_check(hipStreamWaitEvent(stream_, order_events_[last_group[1]], 0), "join lanes");
     hip_check(hipStreamSynchronize(stream_), "level execution");
+    if (kernel_timing) {
+        // durations per launch, and the union of the blind-rotate intervals (two lanes overlap)
+        std::vector<std::pair<float, float>> br;
+        br.reserve(timed.size());
+        for (const Timed &t : timed) {
+            float a = 0, b = 0, c = 0;
+            hip_check(hipEventElapsedTime(&a, base, t.e0), "elapsed");
+            hip_check(hipEventElapsedTime(&b, base, t.e1), "elapsed");
+            hip_check(hipEventElapsedTime(&c, base, t.e2), "elapsed");
+            stats.ms_blind_rotate += b - a;
+            stats.ms_keyswitch += c - b;
+            if (b > a) br.emplace_back(a, b);
+        }
+        std::sort(br.begin(), br.end());
+        float cur_a = 0, cur_b = -1;
+        for (const auto &iv : br) {
+            if (cur_b < cur_a || iv.first > cur_b) {
+                if (cur_b >= cur_a) stats.ms_blind_rotate_busy += cur_b - cur_a;
+                cur_a = iv.first; cur_b = iv.second;
+            } else {
+                cur_b = std::max(cur_b, iv.second);
+            }
+        }
+        if (cur_b >= cur_a) stats.ms_blind_rotate_busy += cur_b - cur_a;
+    }
     stats.levels += (uint64_t)levels;
     ++stats.flushes;
     stats.ms_flush_wall += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
@@ -434,6 +522,48 @@ void Engine::run_keyswitch(const DeviceKeyImage *key, const Torus32 *u, int coun
     hip_check(hipStreamSynchronize(stream_), "keyswitch");
     for (int c = 0; c < count; ++c) std::memcpy(out + (size_t)c * (dp.n + 1), &res[(size_t)c * dp.ct_stride], (size_t)(dp.n + 1) * 4);
     stats.keyswitches += (uint64_t)count;
+}
+
+double Engine::run_lane_probe(const DeviceKeyImage *key, int lanes, int levels, int width) {
+    const DevParams &dp = key->dp;
+    lanes = std::max(1, std::min(lanes, 8));
+    const int per = width / lanes;
+    if (per <= 0 || levels <= 0) return 0.0;
+    // a private "pool": `width` random input ciphertexts, then `width` outputs
+    std::vector<int32_t> host((size_t)width * dp.ct_stride);
+    uint64_t x = 0x9E3779B97F4A7C15ull;
+    for (auto &w : host) { x ^= x << 13; x ^= x >> 7; x ^= x << 17; w = (int32_t)(x >> 16); }
+    int32_t *pool = static_cast<int32_t *>(scratch(40, (size_t)2 * width * dp.ct_stride * 4));
+    hip_check(hipMemcpy(pool, host.data(), host.size() * 4, hipMemcpyHostToDevice), "probe pool");
+    std::vector<RotDesc> rots(width);
+    std::vector<KsDesc> kss(width);
+    for (int i = 0; i < width; ++i) {
+        const int local = i % per;
+        rots[i] = RotDesc{i, (i + 1) % width, 1, 1, -dp.mu, local};
+        kss[i] = KsDesc{local, -1, 0, width + i};
+    }
+    RotDesc *drots = static_cast<RotDesc *>(scratch(41, rots.size() * sizeof(RotDesc)));
+    KsDesc *dks = static_cast<KsDesc *>(scratch(42, kss.size() * sizeof(KsDesc)));
+    hip_check(hipMemcpy(drots, rots.data(), rots.size() * sizeof(RotDesc), hipMemcpyHostToDevice), "probe rots");
+    hip_check(hipMemcpy(dks, kss.data(), kss.size() * sizeof(KsDesc), hipMemcpyHostToDevice), "probe ks");
+    std::vector<hipStream_t> st(lanes);
+    std::vector<int32_t *> ubuf(lanes);
+    for (int s = 0; s < lanes; ++s) {
+        hip_check(hipStreamCreateWithFlags(&st[s], hipStreamNonBlocking), "probe stream");
+        ubuf[s] = static_cast<int32_t *>(scratch(50 + (size_t)s, (size_t)(per + 1) * dp.u_stride * 4));
+        (void)scratch(10 + (size_t)s, (size_t)per * ks_max_splits * dp.ct_stride * 4);   // no growth while running
+    }
+    hip_check(hipDeviceSynchronize(), "probe sync");
+    const auto t0 = std::chrono::steady_clock::now();
+    for (int L = 0; L < levels; ++L)
+        for (int s = 0; s < lanes; ++s) {
+            launch_br(key, pool, drots + (size_t)s * per, per, ubuf[s], nullptr, st[s]);
+            launch_ks(key, ubuf[s], dks + (size_t)s * per, per, pool, st[s], s);
+        }
+    for (int s = 0; s < lanes; ++s) hip_check(hipStreamSynchronize(st[s]), "probe lane");
+    const double ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+    for (int s = 0; s < lanes; ++s) hip_check(hipStreamDestroy(st[s]), "probe stream destroy");
+    return ms;
 }
 
 void Engine::run_negacyclic(const DeviceKeyImage *key, const int32_t *ip, const Torus32 *tp, Torus32 *res, int count) {

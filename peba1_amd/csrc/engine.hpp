@@ -53,12 +53,18 @@ private:
 };
 
 struct LevelPlan {
-    // descriptors of the whole flush, level-major; offsets index into them
+    // descriptors of the whole flush, ordered by (level, lane); group g = level_index * lanes + lane
     std::vector<RotDesc> rots;
     std::vector<KsDesc> kss;
     std::vector<NotDesc> nots;
-    std::vector<int32_t> rot_off, ks_off, not_off;   // size levels+1 (nots: levels+2, level 0 first)
-    int max_rots_per_level = 0;
+    int lanes = 1;
+    int levels = 0;
+    std::vector<int32_t> rot_off, ks_off;   // size levels*lanes + 1; gates of level L (1-based): index (L-1)*lanes + lane
+    std::vector<int32_t> not_off;           // size (levels+1)*lanes + 1; NOTs riding on level L (0 = inputs): L*lanes + lane
+    std::vector<int32_t> max_rots;          // per lane: widest group (sizes the lane's extract buffer)
+    // lanes > 1: need[g * lanes + other] = 1 + the highest level of lane `other` whose results
+    // the gates of group g read (0 = none); g indexes like not_off (level L, lane)
+    std::vector<int32_t> need;
 };
 
 class Engine {
@@ -101,9 +107,17 @@ public:
     int ks_max_splits = 32;
     // gates per workgroup of the tiled key switch (16 or 32; 0 = per-gate kernel only)
     int ks_tile = 16;
-    void launch_ks(const DeviceKeyImage *key, const int32_t *u_buf, const KsDesc *descs, int count, int32_t *pool);
+    // two-lane execution: 1 = the urgent lane's blind-rotate waves raise their issue priority
+    // (measured slower: the co-resident workgroups of the other lane become its stragglers)
+    int lane_prio = 0;
+    // stream == nullptr: the engine's stream; lane selects the scratch buffer of the partial sums
+    void launch_ks(const DeviceKeyImage *key, const int32_t *u_buf, const KsDesc *descs, int count, int32_t *pool,
+                   hipStream_t stream = nullptr, int lane = 0);
     void launch_br(const DeviceKeyImage *key, const int32_t *pool, const RotDesc *rots, int count, int32_t *u_buf,
-                   int32_t *acc_dbg);
+                   int32_t *acc_dbg, hipStream_t stream = nullptr, int wave_prio = 0);
+    // diagnostic (tools/lane_probe.py): `levels` rounds of (blind rotate + key switch) of `width`
+    // random gates in total, issued as `lanes` independent chains on `lanes` streams; returns ms
+    double run_lane_probe(const DeviceKeyImage *key, int lanes, int levels, int width);
 
 private:
     Engine() = default;
@@ -112,6 +126,9 @@ private:
     int cu_count_ = 256;
     bool inited_ = false;
     hipStream_t stream_ = nullptr;
+    hipStream_t lane_stream_[2] = {nullptr, nullptr};   // lane 0 = stream_, lane 1 created on first use
+    std::vector<hipEvent_t> order_events_;              // cross-lane ordering, no timing
+    std::vector<hipEvent_t> timing_events_;             // kernel_timing: 3 per (level, lane) + 1 base
     hipEvent_t ev_[3] = {nullptr, nullptr, nullptr};
     std::vector<SlotPool *> pools_;
     std::vector<void *> scratch_ptr_;

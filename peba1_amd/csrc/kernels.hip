@@ -434,6 +434,9 @@ __global__ __launch_bounds__(256, LOGN == 10 ? 2 : 1) void blind_rotate4_kernel(
     DevParams p, DevKey key, const int32_t *__restrict__ pool, const RotDesc *__restrict__ rots,
     int32_t *__restrict__ u_buf, int32_t *__restrict__ acc_dbg) {
     __shared__ __align__(16) Br4Lds<LOGN> sh;
+    // urgent lane: these waves win issue arbitration against a co-resident workgroup of the
+    // other lane, so a critical-chain gate runs at nearly its stand-alone latency
+    if (p.wave_prio) __builtin_amdgcn_s_setprio(3);
     const RotDesc rd = rots[blockIdx.x];
     blind_rotate4_body<LOGN>(p, key, pool, rd, sh, threadIdx.x);
     extract_sample<LOGN, 256>(p, rd, sh.acc, u_buf, acc_dbg, threadIdx.x);

@@ -14,6 +14,7 @@ struct DevParams {
     uint32_t decomp_offset; // sum_j (Bg/2) 2^{32-j Bgbit}
     uint32_t ks_prec_offset;// 2^{32-(1+basebit t)}
     int32_t mu;             // test-vector amplitude, 1/8
+    int32_t wave_prio;      // per launch: 1 = the blind-rotate waves raise their issue priority (urgent lane)
 };
 
 // Device-resident evaluation key.

@@ -28,6 +28,23 @@ void priority_order(const std::vector<PendingOp> &ops, const std::vector<int32_t
     });
 }
 
+void assign_lanes(const std::vector<PendingOp> &ops, const std::vector<int32_t> &alap, int tight_slack,
+                  std::vector<uint8_t> &lanes_out) {
+    const int n = (int)ops.size();
+    lanes_out.assign(n, 0);
+    std::unordered_map<int32_t, int32_t> producer;
+    producer.reserve((size_t)n * 2);
+    for (int i = 0; i < n; ++i) {
+        if (ops[i].kind == OP_NOT) {
+            auto it = producer.find(ops[i].a);
+            lanes_out[i] = it == producer.end() ? 0 : lanes_out[it->second];
+        } else {
+            lanes_out[i] = (alap[i] - ops[i].level) <= tight_slack ? 0 : 1;
+        }
+        producer.emplace(ops[i].dst, i);
+    }
+}
+
 int schedule_levels(const std::vector<PendingOp> &ops, int asap_depth, bool balance, int unit,
                     std::vector<int32_t> &lvl, std::vector<int32_t> *alap_out) {
     const int n = (int)ops.size();

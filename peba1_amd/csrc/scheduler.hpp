@@ -39,4 +39,15 @@ int schedule_levels(const std::vector<PendingOp> &ops, int asap_depth, bool bala
 void priority_order(const std::vector<PendingOp> &ops, const std::vector<int32_t> &lvl,
                     const std::vector<int32_t> &alap, std::vector<int32_t> &order);
 
+// Two execution lanes (HIP streams) for a levelised DAG.  Level-synchronous execution leaves
+// a bubble at every level boundary (all workgroups of a launch start and end together, then
+// the key switch runs alone).  Cutting the gates into two sets that each run their own
+// level sequence, ordered against each other only where a gate really needs a result of the
+// other set, lets the boundaries of one lane fall inside the launches of the other.
+// lane 0 ("urgent"): gates whose slack (ALAP - ASAP level) is at most tight_slack -- the
+// critical chains; lane 1: the rest.  A NOT rides in the lane of the gate that produces its
+// operand (lane 0 when that is already materialised).  lanes_out[i] in {0, 1}.
+void assign_lanes(const std::vector<PendingOp> &ops, const std::vector<int32_t> &alap, int tight_slack,
+                  std::vector<uint8_t> &lanes_out);
+
 }  // namespace tfhe_hip

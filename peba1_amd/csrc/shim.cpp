@@ -84,6 +84,8 @@ struct Recorder {
     uint64_t keygen_counter = 0;
     bool balance_levels = true;   // slack-aware level filling (scheduler.hpp)
     bool dataflow = false;        // opt-in: one dataflow launch per flush instead of per-level launches
+    int lanes = 1;                // 2: urgent gates and the rest on two streams (scheduler.hpp assign_lanes)
+    int tight_slack = 64;         // lane 0 takes the gates with at most this much slack
     std::unordered_map<int32_t, int32_t> not_origin;   // pending NOT output slot -> its operand slot
 };
 Recorder &rec() {
@@ -91,6 +93,8 @@ Recorder &rec() {
     static bool init = [] {
         if (const char *e = std::getenv("TFHE_HIP_DEFERRED")) r.deferred = std::atoi(e) != 0;
         if (const char *e = std::getenv("TFHE_HIP_DATAFLOW")) r.dataflow = std::atoi(e) != 0;
+        if (const char *e = std::getenv("TFHE_HIP_LANES")) r.lanes = std::atoi(e) > 1 ? 2 : 1;
+        if (const char *e = std::getenv("TFHE_HIP_TIGHT_SLACK")) r.tight_slack = std::atoi(e);
         return true;
     }();
     (void)init;
@@ -230,50 +234,81 @@ int flush_locked() {
         r.max_level = 0;
         return levels;
     }
+    // execution lanes: urgent gates (little slack) and the rest run as two level sequences on
+    // two streams, ordered against each other only where the DAG says so (scheduler.hpp)
+    int K = 1;
+    std::vector<uint8_t> lane;
+    if (r.lanes > 1 && levels > 2) {
+        assign_lanes(r.ops, alap, r.tight_slack, lane);
+        for (uint8_t l : lane) if (l) { K = 2; break; }
+    }
+    if (K == 1) lane.assign(r.ops.size(), 0);
     LevelPlan plan;
-    // counting sort by level
-    std::vector<int32_t> nrot(levels + 2, 0), nks(levels + 2, 0), nnot(levels + 2, 0);
+    plan.lanes = K;
+    plan.levels = levels;
+    // counting sort by (level, lane)
+    const size_t ngroups = (size_t)levels * K, nnotgroups = ((size_t)levels + 1) * K;
+    std::vector<int32_t> nrot(ngroups + 1, 0), nks(ngroups + 1, 0), nnot(nnotgroups + 1, 0);
     for (size_t i = 0; i < r.ops.size(); ++i) {
         const PendingOp &op = r.ops[i];
-        if (op.kind == OP_NOT) ++nnot[lvl[i]];
-        else if (op.kind == OP_MUX) { nrot[lvl[i]] += 2; ++nks[lvl[i]]; }
-        else { ++nrot[lvl[i]]; ++nks[lvl[i]]; }
+        if (op.kind == OP_NOT) { ++nnot[(size_t)lvl[i] * K + lane[i]]; continue; }
+        const size_t g = (size_t)(lvl[i] - 1) * K + lane[i];
+        nrot[g] += op.kind == OP_MUX ? 2 : 1;
+        ++nks[g];
     }
-    plan.rot_off.assign(levels + 1, 0);
-    plan.ks_off.assign(levels + 1, 0);
-    plan.not_off.assign(levels + 2, 0);
-    for (int L = 1; L <= levels; ++L) {
-        plan.rot_off[L] = plan.rot_off[L - 1] + nrot[L];
-        plan.ks_off[L] = plan.ks_off[L - 1] + nks[L];
-        plan.max_rots_per_level = std::max(plan.max_rots_per_level, nrot[L]);
+    plan.rot_off.assign(ngroups + 1, 0);
+    plan.ks_off.assign(ngroups + 1, 0);
+    plan.not_off.assign(nnotgroups + 1, 0);
+    plan.max_rots.assign(K, 0);
+    for (size_t g = 0; g < ngroups; ++g) {
+        plan.rot_off[g + 1] = plan.rot_off[g] + nrot[g];
+        plan.ks_off[g + 1] = plan.ks_off[g] + nks[g];
+        plan.max_rots[g % K] = std::max(plan.max_rots[g % K], nrot[g]);
     }
-    for (int L = 0; L <= levels; ++L) plan.not_off[L + 1] = plan.not_off[L] + nnot[L];
-    plan.rots.resize(plan.rot_off[levels]);
-    plan.kss.resize(plan.ks_off[levels]);
-    plan.nots.resize(plan.not_off[levels + 1]);
-    std::vector<int32_t> rpos(plan.rot_off.begin(), plan.rot_off.end() - 1);   // cursor per level (index L-1)
+    for (size_t g = 0; g < nnotgroups; ++g) plan.not_off[g + 1] = plan.not_off[g] + nnot[g];
+    plan.rots.resize(plan.rot_off[ngroups]);
+    plan.kss.resize(plan.ks_off[ngroups]);
+    plan.nots.resize(plan.not_off[nnotgroups]);
+    std::vector<int32_t> rpos(plan.rot_off.begin(), plan.rot_off.end() - 1);   // cursor per group
     std::vector<int32_t> kpos(plan.ks_off.begin(), plan.ks_off.end() - 1);
-    std::vector<int32_t> npos(plan.not_off.begin(), plan.not_off.end() - 1);   // index L
+    std::vector<int32_t> npos(plan.not_off.begin(), plan.not_off.end() - 1);
+    // cross-lane needs: which level of the other lane must be complete before a group starts
+    std::unordered_map<int32_t, int32_t> producer;
+    if (K > 1) {
+        plan.need.assign(nnotgroups * K, 0);
+        producer.reserve(r.ops.size() * 2);
+        for (size_t i = 0; i < r.ops.size(); ++i) producer.emplace(r.ops[i].dst, (int32_t)i);
+    }
+    auto note_need = [&](size_t i, int32_t slot) {
+        if (slot < 0) return;
+        auto it = producer.find(slot);
+        if (it == producer.end() || (size_t)it->second >= i) return;     // materialised before this flush
+        const int32_t pi = it->second;
+        if (lane[pi] == lane[i]) return;
+        int32_t &w = plan.need[((size_t)lvl[i] * K + lane[i]) * K + lane[pi]];
+        w = std::max(w, lvl[pi] + 1);
+    };
     const int32_t mu = 1 << 29;
     for (size_t i = 0; i < r.ops.size(); ++i) {
         const PendingOp &op = r.ops[i];
+        if (K > 1) { note_need(i, op.a); note_need(i, op.b); note_need(i, op.c); }
         if (op.kind == OP_NOT) {
-            plan.nots[npos[lvl[i]]++] = NotDesc{op.a, op.dst};
+            plan.nots[npos[(size_t)lvl[i] * K + lane[i]]++] = NotDesc{op.a, op.dst};
             continue;
         }
-        const int L = lvl[i] - 1;
-        const int32_t base = plan.rot_off[L];
+        const size_t g = (size_t)(lvl[i] - 1) * K + lane[i];
+        const int32_t base = plan.rot_off[g];
         if (op.kind == OP_MUX) {
             // tfhe bootsMUX: u1 = BR(-1/8 + a + b), u2 = BR(-1/8 - a + c), KS(u1 + u2 + 1/8)
-            const int32_t i0 = rpos[L]++, i1 = rpos[L]++;
+            const int32_t i0 = rpos[g]++, i1 = rpos[g]++;
             plan.rots[i0] = RotDesc{op.a, op.b, 1, 1, -(mu), i0 - base};
             plan.rots[i1] = RotDesc{op.a, op.c, -1, 1, -(mu), i1 - base};
-            plan.kss[kpos[L]++] = KsDesc{i0 - base, i1 - base, mu, op.dst};
+            plan.kss[kpos[g]++] = KsDesc{i0 - base, i1 - base, mu, op.dst};
         } else {
             const GateLin &gl = GATE_LIN[op.kind];
-            const int32_t i0 = rpos[L]++;
+            const int32_t i0 = rpos[g]++;
             plan.rots[i0] = RotDesc{op.a, op.b, gl.sa, gl.sb, gl.c8 * mu, i0 - base};
-            plan.kss[kpos[L]++] = KsDesc{i0 - base, -1, 0, op.dst};
+            plan.kss[kpos[g]++] = KsDesc{i0 - base, -1, 0, op.dst};
         }
     }
     Engine::get().execute(r.key->bk->dev, pool, plan);
@@ -669,6 +704,8 @@ int tfhe_hip_set_tuning(const char *name, int64_t value) {
         return 0;
     }
     if (name && std::strcmp(name, "balance_levels") == 0) { rec().balance_levels = value != 0; return 0; }
+    if (name && std::strcmp(name, "lanes") == 0) { rec().lanes = value > 1 ? 2 : 1; return 0; }
+    if (name && std::strcmp(name, "tight_slack") == 0) { rec().tight_slack = (int)value; return 0; }
     if (name && std::strcmp(name, "dataflow") == 0) { rec().dataflow = value != 0; return 0; }
     set_error(std::string("tfhe_hip_set_tuning: unknown name ") + (name ? name : "(null)"));
     return -1;
@@ -678,9 +715,9 @@ void tfhe_hip_get_stats(TfheHipStats *out) { if (out) *out = Engine::get().stats
 void tfhe_hip_reset_stats(void) { Engine::get().stats = TfheHipStats{}; }
 void tfhe_hip_set_kernel_timing(int on) { Engine::get().kernel_timing = on != 0; }
 
-int tfhe_hip_test_schedule(const int32_t *ops5, int32_t count, int32_t unit, int32_t balance, int32_t *levels_out) {
+static int test_build_ops(const int32_t *ops5, int32_t count, std::vector<PendingOp> &ops) {
     // ops5[i] = {kind, dst, a, b, c}; ASAP levels are derived here exactly as the recorder derives them
-    std::vector<PendingOp> ops((size_t)count);
+    ops.resize((size_t)count);
     std::vector<int32_t> slot_level;
     int depth = 0;
     auto level_of = [&](int32_t s) { return s >= 0 && (size_t)s < slot_level.size() ? slot_level[s] : 0; };
@@ -694,10 +731,33 @@ int tfhe_hip_test_schedule(const int32_t *ops5, int32_t count, int32_t unit, int
         depth = std::max(depth, op.level);
         ops[i] = op;
     }
+    return depth;
+}
+
+int tfhe_hip_test_schedule(const int32_t *ops5, int32_t count, int32_t unit, int32_t balance, int32_t *levels_out) {
+    std::vector<PendingOp> ops;
+    const int depth = test_build_ops(ops5, count, ops);
     std::vector<int32_t> lvl;
     const int d = schedule_levels(ops, depth, balance != 0, unit, lvl);
     for (int32_t i = 0; i < count; ++i) levels_out[i] = lvl[i];
     return d;
+}
+
+int tfhe_hip_test_assign_lanes(const int32_t *ops5, int32_t count, int32_t unit, int32_t tight_slack, int32_t *lanes_out) {
+    std::vector<PendingOp> ops;
+    const int depth = test_build_ops(ops5, count, ops);
+    std::vector<int32_t> lvl, alap;
+    const int d = schedule_levels(ops, depth, true, unit, lvl, &alap);
+    std::vector<uint8_t> lane;
+    assign_lanes(ops, alap, tight_slack, lane);
+    for (int32_t i = 0; i < count; ++i) lanes_out[i] = lane[i];
+    return d;
+}
+
+double tfhe_hip_test_lane_probe(const TFheGateBootstrappingCloudKeySet *bk, int32_t lanes, int32_t levels, int32_t width) {
+    if (!bk || !bk->bk) { set_error("lane_probe: null keyset"); return -1.0; }
+    pool_of_key(bk);
+    return Engine::get().run_lane_probe(bk->bk->dev, lanes, levels, width);
 }
 
 int tfhe_hip_kernel_negacyclic(const TFheGateBootstrappingCloudKeySet *bk, const int32_t *ip, const Torus32 *tp,

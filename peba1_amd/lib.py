@@ -48,7 +48,8 @@ class SecretKeySet(C.Structure):
 class Stats(C.Structure):
     _fields_ = [("blind_rotates", C.c_uint64), ("keyswitches", C.c_uint64), ("linear_ops", C.c_uint64),
                 ("levels", C.c_uint64), ("flushes", C.c_uint64), ("br_launches", C.c_uint64),
-                ("ms_blind_rotate", C.c_double), ("ms_keyswitch", C.c_double), ("ms_flush_wall", C.c_double)]
+                ("ms_blind_rotate", C.c_double), ("ms_keyswitch", C.c_double), ("ms_flush_wall", C.c_double),
+                ("ms_blind_rotate_busy", C.c_double)]
 
 
 PS = C.POINTER(ParameterSet)
@@ -86,6 +87,8 @@ SIGNATURES = {
     "new_tfheGateBootstrappingSecretKeySet_fromFile": (SK, [C.c_void_p]),
     "export_gate_bootstrapping_ciphertext_toFile": (None, [C.c_void_p, LS, PS]),
     "import_gate_bootstrapping_ciphertext_fromFile": (None, [C.c_void_p, LS, PS]),
+    "tfhe_hip_test_assign_lanes": (C.c_int, [I32P, C.c_int32, C.c_int32, C.c_int32, I32P]),
+    "tfhe_hip_test_lane_probe": (C.c_double, [CK, C.c_int32, C.c_int32, C.c_int32]),
     "tfhe_hip_last_error": (C.c_char_p, []),
     "tfhe_hip_clear_error": (None, []),
     "tfhe_hip_set_device": (C.c_int, [C.c_int]),

@@ -139,14 +139,16 @@ def test_sharded_match_over_rccl_world1(p128_keys):
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("fixture,circuit", [("function_f_digest.json", "function_f"),
-                                             ("function_f_fast_digest.json", "function_f_fast")])
-def test_function_f_ciphertexts_match_oracle_digest(p128_keys, fixture, circuit):
+@pytest.mark.parametrize("fixture,circuit,lanes", [("function_f_digest.json", "function_f", 1),
+                                                   ("function_f_fast_digest.json", "function_f_fast", 1),
+                                                   ("function_f_digest.json", "function_f", 2)])
+def test_function_f_ciphertexts_match_oracle_digest(p128_keys, fixture, circuit, lanes):
     """Whole-circuit ciphertext parity: a complete 2-slot Function_f (3,438 bootstrapped gates,
     incl. 24 XNOR + 48 MUX) on the GPU reproduces, bit for bit, the SHA-256 of the 24 output
     ciphertexts that the CPU oracle produced through the same circuit library
     (tests/golden/make_function_f_digest.py, ~10 CPU-minutes).  Same for the optimised DAG
-    (542 blind rotations incl. ANDNY/ANDYN and MUX full adders)."""
+    (542 blind rotations incl. ANDNY/ANDYN and MUX full adders), and for the experimental
+    two-lane execution (urgent gates and the rest on two streams)."""
     import hashlib
     import json
     from types import SimpleNamespace
@@ -166,12 +168,18 @@ def test_function_f_ciphertexts_match_oracle_digest(p128_keys, fixture, circuit)
     bound = circuits.encrypt_number(pp, g["bound"], 3 * bits, ks)
     rb = api.CiphertextArray(pp, 3 * bits)
     api.reset_stats()
+    api.set_tuning("lanes", lanes)
+    api.set_tuning("tight_slack", 8)
     api.set_deferred(True)
     try:
         getattr(circuits, circuit)(rb, SimpleNamespace(slots=S), SimpleNamespace(slots=T), bound, bits, ks)
         api.flush()
     finally:
         api.set_deferred(False)
+        api.set_tuning("lanes", 1)
+        api.set_tuning("tight_slack", 64)
+    if lanes > 1:
+        assert api.stats()["br_launches"] > api.stats()["levels"]      # both lanes really launched
     assert api.stats()["blind_rotates"] == g["blind_rotates"]
     words = rb.words()
     assert hashlib.sha256(words[0].tobytes()).hexdigest() == g["result_b0_sha256"]
