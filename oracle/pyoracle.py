@@ -174,11 +174,12 @@ class KeySet:
                         int(use_ntt))
         return out
 
-    def gate_batch(self, name, ca, cb, nthreads=1):
+    def gate_batch(self, name, ca, cb, nthreads=1, use_ntt=2):
+        """use_ntt=3 is the approximate fp64-FFT stand-in for upstream's CPU path (not the oracle)."""
         ca = np.ascontiguousarray(ca, dtype=np.int32)
         cb = np.ascontiguousarray(cb, dtype=np.int32)
         out = np.zeros_like(ca)
-        lib().orc_gate2_batch(self.h, GATES[name], _p(out), _p(ca), _p(cb), ca.shape[0], nthreads)
+        lib().orc_gate2_batch_mode(self.h, GATES[name], _p(out), _p(ca), _p(cb), ca.shape[0], nthreads, int(use_ntt))
         return out
 
     def mux(self, a, b, c, use_ntt=True):

@@ -369,6 +369,86 @@ static void negacyclic_mul_bits_add(Torus32 *res, const Torus32 *a, const int32_
     }
 }
 
+/* ---------------------------------------------------------------------------
+ * fp64 FFT evaluator (use_ntt = 3): upstream TFHE's way of multiplying, restated as a plain
+ * radix-2 transform.  A real polynomial mod X^N+1 is folded into N/2 complex points
+ * z_j = (p_j + i p_{j+N/2}) w^j, w = exp(i pi / N), whose DFT of size N/2 gives the values at
+ * the roots x with x^{N/2} = i; products are pointwise there.  Approximate (see header).
+ * ------------------------------------------------------------------------- */
+typedef struct FftTab { int32_t N; double *cr, *ci, *tr, *ti; } FftTab;   /* FFT twiddles, twist */
+static FftTab g_fft_tabs[ORC_MAX_TABS];
+static int g_fft_ntabs = 0;
+static pthread_mutex_t g_fft_mtx = PTHREAD_MUTEX_INITIALIZER;
+
+static const FftTab *fft_tab(int32_t N) {
+    pthread_mutex_lock(&g_fft_mtx);
+    for (int i = 0; i < g_fft_ntabs; ++i)
+        if (g_fft_tabs[i].N == N) { pthread_mutex_unlock(&g_fft_mtx); return &g_fft_tabs[i]; }
+    if (g_fft_ntabs == ORC_MAX_TABS) abort();     /* more distinct ring degrees than this test helper expects */
+    FftTab *t = &g_fft_tabs[g_fft_ntabs];
+    const int32_t M = N / 2;
+    const double pi = 3.14159265358979323846;
+    t->N = N;
+    t->cr = (double *)malloc(sizeof(double) * M * 2);  t->ci = t->cr + M;      /* exp(-2 pi i k / M), k < M/2 used */
+    t->tr = (double *)malloc(sizeof(double) * M * 2);  t->ti = t->tr + M;      /* exp(i pi j / N) */
+    for (int32_t k = 0; k < M; ++k) {
+        t->cr[k] = cos(2.0 * pi * k / M);  t->ci[k] = -sin(2.0 * pi * k / M);
+        t->tr[k] = cos(pi * k / N);        t->ti[k] = sin(pi * k / N);
+    }
+    ++g_fft_ntabs;
+    pthread_mutex_unlock(&g_fft_mtx);
+    return t;
+}
+/* forward: natural order in, bit-reversed order out (decimation in frequency) */
+static void fft_fwd(double *re, double *im, const FftTab *t) {
+    const int32_t M = t->N / 2;
+    for (int32_t h = M / 2, step = 1; h >= 1; h >>= 1, step <<= 1)
+        for (int32_t b = 0; b < M; b += 2 * h)
+            for (int32_t j = 0; j < h; ++j) {
+                const double wr = t->cr[j * step], wi = t->ci[j * step];
+                const double ur = re[b + j], ui = im[b + j], vr = re[b + j + h], vi = im[b + j + h];
+                re[b + j] = ur + vr;  im[b + j] = ui + vi;
+                const double dr = ur - vr, di = ui - vi;
+                re[b + j + h] = dr * wr - di * wi;  im[b + j + h] = dr * wi + di * wr;
+            }
+}
+/* inverse: bit-reversed in, natural out (decimation in time, conjugate twiddles), unscaled */
+static void fft_inv(double *re, double *im, const FftTab *t) {
+    const int32_t M = t->N / 2;
+    for (int32_t h = 1, step = M / 2; h < M; h <<= 1, step >>= 1)
+        for (int32_t b = 0; b < M; b += 2 * h)
+            for (int32_t j = 0; j < h; ++j) {
+                const double wr = t->cr[j * step], wi = -t->ci[j * step];
+                const double xr = re[b + j + h], xi = im[b + j + h];
+                const double vr = xr * wr - xi * wi, vi = xr * wi + xi * wr;
+                const double ur = re[b + j], ui = im[b + j];
+                re[b + j] = ur + vr;  im[b + j] = ui + vi;
+                re[b + j + h] = ur - vr;  im[b + j + h] = ui - vi;
+            }
+}
+static void fft_from_i32(double *re, double *im, const int32_t *p, const FftTab *t) {
+    const int32_t M = t->N / 2;
+    for (int32_t j = 0; j < M; ++j) {
+        const double a = (double)p[j], b = (double)p[j + M];
+        re[j] = a * t->tr[j] - b * t->ti[j];
+        im[j] = a * t->ti[j] + b * t->tr[j];
+    }
+    fft_fwd(re, im, t);
+}
+/* acc[j] += round(value_j) mod 2^32 */
+static void fft_add_to_torus(uint32_t *acc, double *re, double *im, const FftTab *t) {
+    const int32_t M = t->N / 2;
+    fft_inv(re, im, t);
+    const double sc = 1.0 / M;
+    for (int32_t j = 0; j < M; ++j) {
+        const double zr = re[j] * sc, zi = im[j] * sc;
+        const double a = zr * t->tr[j] + zi * t->ti[j];          /* times conj(w^j) */
+        const double b = zi * t->tr[j] - zr * t->ti[j];
+        acc[j] += (uint32_t)(int64_t)llround(a);
+        acc[j + M] += (uint32_t)(int64_t)llround(b);
+    }
+}
+
 OrcKeySet *orc_keygen(const OrcParams *p, uint64_t seed) {
     OrcKeySet *ks = (OrcKeySet *)calloc(1, sizeof(OrcKeySet));
     ks->p = *p;
@@ -429,6 +509,14 @@ OrcKeySet *orc_keygen(const OrcParams *p, uint64_t seed) {
                 for (int32_t j = 0; j < N; ++j) dst[j] = (uint32_t)((uint64_t)dst[j] * ft->scale[pr] % FP[pr]);
             }
     }
+    /* fp64 FFT image for the approximate evaluator (use_ntt = 3) */
+    {
+        const FftTab *ft = fft_tab(N);
+        const size_t npoly_f = (size_t)n * kpl * (k + 1);
+        ks->bk_fft = (double *)malloc(sizeof(double) * npoly_f * N);
+        for (size_t qq = 0; qq < npoly_f; ++qq)
+            fft_from_i32(ks->bk_fft + qq * N, ks->bk_fft + qq * N + N / 2, ks->bk + qq * N, ft);
+    }
     /* evaluation-domain image of BK (tfhe: LweBootstrappingKeyFFT) */
     const NttTab *tab = ntt_tab(N);
     const size_t npoly = (size_t)n * kpl * (k + 1);
@@ -444,7 +532,7 @@ OrcKeySet *orc_keygen(const OrcParams *p, uint64_t seed) {
 
 void orc_keyset_free(OrcKeySet *ks) {
     if (!ks) return;
-    free(ks->lwe_key); free(ks->tlwe_key); free(ks->bk); free(ks->ksk); free(ks->bk_ntt); free(ks->bk_fast);
+    free(ks->lwe_key); free(ks->tlwe_key); free(ks->bk); free(ks->ksk); free(ks->bk_ntt); free(ks->bk_fast); free(ks->bk_fft);
     free(ks);
 }
 
@@ -524,7 +612,26 @@ void orc_cmux_rotate(const OrcKeySet *ks, int32_t i, int32_t barai, Torus32 *acc
         mul_xai_minus_one(d + (size_t)u * N, barai, acc + (size_t)u * N, N);
         orc_decompose(dig + (size_t)u * l * N, d + (size_t)u * N, p);
     }
-    if (use_ntt == 2) {
+    if (use_ntt == 3) {
+        const FftTab *ft = fft_tab(N);
+        const int32_t M = N / 2;
+        double *dn = (double *)malloc(sizeof(double) * (size_t)(kpl + 1) * N);
+        double *sr = dn + (size_t)kpl * N, *si = sr + M;
+        for (int32_t q = 0; q < kpl; ++q) fft_from_i32(dn + (size_t)q * N, dn + (size_t)q * N + M, dig + (size_t)q * N, ft);
+        for (int32_t w = 0; w <= k; ++w) {
+            for (int32_t j = 0; j < M; ++j) { sr[j] = 0.0; si[j] = 0.0; }
+            for (int32_t q = 0; q < kpl; ++q) {
+                const double *br = ks->bk_fft + (((size_t)i * kpl + q) * (k + 1) + w) * N, *bi = br + M;
+                const double *xr = dn + (size_t)q * N, *xi = xr + M;
+                for (int32_t j = 0; j < M; ++j) {
+                    sr[j] += xr[j] * br[j] - xi[j] * bi[j];
+                    si[j] += xr[j] * bi[j] + xi[j] * br[j];
+                }
+            }
+            fft_add_to_torus((uint32_t *)(acc + (size_t)w * N), sr, si, ft);
+        }
+        free(dn);
+    } else if (use_ntt == 2) {
         const FastTab *ft = fast_tab(N);
         uint32_t *dn = (uint32_t *)malloc(sizeof(uint32_t) * (size_t)(kpl + 2 * (k + 1)) * N);
         uint32_t *res = dn + (size_t)kpl * N;                 /* [prime][k+1][N] canonical residues */
@@ -715,27 +822,34 @@ void orc_constant(const OrcParams *p, Torus32 *out, int32_t value) {
 typedef struct BatchJob {
     const OrcKeySet *ks; int gate; Torus32 *out; const Torus32 *ca, *cb;
     int32_t begin, end;
+    int mode;
 } BatchJob;
 
 static void *batch_worker(void *arg) {
     BatchJob *j = (BatchJob *)arg;
     const size_t w = (size_t)j->ks->p.n + 1;
     for (int32_t g = j->begin; g < j->end; ++g)
-        orc_gate2(j->ks, j->gate, j->out + g * w, j->ca + g * w, j->cb + g * w, 2);
+        orc_gate2(j->ks, j->gate, j->out + g * w, j->ca + g * w, j->cb + g * w, j->mode);
     return NULL;
 }
 
 void orc_gate2_batch(const OrcKeySet *ks, int gate, Torus32 *out, const Torus32 *ca, const Torus32 *cb,
                      int32_t count, int32_t nthreads) {
+    orc_gate2_batch_mode(ks, gate, out, ca, cb, count, nthreads, 2);
+}
+
+void orc_gate2_batch_mode(const OrcKeySet *ks, int gate, Torus32 *out, const Torus32 *ca, const Torus32 *cb,
+                          int32_t count, int32_t nthreads, int use_ntt) {
     if (nthreads < 1) nthreads = 1;
     if (nthreads > count) nthreads = count > 0 ? count : 1;
     (void)fast_tab(ks->p.N);
+    (void)fft_tab(ks->p.N);
     pthread_t *th = (pthread_t *)malloc(sizeof(pthread_t) * nthreads);
     BatchJob *jobs = (BatchJob *)malloc(sizeof(BatchJob) * nthreads);
     for (int32_t t = 0; t < nthreads; ++t) {
         jobs[t] = (BatchJob){ks, gate, out, ca, cb,
                              (int32_t)((int64_t)count * t / nthreads),
-                             (int32_t)((int64_t)count * (t + 1) / nthreads)};
+                             (int32_t)((int64_t)count * (t + 1) / nthreads), use_ntt};
         pthread_create(&th[t], NULL, batch_worker, &jobs[t]);
     }
     for (int32_t t = 0; t < nthreads; ++t) pthread_join(th[t], NULL);

@@ -70,6 +70,7 @@ typedef struct OrcKeySet {
     Torus32  *ksk;       /* [kN][t][base][n+1]   row 0 of each digit is zero */
     uint64_t *bk_ntt;    /* [n][(k+1)l][k+1][N]  Goldilocks NTT image of bk  */
     uint32_t *bk_fast;   /* [n][(k+1)l][k+1][2][N] two-prime Montgomery image  */
+    double   *bk_fft;    /* [n][(k+1)l][k+1][re N/2 | im N/2] fp64 FFT image (use_ntt = 3 only) */
 } OrcKeySet;
 
 OrcKeySet *orc_keygen(const OrcParams *p, uint64_t seed);
@@ -86,7 +87,11 @@ int32_t orc_decrypt_bit(const OrcKeySet *ks, const Torus32 *ct);
 int32_t orc_modswitch(Torus32 x, int32_t Msize);              /* step 2 */
 Torus32 orc_modswitch_to_torus(int32_t mu, int32_t Msize);
 /* use_ntt arguments below: 0 = schoolbook, 1 = Goldilocks NTT, 2 = two 27-bit primes + CRT
- * (vectorisable; used by the cpu_baseline).  All three give the same words. */
+ * (vectorisable; used by the cpu_baseline).  All three give the same words.
+ * 3 = fp64 FFT, the way upstream TFHE multiplies (folded N/2-point complex transform):
+ * APPROXIMATE, NOT the oracle -- low-order noise bits differ from the exact modes; it exists
+ * only as a cost-faithful stand-in for upstream's CPU path in bench.py's cpu_baseline note
+ * and is checked at decrypt level. */
 /* exact negacyclic product res = ip * tp mod (X^N+1) mod 2^32, schoolbook */
 void orc_negacyclic_schoolbook(Torus32 *res, const int32_t *ip, const Torus32 *tp, int32_t N);
 /* same product through the Goldilocks NTT (must equal the schoolbook)      */
@@ -122,6 +127,9 @@ void orc_constant(const OrcParams *p, Torus32 *out, int32_t value);
 /* many independent 2-input gates on `nthreads` host threads (cpu_baseline) */
 void orc_gate2_batch(const OrcKeySet *ks, int gate, Torus32 *out, const Torus32 *ca, const Torus32 *cb,
                      int32_t count, int32_t nthreads);
+/* same with an explicit evaluator (use_ntt as above; 3 = the approximate fp64-FFT stand-in) */
+void orc_gate2_batch_mode(const OrcKeySet *ks, int gate, Torus32 *out, const Torus32 *ca, const Torus32 *cb,
+                          int32_t count, int32_t nthreads, int use_ntt);
 
 #ifdef __cplusplus
 }

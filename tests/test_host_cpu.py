@@ -90,6 +90,11 @@ def test_oracle_truth_tables_small_params(oracle):
                 assert (o == ks.gate(name, ca, cb, use_ntt=False)).all()      # Goldilocks == schoolbook
                 assert (o == ks.gate(name, ca, cb, use_ntt=2)).all()          # == two-prime evaluator
                 assert ks.decrypt(o)[0] == f(a, b)
+                # the fp64-FFT stand-in (cpu_baseline note only, not an oracle): same plaintext,
+                # phase within a hair of the exact one
+                approx = ks.gate(name, ca, cb, use_ntt=3)
+                assert ks.decrypt(approx)[0] == f(a, b)
+                assert abs(int(ks.phase(approx)) - int(ks.phase(o))) < 2 ** 12
     for a in (0, 1):
         for b in (0, 1):
             for c in (0, 1):

@@ -7,13 +7,13 @@ from peba1_amd import api, lib
 def main():
     L = lib.load()
     args = sys.argv[1:]
-    p2048 = "--p2048" in args
-    args = [a for a in args if a != "--p2048"]
-    pp = api.ParameterSet(p2048=True) if p2048 else api.ParameterSet(128)
+    p2048, p80 = "--p2048" in args, "--p80" in args
+    args = [a for a in args if a not in ("--p2048", "--p80")]
+    pp = api.ParameterSet(p2048=True) if p2048 else api.ParameterSet(80 if p80 else 128)
     print(f"params n={pp.n} N={pp.N} l={pp.l} Bgbit={pp.Bgbit}", flush=True)
     t = time.time(); ks = api.SecretKeySet(pp, 0x5EBA2); print("keygen+upload s", time.time() - t, flush=True)
     rng = np.random.default_rng(0)
-    sizes = [int(s) for s in (args or ["64", "256", "1024", "2048", "4096"])]
+    sizes = [int(s) for s in (args or ["1", "16", "256", "1024", "4096"])]
     G = max(sizes)
     a = api.CiphertextArray(pp, G).encrypt(rng.integers(0, 2, G), ks)
     b = api.CiphertextArray(pp, G).encrypt(rng.integers(0, 2, G), ks)
