@@ -315,3 +315,31 @@ def test_server_side_evaluation_from_files(p128_keys, oracle, tmp_path):
     # the session keyset still works after the loaded one is released
     api.gate_batch("OR", back, a, b, ks)
     assert back.decrypt(ks).tolist() == [x | y for x, y in zip(abits, bbits)]
+
+
+def test_edge_cases_empty_ragged_and_wide(p128_keys, oracle):
+    """Empty batches and flushes are no-ops; a bad gate code is refused; a batch wider than one
+    key-switch chunk (8192 gates: tiled key switch in two chunks, blind rotate in 17 rounds)
+    still matches the oracle gate by gate (sampled) and the truth table everywhere."""
+    from peba1_amd import api, lib
+    pp, ks, oks = p128_keys
+    L = lib.load()
+    e = api.CiphertextArray(pp, 1)
+    assert L.tfhe_hip_gate_batch(api.GATE_CODES["AND"], e.ptr, e.ptr, e.ptr, 0, ks.cloud) == 0
+    assert api.flush() == 0
+    assert L.tfhe_hip_gate_batch(99, e.ptr, e.ptr, e.ptr, 1, ks.cloud) == -1
+    assert b"bad gate code" in L.tfhe_hip_last_error()
+    assert L.tfhe_hip_export_samples(e.ptr, 0, pp.ptr, None) == 0
+    # wide batch
+    G = 8192 + 37
+    rng = np.random.default_rng(8192)
+    abits, bbits = rng.integers(0, 2, G), rng.integers(0, 2, G)
+    L.tfhe_hip_set_encrypt_seed(4242)
+    a = api.CiphertextArray(pp, G).encrypt(abits, ks)
+    b = api.CiphertextArray(pp, G).encrypt(bbits, ks)
+    res = api.CiphertextArray(pp, G)
+    api.gate_batch("ORNY", res, a, b, ks)
+    assert (res.decrypt(ks) == ((1 - abits) | bbits)).all()
+    wa, wb, got = a.words(), b.words(), res.words()
+    for i in (0, 15, 16, 8191, 8192, G - 1):
+        assert (got[i] == oks.gate("ORNY", wa[i], wb[i])).all(), i
