@@ -1,26 +1,32 @@
 // kernels.hip -- hand-written gfx950 kernels of the bootstrapped-gate path.
 //
-//   K6 bk_transform_kernel   Torus32 bootstrapping key -> NTT image (once per key)
-//   K1+K2 blind_rotate_kernel  gate prelude, modulus switch, blind rotate
-//                              (n external products), sample extract
-//   K3/K4 keyswitch_kernel   (u0 [+ u1] + const) -> LWE sample under the gate key
-//   K5 not_kernel            negation
+//   K6    bk_transform_kernel     Torus32 bootstrapping key -> NTT image (once per key)
+//   K1+K2 blind_rotate4_kernel    gate prelude, modulus switch, blind rotate (n external
+//                                 products), sample extract; four wave64 per rotation (default)
+//         blind_rotate_kernel     the same with two wave64 per rotation (selectable, tested)
+//   K3/K4 keyswitch_tile_kernel   (u0 [+ u1] + const) -> LWE sample under the gate key, one pass
+//                                 over the KSK rows of a coefficient range serves 16 gates
+//         keyswitch_kernel        per-gate form for narrow launches; ks_reduce_kernel adds the
+//                                 partial sums of the ranges
+//   K5    not_kernel              negation
+//         gate_dataflow_kernel    experimental: a whole gate DAG in one persistent launch
+//         gather/scatter_slots    packed words <-> ciphertext pool (import, export, collectives)
 //
 // Restates (does not translate) tfhe's tfhe_bootstrap_woKS_FFT / tfhe_blindRotate_FFT
 // / tGswFFTExternMulToTLwe / lweKeySwitch as described in SURVEY.md Appendix A.3;
 // reference call sites: /root/reference/src/Math.cpp:34-43 (every bootsXOR/bootsAND).
 //
-// All kernels are templates on LOGN (N = 1024: TFHE's 128-bit set, N = 2048: BASELINE
-// configs[4]); 16 or 32 coefficients per lane.
-// Mapping of the 2-wave form (k = 1): one workgroup of two wave64 per blind rotation, wave
-// q does all arithmetic modulo prime q.  The accumulator (2 x 1024 Torus32) lives
-// in LDS for the whole n-step loop; per step a wave reads the rotated
-// accumulator, extracts gadget digits, runs 6 forward NTTs (ntt_wave.hpp),
-// multiply-accumulates against the streamed key image in 64-bit
-// (v_mad_u64_u32), runs 2 inverse NTTs, swaps one residue polynomial with its
-// partner wave and CRT-recombines the polynomial it owns.  Two workgroup
-// barriers per step.  The key image is read with 16-byte-per-lane coalesced
-// loads (1 KiB per wave instruction), 48 KiB per wave per step.
+// All ring kernels are templates on LOGN (N = 1024: TFHE's parameter sets, N = 2048: BASELINE
+// configs[4]); 16 or 32 coefficients per lane.  The accumulator (2 x N Torus32) lives in LDS
+// for the whole n-step loop.
+// 4-wave form: wave (q, u) works modulo prime q on input polynomial u -- per step the rotated
+// accumulator, gadget digits, l forward NTTs (ntt_wave.hpp), 64-bit multiply-accumulate
+// against the streamed key image (v_mad_i64_i32; 16-byte-per-lane coalesced loads, 1 KiB per
+// wave instruction), partial sum of the other output polynomial to wave (q, 1-u) through LDS,
+// one inverse NTT, half of the residues swapped with wave (1-q, u), CRT.  Three workgroup
+// barriers per step.
+// 2-wave form: wave q does all arithmetic modulo prime q (2l forward and 2 inverse NTTs per
+// step), swaps one residue polynomial with its partner and CRT-recombines the one it owns.
 #include "kernels.hpp"
 #include "ntt_wave.hpp"
 
