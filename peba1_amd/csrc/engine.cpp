@@ -392,6 +392,17 @@ void Engine::execute(const DeviceKeyImage *key, SlotPool *pool, const LevelPlan 
             if (nrot) ++stats.br_launches;
         }
     }
+    if (const char *trace = std::getenv("TFHE_HIP_TRACE_LEVELS")) {   // diagnostic: rotations per (level, lane)
+        if (FILE *f = std::fopen(trace, "a")) {
+            std::fprintf(f, "flush levels=%d lanes=%d\n", levels, K);
+            for (int L = 1; L <= levels; ++L)
+                for (int s = 0; s < K; ++s) {
+                    const size_t gg = (size_t)(L - 1) * K + s;
+                    std::fprintf(f, "%d %d %d\n", L, s, plan.rot_off[gg + 1] - plan.rot_off[gg]);
+                }
+            std::fclose(f);
+        }
+    }
     hip_check(hipGetLastError(), "kernel launch");
     if (K > 1 && last_group[1] >= 0) hip_check(hipStreamWaitEvent(stream_, order_events_[last_group[1]], 0), "join lanes");
     hip_check(hipStreamSynchronize(stream_), "level execution");

@@ -123,25 +123,47 @@ int schedule_levels(const std::vector<PendingOp> &ops, int asap_depth, bool bala
 
     std::priority_queue<HeapItem, std::vector<HeapItem>, std::greater<HeapItem>> heap;
     std::vector<int32_t> batch;
+    // rotations not yet scheduled, by deadline (ALAP level)
+    std::vector<long long> due(asap_depth + 2, 0);
+    for (int i = 0; i < n; ++i) due[alap[i]] += op_rotations(ops[i]);
     for (int L = 1; L <= asap_depth; ++L) {
         for (int32_t i : avail[L]) heap.push(HeapItem{alap[i], i});
         const long long levels_left = asap_depth - L + 1;
-        long long cap;
-        if (remaining <= (long long)unit * levels_left) cap = unit;
-        else if (remaining <= 2LL * unit * levels_left) cap = 2LL * unit;
-        else if (remaining <= 4LL * unit * levels_left) cap = 4LL * unit;
-        else cap = ((remaining + levels_left - 1) / levels_left + 4LL * unit - 1) / (4LL * unit) * (4LL * unit);
+        // Width policy.  A launch costs by occupancy steps (MI355X, P128: up to 1 workgroup per
+        // CU 4.2 ms, up to 2 per CU 6.5 ms, then 10.1 and 12.6 ms for 3 and 4 units), so the
+        // cheap widths are exactly 1x `unit` for a level that could not be wider anyway and
+        // multiples of 2x `unit`; a width just above a multiple of 2x `unit` is the worst buy.
+        // Base width: `unit` once the remaining work fits in one unit per remaining level, else
+        // 2 units.  The base is doubled only when the deadlines demand it: if for some future
+        // level D the rotations due by D exceed what base-wide levels L..D can hold (earliest-
+        // deadline-first feasibility), some level must be wider, and a full double-width level
+        // now is cheaper than forced overflows later.
+        const long long base = remaining <= (long long)unit * levels_left ? unit : 2LL * unit;
+        long long cap = base, running = 0, excess = 0;
+        const int horizon = std::min(asap_depth, L + 1023);     // bounded look-ahead keeps deep DAGs cheap
+        for (int D = L; D <= horizon; ++D) {
+            running += due[D];
+            excess = std::max(excess, running - base * (long long)(D - L + 1));
+        }
+        while (excess > cap - base && cap < 16LL * unit) cap *= 2;
         long long width = 0;
         batch.clear();
-        while (!heap.empty()) {
-            const HeapItem top = heap.top();
-            const int w = op_rotations(ops[top.idx]);
-            if (top.alap > L && width + w > cap) break;
-            heap.pop();
-            lvl[top.idx] = L;
-            width += w;
-            batch.push_back(top.idx);
-        }
+        auto take = [&](long long limit, bool forced_only) {
+            while (!heap.empty()) {
+                const HeapItem top = heap.top();
+                const int w = op_rotations(ops[top.idx]);
+                if (top.alap > L && (forced_only || width + w > limit)) break;
+                heap.pop();
+                lvl[top.idx] = L;
+                width += w;
+                due[top.alap] -= w;
+                batch.push_back(top.idx);
+            }
+        };
+        take(cap, false);
+        // gates at their deadline overflowed the width: round it up to the next multiple of
+        // two units and fill that with slack gates (the second half of an occupancy step is cheap)
+        if (width > cap) take((width + 2LL * unit - 1) / (2LL * unit) * (2LL * unit), false);
         remaining -= width;
         for (int32_t i : batch) release_successors(i, L, release_successors);
     }
