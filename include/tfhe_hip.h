@@ -92,6 +92,9 @@ int tfhe_hip_gate_batch(int gate, LweSample *result, const LweSample *a, const L
  * "ks_tile": 16 (default) or 32 = launches of at least 2*tile key switches use the tiled
  * kernel (a workgroup streams the KSK rows of one range once for `tile` gates); 0 = always
  * one workgroup per (gate, range); env TFHE_HIP_KS_TILE.
+ * "br_fair": k > 0 (default 18, env TFHE_HIP_BR_FAIR) = in launches that put two blind-rotate
+ * workgroups on a CU, the two swap wave issue priority every 2^k shader cycles so that both
+ * finish together; 0 = leave it to the hardware's oldest-first arbitration.
  * "balance_levels": 1 (default) = slack-aware level filling at flush, 0 = plain ASAP
  * levels.
  * "dataflow": 0 (default) = one blind-rotate + one key-switch launch per level; 1 (env
@@ -133,6 +136,9 @@ int tfhe_hip_test_assign_lanes(const int32_t *ops5, int32_t count, int32_t unit,
 /* Diagnostic (tools/lane_probe.py): `levels` rounds of (blind rotate + key switch) over `width`
  * random gates, issued as `lanes` independent chains on `lanes` HIP streams; returns the wall
  * time in ms (negative on error).  Measures what overlapping level-synchronous chains could gain. */
+/* Diagnostic: one blind-rotate launch of `width` random gates; times2[2i], times2[2i+1] = the
+ * shader clock (s_memtime, 100 MHz) at the start and end of workgroup i. */
+int tfhe_hip_test_wg_times(const TFheGateBootstrappingCloudKeySet *bk, int32_t width, uint64_t *times2);
 double tfhe_hip_test_lane_probe(const TFheGateBootstrappingCloudKeySet *bk, int32_t lanes, int32_t levels, int32_t width);
 
 /* ---- kernel-level entry points (K2/K3 parity tests against the oracle) ---- */

@@ -95,6 +95,7 @@ void Engine::ensure_init() {
         hip_check(hipStreamCreateWithPriority(&stream_, hipStreamNonBlocking, greatest), "hipStreamCreate");
     }
     if (const char *env = std::getenv("TFHE_HIP_LANE_PRIO")) lane_prio = std::atoi(env);
+    if (const char *env = std::getenv("TFHE_HIP_BR_FAIR")) br_fair = std::atoi(env);
     for (auto &e : ev_) hip_check(hipEventCreate(&e), "hipEventCreate");
     inited_ = true;
 }
@@ -149,6 +150,9 @@ static DevParams make_dev_params(const Params &p) {
     d.decomp_offset = p.decomp_offset(); d.ks_prec_offset = p.ks_prec_offset();
     d.mu = 1 << 29;
     d.wave_prio = 0;
+    d.fair_shift = 0;
+    d.cu_arrivals = nullptr;
+    d.wg_times = nullptr;
     return d;
 }
 
@@ -274,6 +278,15 @@ void Engine::launch_br(const DeviceKeyImage *key, const int32_t *pool, const Rot
     if (count <= br4_max_rotations) {
         DevParams dp = key->dp;
         dp.wave_prio = wave_prio;
+        if (br_fair > 0 && count > cu_count_ && dp.N <= 1024) {   // only launches that put two workgroups on a CU
+            if (!cu_arrivals_) {
+                hip_check(hipMalloc(&cu_arrivals_, 4096 * sizeof(uint32_t)), "hipMalloc(cu arrivals)");
+                hip_check(hipMemset(cu_arrivals_, 0, 4096 * sizeof(uint32_t)), "hipMemset(cu arrivals)");
+            }
+            dp.fair_shift = br_fair;
+            dp.cu_arrivals = cu_arrivals_;
+        }
+        dp.wg_times = wg_times_dbg_;
         launch_blind_rotate4(stream, dp, key->key, pool, rots, count, u_buf, acc_dbg);
         return;
     }
@@ -535,7 +548,7 @@ void Engine::run_keyswitch(const DeviceKeyImage *key, const Torus32 *u, int coun
     stats.keyswitches += (uint64_t)count;
 }
 
-double Engine::run_lane_probe(const DeviceKeyImage *key, int lanes, int levels, int width) {
+double Engine::run_lane_probe(const DeviceKeyImage *key, int lanes, int levels, int width, unsigned long long *wg_times) {
     const DevParams &dp = key->dp;
     lanes = std::max(1, std::min(lanes, 8));
     const int per = width / lanes;
@@ -563,6 +576,18 @@ double Engine::run_lane_probe(const DeviceKeyImage *key, int lanes, int levels, 
         hip_check(hipStreamCreateWithFlags(&st[s], hipStreamNonBlocking), "probe stream");
         ubuf[s] = static_cast<int32_t *>(scratch(50 + (size_t)s, (size_t)(per + 1) * dp.u_stride * 4));
         (void)scratch(10 + (size_t)s, (size_t)per * ks_max_splits * dp.ct_stride * 4);   // no growth while running
+    }
+    unsigned long long *dtimes = nullptr;
+    if (wg_times) {                                      // one launch, per-workgroup start/end stamps
+        dtimes = static_cast<unsigned long long *>(scratch(43, (size_t)2 * width * 8));
+        wg_times_dbg_ = dtimes;
+        hip_check(hipDeviceSynchronize(), "probe sync");
+        launch_br(key, pool, drots, width, ubuf[0], nullptr, st[0]);
+        hip_check(hipStreamSynchronize(st[0]), "probe stamps");
+        wg_times_dbg_ = nullptr;
+        hip_check(hipMemcpy(wg_times, dtimes, (size_t)2 * width * 8, hipMemcpyDeviceToHost), "probe stamps copy");
+        for (int s = 0; s < lanes; ++s) hip_check(hipStreamDestroy(st[s]), "probe stream destroy");
+        return 0.0;
     }
     hip_check(hipDeviceSynchronize(), "probe sync");
     const auto t0 = std::chrono::steady_clock::now();

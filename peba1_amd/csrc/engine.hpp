@@ -110,6 +110,10 @@ public:
     // two-lane execution: 1 = the urgent lane's blind-rotate waves raise their issue priority
     // (measured slower: the co-resident workgroups of the other lane become its stragglers)
     int lane_prio = 0;
+    // blind rotate: k > 0 = the two workgroups sharing a CU swap issue priority every 2^k shader
+    // cycles (0 = off: the hardware's oldest-first issue runs one at full speed and leaves the
+    // other to finish alone with one wave per SIMD; measured optimum 2^16..2^20, tools/wg_times.py)
+    int br_fair = 18;
     // stream == nullptr: the engine's stream; lane selects the scratch buffer of the partial sums
     void launch_ks(const DeviceKeyImage *key, const int32_t *u_buf, const KsDesc *descs, int count, int32_t *pool,
                    hipStream_t stream = nullptr, int lane = 0);
@@ -117,7 +121,9 @@ public:
                    int32_t *acc_dbg, hipStream_t stream = nullptr, int wave_prio = 0);
     // diagnostic (tools/lane_probe.py): `levels` rounds of (blind rotate + key switch) of `width`
     // random gates in total, issued as `lanes` independent chains on `lanes` streams; returns ms
-    double run_lane_probe(const DeviceKeyImage *key, int lanes, int levels, int width);
+    // wg_times != nullptr: instead, ONE blind-rotate launch of `width` gates whose workgroups stamp
+    // s_memtime at start and end into wg_times[2 * width]
+    double run_lane_probe(const DeviceKeyImage *key, int lanes, int levels, int width, unsigned long long *wg_times = nullptr);
 
 private:
     Engine() = default;
@@ -126,6 +132,8 @@ private:
     int cu_count_ = 256;
     bool inited_ = false;
     hipStream_t stream_ = nullptr;
+    uint32_t *cu_arrivals_ = nullptr;
+    unsigned long long *wg_times_dbg_ = nullptr;        // set by the workgroup-time probe only
     hipStream_t lane_stream_[2] = {nullptr, nullptr};   // lane 0 = stream_, lane 1 created on first use
     std::vector<hipEvent_t> order_events_;              // cross-lane ordering, no timing
     std::vector<hipEvent_t> timing_events_;             // kernel_timing: 3 per (level, lane) + 1 base

@@ -353,7 +353,7 @@ struct Br4Lds {
 template <int LOGN>
 __device__ __forceinline__ void blind_rotate4_body(const DevParams &p, const DevKey &key,
                                                    const int32_t *__restrict__ pool, const RotDesc &rd,
-                                                   Br4Lds<LOGN> &sh, int tid) {
+                                                   Br4Lds<LOGN> &sh, int tid, int parity = 0) {
     using NTT = WaveNtt<LOGN>;
     constexpr int N = NTT::N, REGS = NTT::REGS, HALF = REGS / 2;
     const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -379,6 +379,13 @@ __device__ __forceinline__ void blind_rotate4_body(const DevParams &p, const Dev
     STAMP_DECL;
 
     for (int i = 0; i < n; ++i) {
+        if (p.fair_shift > 0) {
+            // time slices of 2^fair_shift shader cycles: both workgroups read the same CU clock,
+            // so exactly one of them holds the higher priority at any moment
+            const uint32_t slice = (uint32_t)(__builtin_amdgcn_s_memtime() >> p.fair_shift);
+            if ((slice ^ (uint32_t)parity) & 1u) __builtin_amdgcn_s_setprio(1);
+            else __builtin_amdgcn_s_setprio(0);
+        }
         const int abar = __builtin_amdgcn_readfirstlane((int)sh.bar[i]);
         if (abar == 0) continue;
         STAMP(0);
@@ -443,9 +450,33 @@ __global__ __launch_bounds__(256, LOGN == 10 ? 2 : 1) void blind_rotate4_kernel(
     // urgent lane: these waves win issue arbitration against a co-resident workgroup of the
     // other lane, so a critical-chain gate runs at nearly its stand-alone latency
     if (p.wave_prio) __builtin_amdgcn_s_setprio(3);
+    // Two workgroups share a CU, and the hardware issues oldest-wave-first: launched together,
+    // one runs at its stand-alone speed (4.1 ms) and the other gets the leftover issue slots,
+    // then finishes alone with one wave per SIMD (6.45 ms in all; tools/wg_times.py).  Letting
+    // the two swap issue priority every few steps keeps both at two waves per SIMD to the end.
+    int parity = 0;
+    if (p.fair_shift > 0) {
+        __shared__ int s_parity;
+        if (threadIdx.x == 0) {
+            const uint32_t hw = __builtin_amdgcn_s_getreg((31 << 11) | (0 << 6) | 4);    // HW_ID
+            const uint32_t xcc = __builtin_amdgcn_s_getreg((3 << 11) | (0 << 6) | 20);   // XCC_ID
+            const uint32_t cu = ((xcc & 0xFu) << 8) | ((hw >> 8) & 0xFFu);              // cu, sh, se
+            s_parity = (int)(atomicAdd(&p.cu_arrivals[cu], 1u) & 1u);
+        }
+        __syncthreads();
+        parity = __builtin_amdgcn_readfirstlane(s_parity);
+    }
+    if (p.wg_times && threadIdx.x == 0) {
+        // low 48 bits: shader clock; high 16 bits: XCC id and the CU / SH / SE fields of HW_ID
+        const uint64_t hw = __builtin_amdgcn_s_getreg((31 << 11) | (0 << 6) | 4);
+        const uint64_t xcc = __builtin_amdgcn_s_getreg((3 << 11) | (0 << 6) | 20);
+        p.wg_times[2 * blockIdx.x] = (__builtin_amdgcn_s_memtime() & 0xFFFFFFFFFFFFull) |
+                                     ((((xcc & 0xF) << 8) | ((hw >> 8) & 0xFF)) << 48);
+    }
     const RotDesc rd = rots[blockIdx.x];
-    blind_rotate4_body<LOGN>(p, key, pool, rd, sh, threadIdx.x);
+    blind_rotate4_body<LOGN>(p, key, pool, rd, sh, threadIdx.x, parity);
     extract_sample<LOGN, 256>(p, rd, sh.acc, u_buf, acc_dbg, threadIdx.x);
+    if (p.wg_times && threadIdx.x == 0) p.wg_times[2 * blockIdx.x + 1] = __builtin_amdgcn_s_memtime();
 }
 
 // ---------------------------------------------------------------------------

@@ -703,6 +703,7 @@ int tfhe_hip_set_tuning(const char *name, int64_t value) {
         Engine::get().ks_tile = (int)value;
         return 0;
     }
+    if (name && std::strcmp(name, "br_fair") == 0) { Engine::get().br_fair = (int)value; return 0; }
     if (name && std::strcmp(name, "balance_levels") == 0) { rec().balance_levels = value != 0; return 0; }
     if (name && std::strcmp(name, "lanes") == 0) { rec().lanes = value > 1 ? 2 : 1; return 0; }
     if (name && std::strcmp(name, "tight_slack") == 0) { rec().tight_slack = (int)value; return 0; }
@@ -758,6 +759,13 @@ double tfhe_hip_test_lane_probe(const TFheGateBootstrappingCloudKeySet *bk, int3
     if (!bk || !bk->bk) { set_error("lane_probe: null keyset"); return -1.0; }
     pool_of_key(bk);
     return Engine::get().run_lane_probe(bk->bk->dev, lanes, levels, width);
+}
+
+int tfhe_hip_test_wg_times(const TFheGateBootstrappingCloudKeySet *bk, int32_t width, uint64_t *times2) {
+    if (!bk || !bk->bk || !times2 || width <= 0) { set_error("wg_times: bad arguments"); return -1; }
+    pool_of_key(bk);
+    Engine::get().run_lane_probe(bk->bk->dev, 1, 1, width, reinterpret_cast<unsigned long long *>(times2));
+    return 0;
 }
 
 int tfhe_hip_kernel_negacyclic(const TFheGateBootstrappingCloudKeySet *bk, const int32_t *ip, const Torus32 *tp,
