@@ -343,3 +343,29 @@ def test_edge_cases_empty_ragged_and_wide(p128_keys, oracle):
     wa, wb, got = a.words(), b.words(), res.words()
     for i in (0, 15, 16, 8191, 8192, G - 1):
         assert (got[i] == oks.gate("ORNY", wa[i], wb[i])).all(), i
+
+
+def test_priority_swapping_does_not_change_results(p128_keys, oracle):
+    """br_fair (co-resident blind-rotate workgroups swap issue priority) is pure scheduling:
+    a launch wide enough to put two workgroups on every CU gives the same words with it off."""
+    from peba1_amd import api, lib
+    pp, ks, oks = p128_keys
+    L = lib.load()
+    G = 700
+    rng = np.random.default_rng(18)
+    L.tfhe_hip_set_encrypt_seed(1818)
+    a = api.CiphertextArray(pp, G).encrypt(rng.integers(0, 2, G), ks)
+    b = api.CiphertextArray(pp, G).encrypt(rng.integers(0, 2, G), ks)
+    out = []
+    try:
+        for fair in (18, 0, 12):
+            api.set_tuning("br_fair", fair)
+            res = api.CiphertextArray(pp, G)
+            api.gate_batch("XNOR", res, a, b, ks)
+            out.append(res.words())
+    finally:
+        api.set_tuning("br_fair", 18)
+    assert (out[0] == out[1]).all() and (out[0] == out[2]).all()
+    wa, wb = a.words(), b.words()
+    for i in (0, 255, 256, 699):
+        assert (out[0][i] == oks.gate("XNOR", wa[i], wb[i])).all(), i
