@@ -308,8 +308,27 @@ void Engine::launch_ks(const DeviceKeyImage *key, const int32_t *u_buf, const Ks
     for (int done = 0; done < count; done += chunk) {
         const int cnt = std::min(chunk, count - done);
         int splits = 1;
-        if (tiled && cnt >= 2 * ks_tile) splits = ks_max_splits;
-        else while (splits < ks_max_splits && cnt * splits * 2 <= ks_target_blocks) splits *= 2;
+        if (tiled && cnt >= 2 * ks_tile) {
+            // the number of coefficient ranges is free between nin/64 and ks_max_splits: take the
+            // one whose grid (tiles x ranges) fills whole rounds of the workgroups the chip holds
+            // (the kernel's ~190 VGPRs allow two waves per SIMD, i.e. 8 / waves-per-workgroup
+            // workgroups per CU, and its LDS strips a similar number), e.g. 36 tiles x 28 ranges =
+            // 1008 of 1024 slots in two rounds instead of 36 x 32 = 1152 in three
+            const int threads = ((dp.ct_stride / 4 + 63) / 64) * 64;
+            const size_t lds = (size_t)16 * threads * 16 + (size_t)ks_tile * 65 * 4;
+            const int per_cu = std::max(1, std::min((int)((160 * 1024) / lds), 8 / (threads / 64)));
+            const long long slots = (long long)cu_count_ * per_cu;
+            const long long tiles = (cnt + ks_tile - 1) / ks_tile;
+            const int lo = std::max(2, (nin + 63) / 64);
+            double best = -1.0;
+            for (int sp = lo; sp <= ks_max_splits; ++sp) {
+                const long long blocks = tiles * sp, rounds = (blocks + slots - 1) / slots;
+                const double eff = (double)blocks / (double)(rounds * slots);
+                if (eff >= best - 1e-9) { best = eff; splits = sp; }        // ties: more, shorter ranges
+            }
+        } else {
+            while (splits < ks_max_splits && cnt * splits * 2 <= ks_target_blocks) splits *= 2;
+        }
         int32_t *partial = nullptr;
         if (splits > 1) partial = static_cast<int32_t *>(scratch(10 + (size_t)lane, (size_t)cnt * splits * dp.ct_stride * 4));
         launch_keyswitch(stream, dp, key->key, u_buf, descs + done, cnt, pool, splits, partial, tiled ? ks_tile : 0);
