@@ -757,13 +757,15 @@ __global__ __launch_bounds__(KS_MAX_THREADS) void ks_reduce_kernel(DevParams p, 
 // LDS word per (gate, coefficient), the same for all lanes.  Needs ks_t = 8,
 // ks_basebit = 2 (every built-in parameter set) and at most 64 coefficients per range;
 // partial sums go through ks_reduce_kernel as above.
+typedef uint32_t v4u32 __attribute__((ext_vector_type(4)));
+
 template <int THREADS, int G>
 __global__ __launch_bounds__(THREADS) void keyswitch_tile_kernel(DevParams p, DevKey key, const int32_t *__restrict__ u_buf,
                                                               const KsDesc *__restrict__ descs, int count,
                                                               int32_t *__restrict__ partial) {
     constexpr int JB = 4, ROWS = JB * 3, MAXR = 64;
     __shared__ uint4 rows[JB * 4 * THREADS];
-    __shared__ uint32_t su[G][MAXR];
+    __shared__ __align__(16) uint32_t su[MAXR][G];       // [coefficient][gate]: four gates' digit words per 16-byte read
     __shared__ uint32_t sbody[G];
     const int tid = threadIdx.x;
     const int nin = p.k * p.N;
@@ -779,7 +781,7 @@ __global__ __launch_bounds__(THREADS) void keyswitch_tile_kernel(DevParams p, De
             v = (uint32_t)u_buf[(size_t)d.u0 * p.u_stride + i0 + ii] + p.ks_prec_offset;
             if (d.u1 >= 0) v += (uint32_t)u_buf[(size_t)d.u1 * p.u_stride + i0 + ii];
         }
-        su[g][ii] = v;
+        su[ii][g] = v;
     }
     if (tid < G && g0 + tid < count) {
         const KsDesc d = descs[g0 + tid];
@@ -800,30 +802,59 @@ __global__ __launch_bounds__(THREADS) void keyswitch_tile_kernel(DevParams p, De
     const uint4 *src = ksk + (size_t)(i0 * 8) * 3 * nvec;
 #pragma unroll
     for (int r = 0; r < ROWS; ++r) rows[(r / 3 * 4 + r % 3 + 1) * THREADS + tid] = src[(size_t)r * nvec];
-    const uint4 *strip = rows + tid;
+    // byte address of this thread's strip in LDS (the low half of a generic LDS pointer)
+    const uint32_t strip_addr = (uint32_t)reinterpret_cast<uintptr_t>(rows) + (uint32_t)tid * 16u;
     for (int st = 0; st < nst; ++st) {
         // next stage's rows: loads issued before this stage's arithmetic, stored after it
         // (the strip is private to the thread and a wave's LDS operations stay in order).
-        // Unconditional, the last stage re-reads itself: a conditional load keeps the array
-        // in scratch memory with this compiler.
-        uint4 pre[ROWS];
+        // Unconditional: the last stage re-reads itself.
+        // (twelve named values, not an array: with the explicit LDS reads below the compiler
+        // would keep an array in scratch memory)
         if (st + 1 < nst) src += (size_t)ROWS * nvec;
-#pragma unroll
-        for (int r = 0; r < ROWS; ++r) pre[r] = src[(size_t)r * nvec];
+#define KS_ROWS(X) X(0) X(1) X(2) X(3) X(4) X(5) X(6) X(7) X(8) X(9) X(10) X(11)
+#define KS_LOAD(r) const uint4 pre##r = src[(size_t)(r) * nvec];
+        KS_ROWS(KS_LOAD)
+#undef KS_LOAD
         const int ii = st >> 1;
         const int sh0 = 24 - 8 * (st & 1);               // digit j sits at bits [31-2j, 30-2j]
+        // Four gates at a time: their sixteen strip reads are issued back to back and waited for
+        // once.  (Left to the compiler the reads are sunk next to their uses, two in flight,
+        // and the loop is bound by LDS latency; hence the explicit ds_read_b128 / s_waitcnt.
+        // The compiler's own LDS waits stay correct: operations of a wave complete in order
+        // and it only ever under-counts what is outstanding.)
 #pragma unroll
-        for (int g = 0; g < G; ++g) {
-            const uint32_t x = su[g][ii] >> sh0;         // this stage's four digits in the low byte
+        for (int g = 0; g < G; g += 4) {
+            v4u32 row[16];
+            const uint4 xs = *reinterpret_cast<const uint4 *>(&su[ii][g]);
+            const uint32_t xe[4] = {xs.x, xs.y, xs.z, xs.w};
 #pragma unroll
-            for (int jj = 0; jj < JB; ++jj) {
-                const uint32_t d = (x >> (6 - 2 * jj)) & 3u;
-                const uint4 row = strip[(jj * 4 + (int)d) * THREADS];
-                acc[g].x -= row.x; acc[g].y -= row.y; acc[g].z -= row.z; acc[g].w -= row.w;
+            for (int e = 0; e < 4; ++e) {
+                const uint32_t x = xe[e] >> sh0;             // this stage's four digits in the low byte
+#pragma unroll
+                for (int jj = 0; jj < JB; ++jj) {
+                    const uint32_t d = (x >> (6 - 2 * jj)) & 3u;
+                    const uint32_t addr = strip_addr + d * (uint32_t)(THREADS * 16);
+                    asm volatile("ds_read_b128 %0, %1 offset:%2"
+                                 : "=v"(row[e * 4 + jj]) : "v"(addr), "n"(jj * 4 * THREADS * 16) : "memory");
+                }
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)"
+                         : "+v"(row[0]), "+v"(row[1]), "+v"(row[2]), "+v"(row[3]), "+v"(row[4]), "+v"(row[5]),
+                           "+v"(row[6]), "+v"(row[7]), "+v"(row[8]), "+v"(row[9]), "+v"(row[10]), "+v"(row[11]),
+                           "+v"(row[12]), "+v"(row[13]), "+v"(row[14]), "+v"(row[15]));
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+#pragma unroll
+                for (int jj = 0; jj < JB; ++jj) {
+                    const v4u32 r = row[e * 4 + jj];
+                    acc[g + e].x -= r.x; acc[g + e].y -= r.y; acc[g + e].z -= r.z; acc[g + e].w -= r.w;
+                }
             }
         }
-#pragma unroll
-        for (int r = 0; r < ROWS; ++r) rows[(r / 3 * 4 + r % 3 + 1) * THREADS + tid] = pre[r];
+#define KS_STORE(r) rows[((r) / 3 * 4 + (r) % 3 + 1) * THREADS + tid] = pre##r;
+        KS_ROWS(KS_STORE)
+#undef KS_STORE
+#undef KS_ROWS
     }
 #pragma unroll
     for (int g = 0; g < G; ++g) {
