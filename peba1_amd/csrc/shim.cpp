@@ -195,6 +195,13 @@ int flush_locked() {
     // level of every op: ASAP, or slack-aware balanced (same depth, fuller narrow levels)
     std::vector<int32_t> lvl, alap;
     const int levels = schedule_levels(r.ops, r.max_level, r.balance_levels, Engine::get().cu_count(), lvl, &alap);
+    if (const char *trace = std::getenv("TFHE_HIP_TRACE_DAG")) {      // diagnostic: per op "kind asap alap level"
+        if (FILE *f = std::fopen(trace, "w")) {
+            for (size_t i = 0; i < r.ops.size(); ++i)
+                std::fprintf(f, "%d %d %d %d\n", (int)r.ops[i].kind, r.ops[i].level, alap[i], lvl[i]);
+            std::fclose(f);
+        }
+    }
     if (r.dataflow) {
         // one launch for the whole DAG: tasks in topological priority order, each naming the
         // tasks that produce its operands
