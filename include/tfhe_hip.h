@@ -95,6 +95,9 @@ int tfhe_hip_gate_batch(int gate, LweSample *result, const LweSample *a, const L
  * "br_fair": k > 0 (default 18, env TFHE_HIP_BR_FAIR) = in launches that put two blind-rotate
  * workgroups on a CU, the two swap wave issue priority every 2^k shader cycles so that both
  * finish together; 0 = leave it to the hardware's oldest-first arbitration.
+ * "reuse_gates": 1 (default) = in deferred mode a gate recorded again with the same operand
+ * samples before the flush shares the pending gate's result instead of being evaluated again
+ * (same function of the same ciphertexts, so the same words); 0 = evaluate every call.
  * "balance_levels": 1 (default) = slack-aware level filling at flush, 0 = plain ASAP
  * levels.
  * "dataflow": 0 (default) = one blind-rotate + one key-switch launch per level; 1 (env
@@ -121,6 +124,7 @@ typedef struct TfheHipStats {
     double   ms_flush_wall;     /* host wall time inside flush */
     double   ms_blind_rotate_busy; /* time during which at least one blind-rotate launch was running
                                       (== ms_blind_rotate with one lane; less when two lanes overlap) */
+    uint64_t reused_gates;      /* recorded gates served by an identical pending gate ("reuse_gates") */
 } TfheHipStats;
 void tfhe_hip_get_stats(TfheHipStats *out);
 void tfhe_hip_reset_stats(void);

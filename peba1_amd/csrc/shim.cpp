@@ -12,9 +12,11 @@
 // (Math.cpp:47-49).  The level of an operation is 1 + the maximum level of its
 // operand slots; a flush executes level 1, 2, ... as batched kernel launches.
 // bootsCOPY and bootsCONSTANT only re-point handles (no data moves).
+#include <array>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <map>
 #include <mutex>
 #include <new>
 #include <string>
@@ -87,7 +89,18 @@ struct Recorder {
     int lanes = 1;                // 2: urgent gates and the rest on two streams (scheduler.hpp assign_lanes)
     int tight_slack = 64;         // lane 0 takes the gates with at most this much slack
     std::unordered_map<int32_t, int32_t> not_origin;   // pending NOT output slot -> its operand slot
+    // Pending gates by (kind, operand slots): a gate recorded again with the same operands before
+    // the flush is the same function of the same ciphertexts, so its result slot is shared
+    // instead of evaluated twice (the reference's circuits do this 12,545 times per match,
+    // mostly AND / XOR against the shared constant samples).  Results are unchanged.
+    bool reuse_gates = true;
+    std::unordered_map<uint64_t, int32_t> pending_gate;            // two-input gates and NOT: key -> result slot
+    std::map<std::array<int32_t, 3>, int32_t> pending_mux;         // MUX: (a, b, c) -> result slot
 };
+// key of a pending gate; symmetric two-input gates (sa == sb in GATE_LIN) with ordered operands
+uint64_t gate_key(int kind, int32_t a, int32_t b) {
+    return ((uint64_t)(uint32_t)kind << 58) ^ ((uint64_t)(uint32_t)a << 29) ^ (uint64_t)(uint32_t)b;
+}
 Recorder &rec() {
     static Recorder r;
     static bool init = [] {
@@ -174,7 +187,21 @@ void record_gate2(int code, LweSample *result, const LweSample *ca, const LweSam
     begin_op(bk);
     SlotPool *pool = r.pool;
     const int32_t sa = ensure_slot(ca, pool), sb = ensure_slot(cb, pool);
+    uint64_t key = 0;
+    if (r.reuse_gates) {
+        const bool symmetric = GATE_LIN[code].sa == GATE_LIN[code].sb;   // t = c0 + s (A + B)
+        key = symmetric && sb < sa ? gate_key(code, sb, sa) : gate_key(code, sa, sb);
+        auto it = r.pending_gate.find(key);
+        if (it != r.pending_gate.end()) {
+            pool->retain(it->second);
+            repoint(result, pool, it->second);
+            ++Engine::get().stats.reused_gates;
+            finish_op(result);
+            return;
+        }
+    }
     const int32_t dst = pool->alloc();
+    if (r.reuse_gates) r.pending_gate.emplace(key, dst);
     const int32_t level = 1 + std::max(pool->level[sa], pool->level[sb]);
     pool->level[dst] = level;
     pool->retain(sa); pool->retain(sb); pool->retain(dst);   // pending references
@@ -195,10 +222,11 @@ int flush_locked() {
     // level of every op: ASAP, or slack-aware balanced (same depth, fuller narrow levels)
     std::vector<int32_t> lvl, alap;
     const int levels = schedule_levels(r.ops, r.max_level, r.balance_levels, Engine::get().cu_count(), lvl, &alap);
-    if (const char *trace = std::getenv("TFHE_HIP_TRACE_DAG")) {      // diagnostic: per op "kind asap alap level"
+    if (const char *trace = std::getenv("TFHE_HIP_TRACE_DAG")) {      // diagnostic: per op "kind asap alap level dst a b c" (slots)
         if (FILE *f = std::fopen(trace, "w")) {
             for (size_t i = 0; i < r.ops.size(); ++i)
-                std::fprintf(f, "%d %d %d %d\n", (int)r.ops[i].kind, r.ops[i].level, alap[i], lvl[i]);
+                std::fprintf(f, "%d %d %d %d %d %d %d %d\n", (int)r.ops[i].kind, r.ops[i].level, alap[i], lvl[i],
+                             r.ops[i].dst, r.ops[i].a, r.ops[i].b, r.ops[i].c);
             std::fclose(f);
         }
     }
@@ -238,6 +266,8 @@ int flush_locked() {
         }
         r.ops.clear();
         r.not_origin.clear();
+        r.pending_gate.clear();
+        r.pending_mux.clear();
         r.max_level = 0;
         return levels;
     }
@@ -328,6 +358,8 @@ int flush_locked() {
     }
     r.ops.clear();
     r.not_origin.clear();
+    r.pending_gate.clear();
+    r.pending_mux.clear();
     r.max_level = 0;
     return levels;
 }
@@ -509,7 +541,18 @@ void bootsNOT(LweSample *result, const LweSample *ca, const TFheGateBootstrappin
             return;
         }
     }
+    if (r.reuse_gates) {
+        auto it = r.pending_gate.find(gate_key(OP_NOT, sa, 0));
+        if (it != r.pending_gate.end()) {
+            pool->retain(it->second);
+            repoint(result, pool, it->second);
+            ++Engine::get().stats.reused_gates;
+            finish_op(result);
+            return;
+        }
+    }
     const int32_t dst = pool->alloc();
+    if (r.reuse_gates) r.pending_gate.emplace(gate_key(OP_NOT, sa, 0), dst);
     const int32_t level = pool->level[sa];     // linear: rides on its operand's level
     pool->level[dst] = level;
     pool->retain(sa); pool->retain(dst);
@@ -538,7 +581,18 @@ void bootsMUX(LweSample *result, const LweSample *a, const LweSample *b, const L
     begin_op(bk);
     SlotPool *pool = r.pool;
     const int32_t sa = ensure_slot(a, pool), sb = ensure_slot(b, pool), sc = ensure_slot(c, pool);
+    if (r.reuse_gates) {
+        auto it = r.pending_mux.find({sa, sb, sc});
+        if (it != r.pending_mux.end()) {
+            pool->retain(it->second);
+            repoint(result, pool, it->second);
+            ++Engine::get().stats.reused_gates;
+            finish_op(result);
+            return;
+        }
+    }
     const int32_t dst = pool->alloc();
+    if (r.reuse_gates) r.pending_mux.emplace(std::array<int32_t, 3>{sa, sb, sc}, dst);
     const int32_t level = 1 + std::max(pool->level[sa], std::max(pool->level[sb], pool->level[sc]));
     pool->level[dst] = level;
     pool->retain(sa); pool->retain(sb); pool->retain(sc); pool->retain(dst);
@@ -711,6 +765,7 @@ int tfhe_hip_set_tuning(const char *name, int64_t value) {
         return 0;
     }
     if (name && std::strcmp(name, "br_fair") == 0) { Engine::get().br_fair = (int)value; return 0; }
+    if (name && std::strcmp(name, "reuse_gates") == 0) { rec().reuse_gates = value != 0; return 0; }
     if (name && std::strcmp(name, "balance_levels") == 0) { rec().balance_levels = value != 0; return 0; }
     if (name && std::strcmp(name, "lanes") == 0) { rec().lanes = value > 1 ? 2 : 1; return 0; }
     if (name && std::strcmp(name, "tight_slack") == 0) { rec().tight_slack = (int)value; return 0; }

@@ -180,11 +180,44 @@ def test_function_f_ciphertexts_match_oracle_digest(p128_keys, fixture, circuit,
         api.set_tuning("tight_slack", 64)
     if lanes > 1:
         assert api.stats()["br_launches"] > api.stats()["levels"]      # both lanes really launched
-    assert api.stats()["blind_rotates"] == g["blind_rotates"]
+    st = api.stats()
+    # the recorder shares the result of a gate recorded twice with the same operands (reuse_gates)
+    assert st["blind_rotates"] <= g["blind_rotates"] <= st["blind_rotates"] + 2 * st["reused_gates"]
     words = rb.words()
     assert hashlib.sha256(words[0].tobytes()).hexdigest() == g["result_b0_sha256"]
     assert hashlib.sha256(words.tobytes()).hexdigest() == g["result_b_sha256"]
     assert rb.decrypt(ks)[0] == g["match_bit"]
+
+
+def test_gate_reuse_is_transparent(p128_keys):
+    """reuse_gates: a 3-slot Function_f with and without sharing of identical pending gates --
+    fewer blind rotations, the same 24 output ciphertexts."""
+    from peba1_amd import api, circuits, lib
+    pp, ks, _ = p128_keys
+    out, rots = [], []
+    try:
+        for reuse in (1, 0):
+            api.set_tuning("reuse_gates", reuse)
+            lib.load().tfhe_hip_set_encrypt_seed(333)
+            T = circuits.EncryptedVector(pp, [12, 200, 77], 8, ks)
+            S = circuits.EncryptedVector(pp, [15, 190, 78], 8, ks)
+            bound = circuits.encrypt_number(pp, 100, 24, ks)
+            rb = api.CiphertextArray(pp, 24)
+            api.reset_stats()
+            api.set_deferred(True)
+            try:
+                circuits.function_f(rb, S, T, bound, 8, ks)
+                api.flush()
+            finally:
+                api.set_deferred(False)
+            st = api.stats()
+            out.append(rb.words())
+            rots.append((st["blind_rotates"], st["reused_gates"]))
+    finally:
+        api.set_tuning("reuse_gates", 1)
+    assert (out[0] == out[1]).all()
+    assert rots[1][1] == 0 and rots[0][1] > 0 and rots[0][0] < rots[1][0], rots
+    assert rb.decrypt(ks)[0] == 1                                   # 9 + 100 + 1 > 100
 
 
 def test_optimised_match_full_size(p128_keys):
@@ -207,7 +240,7 @@ def test_optimised_match_full_size(p128_keys):
             levels = api.flush()
             st = api.stats()
             assert rb.decrypt(ks).tolist() == [want] + [0] * 23
-            assert st["blind_rotates"] == 29536 and levels < 110, (st["blind_rotates"], levels)
+            assert 25000 < st["blind_rotates"] <= 29536 and levels < 110, (st["blind_rotates"], levels)
         dist = api.CiphertextArray(pp, 24)
         circuits.euclidean_distance_fast(dist, S, T, 8, ks)
         assert circuits.decrypt_number(dist, ks) == 1400950          # SURVEY 8c known answer
