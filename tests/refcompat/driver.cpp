@@ -1,9 +1,13 @@
 // driver.cpp -- TEST INFRASTRUCTURE.  Runs the known-answer scenarios of SURVEY.md 8c
-// over the plaintext-bit provider (tests/mock) and prints one JSON object.  Built twice:
+// and prints one JSON object.  Built three ways:
 //   -DUSE_REFERENCE : against /root/reference/src/Math.cpp (compiled in a temp dir,
-//                     never copied), proving source compatibility of include/tfhe/*.h
-//   default         : against this repo's libpeba1-circuits
-// Equal output = same values, same gate counts, same gate sequence.
+//                     never copied) over the plaintext-bit provider (tests/mock), proving
+//                     source compatibility of include/tfhe/*.h
+//   default         : this repo's libpeba1-circuits over the same provider
+//   -DUSE_REFERENCE -DREAL_PROVIDER : the reference's Math.cpp linked against libtfhe-hip.so
+//                     itself (oracle/Makefile -> oracle/_ref/refdriver_hip): the reference's own
+//                     object code on the GPU library, run by tests/test_gpu_circuits.py
+// Equal output = same values (and, over the mock, same gate counts and gate sequence).
 #include <cstdint>
 #include <cstdio>
 #include <string>
@@ -15,12 +19,26 @@
 #include "peba1_circuits.h"
 #endif
 
+#ifdef REAL_PROVIDER
+#include "tfhe_hip.h"
+// no gate counters in the real library: blind rotations from its statistics, the rest zero
+static void mock_reset(void) { tfhe_hip_flush(); tfhe_hip_reset_stats(); }
+static void mock_counts(int64_t *out) { for (int i = 0; i < 16; ++i) out[i] = 0; }
+static uint64_t mock_trace_hash(void) { return 0; }
+static int64_t mock_bootstraps(void) {
+    TfheHipStats st;
+    tfhe_hip_flush();
+    tfhe_hip_get_stats(&st);
+    return (int64_t)st.blind_rotates;
+}
+#else
 extern "C" {
 void mock_reset(void);
 void mock_counts(int64_t *out);
 uint64_t mock_trace_hash(void);
 int64_t mock_bootstraps(void);
 }
+#endif
 
 static TFheGateBootstrappingParameterSet *params;
 static TFheGateBootstrappingSecretKeySet *key;

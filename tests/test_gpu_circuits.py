@@ -246,3 +246,27 @@ def test_optimised_match_full_size(p128_keys):
         assert circuits.decrypt_number(dist, ks) == 1400950          # SURVEY 8c known answer
     finally:
         api.set_deferred(False)
+
+
+def test_reference_object_code_on_the_gpu_library():
+    """The literal drop-in: the reference's own src/Math.cpp, compiled where it lies and LINKED
+    against libtfhe-hip.so (oracle/Makefile `ref` -> oracle/_ref/refdriver_hip, built where
+    /root/reference exists), runs the known-answer scenarios of SURVEY 8c on the GPU in deferred
+    mode: 8-bit adder / subtractor / multiplier, both 128-slot distances, Function_f at two
+    bounds for genuine and impostor -- values equal to tests/golden/circuit_known_answers.json."""
+    import json
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = os.path.join(root, "oracle", "_ref", "refdriver_hip")
+    if not os.path.exists(exe):
+        pytest.skip("oracle/_ref/refdriver_hip not built (needs /root/reference at build time)")
+    out = subprocess.run([exe], env=dict(os.environ, TFHE_HIP_DEFERRED="1"), capture_output=True, text=True, timeout=400)
+    assert out.returncode == 0, out.stderr[-2000:]
+    got = json.loads(out.stdout)
+    with open(os.path.join(root, "tests", "golden", "circuit_known_answers.json")) as f:
+        want = json.load(f)
+    assert set(got) == set(want)
+    for name, w in want.items():
+        assert got[name]["value"] == w["value"], (name, got[name]["value"], w["value"])
+        # executed rotations: at most what the circuit records (identical pending gates are shared)
+        assert 0 < got[name]["blind_rotates"] <= w["blind_rotates"], name
