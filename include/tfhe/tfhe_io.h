@@ -4,7 +4,9 @@
  * keyset and ciphertexts.  The entry points carry upstream's names and argument meaning.
  * The byte format is this library's own container ("TFHP", version 1, little endian):
  * upstream's layout is not in /root/reference and could not be verified, so files are NOT
- * interchangeable with upstream's.
+ * interchangeable with upstream's.  A malformed, truncated or foreign (upstream) file is not
+ * fatal: loaders return NULL, import leaves the sample untouched, and tfhe_hip_last_error()
+ * says why.
  *
  * Client.h uses std::vector while including only tfhe headers, so in C++ this
  * header must pull in <vector> and <iostream> as upstream's does. */

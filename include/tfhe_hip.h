@@ -23,8 +23,12 @@ enum TfheHipGate {
     TFHE_HIP_ANDNY, TFHE_HIP_ANDYN, TFHE_HIP_ORNY, TFHE_HIP_ORYN
 };
 
-/* ---- error channel: the upstream API returns void everywhere;
- * failures are reported here and fatal ones also abort, like upstream ---- */
+/* ---- error channel: the upstream API returns void everywhere, so failures
+ * are reported here.  Conditions the caller can recover from -- ciphertext slot pool exhausted,
+ * a sample this library did not allocate, a sample used with a key of another LWE dimension,
+ * a null key, a malformed / truncated / foreign file -- leave the call WITHOUT EFFECT (result
+ * untouched; loaders return NULL; int entry points return -1) and set the message.  Only HIP
+ * runtime failures and "no GPU present" abort the process, like upstream's fatal paths. ---- */
 const char *tfhe_hip_last_error(void);
 void tfhe_hip_clear_error(void);
 
@@ -39,7 +43,10 @@ TFheGateBootstrappingParameterSet *tfhe_hip_new_parameters(
 /* BASELINE.json configs[4]: N=2048, Bg=2^6, l=3 (n=1024, ks 8x2 bit fixed by this repo) */
 TFheGateBootstrappingParameterSet *tfhe_hip_new_p2048_parameters(void);
 
-/* ---- deterministic key generation and encryption randomness ---- */
+/* ---- deterministic key generation and encryption randomness ----
+ * By default new_random_gate_bootstrapping_secret_keyset and bootsSymEncrypt draw from a
+ * generator seeded with OS entropy (getrandom); the entry points below fix the seeds, for
+ * tests and golden fixtures only. ---- */
 TFheGateBootstrappingSecretKeySet *tfhe_hip_new_secret_keyset_seeded(
     const TFheGateBootstrappingParameterSet *params, uint64_t seed);
 /* host-only keyset (no device upload): lets CPU-only tests check key derivation */

@@ -32,6 +32,8 @@ const std::string &last_error_ref() { return g_last_error; }
     std::abort();
 }
 
+[[noreturn]] void api_fail(const std::string &msg) { throw ApiError{msg}; }
+
 void hip_check(hipError_t e, const char *what) {
     if (e != hipSuccess) fatal(std::string(what) + ": " + hipGetErrorString(e));
 }
@@ -41,6 +43,7 @@ SlotPool::SlotPool(int ct_words, int ct_stride, size_t capacity) : words_(ct_wor
     hip_check(hipMalloc(reinterpret_cast<void **>(&data_), cap_ * (size_t)stride_ * sizeof(int32_t)), "hipMalloc(slot pool)");
     ref_.assign(cap_, 0);
     level.assign(cap_, 0);
+    pending.assign(cap_, 0);
     free_.reserve(cap_);
     for (size_t i = cap_; i-- > 0;) free_.push_back((int32_t)i);
 }
@@ -49,12 +52,13 @@ SlotPool::~SlotPool() {
 }
 int32_t SlotPool::alloc() {
     if (free_.empty())
-        fatal("ciphertext slot pool exhausted (" + std::to_string(cap_) +
-              " slots); raise TFHE_HIP_POOL_SLOTS or call tfhe_hip_flush() more often");
+        api_fail("ciphertext slot pool exhausted (" + std::to_string(cap_) +
+                 " slots); raise TFHE_HIP_POOL_SLOTS or free ciphertext arrays");
     const int32_t s = free_.back();
     free_.pop_back();
     ref_[s] = 1;
     level[s] = 0;
+    pending[s] = 0;
     return s;
 }
 void SlotPool::release(int32_t s) {
@@ -213,12 +217,22 @@ void Engine::free_key(DeviceKeyImage *img) {
     delete img;
 }
 
-SlotPool *Engine::pool_for(const Params &p) {
-    ensure_init();
+SlotPool *Engine::find_pool(const Params &p) const {
     for (SlotPool *pl : pools_)
         if (pl->ct_stride() == p.ct_stride() && pl->ct_words() == p.ct_words()) return pl;
+    return nullptr;
+}
+
+SlotPool *Engine::pool_for(const Params &p) {
+    ensure_init();
+    if (SlotPool *pl = find_pool(p)) return pl;
     size_t cap = 1u << 21;   // 2,097,152 slots = 5.3 GB at n = 630 (HBM is 288 GB): ~9 matches in flight
     if (const char *env = std::getenv("TFHE_HIP_POOL_SLOTS")) cap = (size_t)std::atoll(env);
+    // slot ids are packed into 29-bit fields by the recorder's table of pending gates (shim.cpp gate_key)
+    if (cap < 8 || cap > MAX_POOL_SLOTS) {
+        set_error("TFHE_HIP_POOL_SLOTS out of range [8, 2^29]; clamped");
+        cap = cap < 8 ? 8 : MAX_POOL_SLOTS;
+    }
     auto *pl = new SlotPool(p.ct_words(), p.ct_stride(), cap);
     // shared read-only slots: the trivial samples (0, -1/8) -- also what a fresh sample is -- and (0, +1/8)
     std::vector<Torus32> z(p.n, 0);

@@ -27,9 +27,20 @@ const std::string &last_error_ref();
 [[noreturn]] void fatal(const std::string &msg);
 void hip_check(hipError_t e, const char *what);
 
+// A condition the caller can recover from (slot pool exhausted, a sample this library did not
+// allocate, a sample used with a key of another LWE dimension, a malformed file): thrown inside
+// the library, caught at every extern "C" entry, reported through tfhe_hip_last_error() with
+// the call left without effect.  fatal() (abort, like upstream) is kept for HIP runtime
+// failures and for "no GPU", after which nothing can work.
+struct ApiError { std::string msg; };
+[[noreturn]] void api_fail(const std::string &msg);
+
 // Pool of device-resident ciphertext slots (ct_stride words each).  Slots are
 // immutable once written (the recorder renames every destination), reference
 // counted, and recycled through a free list.
+// slot ids must fit the 29-bit fields of the recorder's pending-gate keys (shim.cpp gate_key)
+constexpr size_t MAX_POOL_SLOTS = (size_t)1 << 29;
+
 class SlotPool {
 public:
     SlotPool(int ct_words, int ct_stride, size_t capacity);
@@ -42,7 +53,8 @@ public:
     int ct_words() const { return words_; }
     size_t capacity() const { return cap_; }
     size_t in_use() const { return cap_ - free_.size(); }
-    std::vector<int32_t> level;      // pending level of each slot's value, 0 = materialised
+    std::vector<int32_t> level;      // level of the recorded operation that will write the slot (0: an input)
+    std::vector<uint8_t> pending;    // 1 = written by a recorded operation that has not run yet
     int32_t const_slot[2] = {-1, -1};   // shared read-only trivial samples (0, -1/8) and (0, +1/8)
 private:
     int words_, stride_;
@@ -79,6 +91,7 @@ public:
     DeviceKeyImage *upload_key(const TfheHipCloudKey &ck);
     void free_key(DeviceKeyImage *img);
     SlotPool *pool_for(const Params &p);
+    SlotPool *find_pool(const Params &p) const;   // the pool of this ciphertext shape if one exists; never initialises the device
 
     void write_slot(SlotPool *pool, int32_t slot, const Torus32 *a, Torus32 b);       // host -> device
     void read_slot(SlotPool *pool, int32_t slot, Torus32 *a, Torus32 *b);             // device -> host

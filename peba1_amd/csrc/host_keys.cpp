@@ -10,9 +10,28 @@
 #include "host_keys.hpp"
 
 #include <cmath>
+#include <cstdio>
 #include <cstring>
+#include <ctime>
+#include <sys/random.h>
+#include <unistd.h>
 
 namespace tfhe_hip {
+
+uint64_t os_entropy() {
+    uint64_t v = 0;
+    if (getrandom(&v, sizeof v, 0) == (ssize_t)sizeof v) return v;
+    if (FILE *f = std::fopen("/dev/urandom", "rb")) {
+        const size_t got = std::fread(&v, 1, sizeof v, f);
+        std::fclose(f);
+        if (got == sizeof v) return v;
+    }
+    // no entropy source at all: better than a constant, and said so
+    std::fprintf(stderr, "libtfhe-hip: warning: no OS entropy source, seeding from clock and pid\n");
+    struct timespec ts;
+    clock_gettime(CLOCK_REALTIME, &ts);
+    return ((uint64_t)ts.tv_sec << 32) ^ (uint64_t)ts.tv_nsec ^ ((uint64_t)getpid() << 20);
+}
 
 uint32_t Params::decomp_offset() const {
     uint32_t off = 0;

@@ -50,6 +50,9 @@ private:
     uint64_t s_[4];
 };
 Torus32 dtot32(double d);
+// 64 bits from the operating system (getrandom, /dev/urandom as a fallback): the seed of every
+// keyset and of the encryption generator unless the caller fixes one
+uint64_t os_entropy();
 
 }  // namespace tfhe_hip
 

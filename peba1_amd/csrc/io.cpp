@@ -3,6 +3,7 @@
 // little endian.
 #include <cstdio>
 #include <cstring>
+#include <memory>
 #include <mutex>
 #include <set>
 #include <string>
@@ -23,10 +24,10 @@ struct Header { char magic[4]; uint32_t version, kind, reserved; uint64_t bytes;
 static_assert(sizeof(Header) == 24, "file header layout");
 
 void put(FILE *F, const void *p, size_t n) {
-    if (n && std::fwrite(p, 1, n, F) != n) fatal("tfhe_io: short write");
+    if (n && std::fwrite(p, 1, n, F) != n) api_fail("tfhe_io: short write");
 }
 void get(FILE *F, void *p, size_t n) {
-    if (n && std::fread(p, 1, n, F) != n) fatal("tfhe_io: short read (truncated or foreign file)");
+    if (n && std::fread(p, 1, n, F) != n) api_fail("tfhe_io: short read (truncated or foreign file)");
 }
 void put_header(FILE *F, uint32_t kind, uint64_t bytes) {
     Header h{{'T', 'F', 'H', 'P'}, VERSION, kind, 0, bytes};
@@ -35,9 +36,9 @@ void put_header(FILE *F, uint32_t kind, uint64_t bytes) {
 uint64_t get_header(FILE *F, uint32_t kind) {
     Header h;
     get(F, &h, sizeof h);
-    if (std::memcmp(h.magic, "TFHP", 4) != 0) fatal("tfhe_io: not a libtfhe-hip file (upstream tfhe files are not interchangeable)");
-    if (h.version != VERSION) fatal("tfhe_io: unsupported file version " + std::to_string(h.version));
-    if (h.kind != kind) fatal("tfhe_io: file holds object kind " + std::to_string(h.kind) + ", expected " + std::to_string(kind));
+    if (std::memcmp(h.magic, "TFHP", 4) != 0) api_fail("tfhe_io: not a libtfhe-hip file (upstream tfhe files are not interchangeable)");
+    if (h.version != VERSION) api_fail("tfhe_io: unsupported file version " + std::to_string(h.version));
+    if (h.kind != kind) api_fail("tfhe_io: file holds object kind " + std::to_string(h.kind) + ", expected " + std::to_string(kind));
     return h.bytes;
 }
 
@@ -50,8 +51,9 @@ Params get_params(FILE *F) {
     ParamsRecord r;
     get(F, &r, sizeof r);
     const Params p = from_record(r);
-    if (p.n <= 0 || p.N <= 0 || (p.N & (p.N - 1)) || p.k < 1 || p.l < 1 || p.l * p.Bgbit > 32 || p.ks_t * p.ks_basebit > 31)
-        fatal("tfhe_io: corrupt parameter record");
+    if (p.n <= 0 || p.n > 4096 || p.N <= 0 || p.N > 65536 || (p.N & (p.N - 1)) || p.k < 1 || p.k > 4 || p.l < 1 || p.Bgbit < 1 ||
+        p.l * p.Bgbit > 32 || p.ks_t < 1 || p.ks_basebit < 1 || p.ks_t * p.ks_basebit > 31)
+        api_fail("tfhe_io: corrupt parameter record");
     return p;
 }
 
@@ -66,11 +68,11 @@ std::set<const void *> g_owned_cloud, g_owned_secret;
 
 void put_cloud_payload(FILE *F, const TfheHipCloudKey &ck) { put_params(F, ck.p); put_vec(F, ck.bk); put_vec(F, ck.ksk); }
 TfheHipCloudKey *get_cloud_payload(FILE *F) {
-    auto *ck = new TfheHipCloudKey();
+    std::unique_ptr<TfheHipCloudKey> ck(new TfheHipCloudKey());
     ck->p = get_params(F);
     get_vec(F, ck->bk, ck->p.bk_words());
     get_vec(F, ck->ksk, ck->p.ksk_words());
-    return ck;
+    return ck.release();
 }
 uint64_t cloud_bytes(const Params &p) { return sizeof(ParamsRecord) + (p.bk_words() + p.ksk_words()) * sizeof(Torus32); }
 
@@ -82,22 +84,40 @@ bool io_forget_owned_cloud(const void *ks) { std::lock_guard<std::mutex> g(g_mtx
 bool io_forget_owned_secret(const void *ks) { std::lock_guard<std::mutex> g(g_mtx); return g_owned_secret.erase(ks) != 0; }
 }  // namespace tfhe_hip
 
+// A malformed, truncated or foreign (e.g. upstream tfhe) file is reported through
+// tfhe_hip_last_error(): loaders return nullptr, the others leave their arguments untouched.
+template <typename F>
+auto io_guard(F &&body) -> decltype(body()) {
+    try { return body(); }
+    catch (const ApiError &e) { set_error(e.msg); return decltype(body())(); }
+    catch (const std::bad_alloc &) { set_error("tfhe_io: out of host memory"); return decltype(body())(); }
+}
+struct Done {};   // "void" for io_guard
+
 extern "C" {
 
 void export_tfheGateBootstrappingParameterSet_toFile(FILE *F, const TFheGateBootstrappingParameterSet *params) {
-    put_header(F, KIND_PARAMS, sizeof(ParamsRecord));
-    put_params(F, params_of(params));
+    io_guard([&] {
+        put_header(F, KIND_PARAMS, sizeof(ParamsRecord));
+        put_params(F, params_of(params));
+        return Done{};
+    });
 }
 TFheGateBootstrappingParameterSet *new_tfheGateBootstrappingParameterSet_fromFile(FILE *F) {
-    get_header(F, KIND_PARAMS);
-    return &make_param_bundle(get_params(F))->set;
+    return io_guard([&]() -> TFheGateBootstrappingParameterSet * {
+        get_header(F, KIND_PARAMS);
+        return &make_param_bundle(get_params(F))->set;
+    });
 }
 
 void export_tfheGateBootstrappingCloudKeySet_toFile(FILE *F, const TFheGateBootstrappingCloudKeySet *keyset) {
-    put_header(F, KIND_CLOUD, cloud_bytes(keyset->bk->p));
-    put_cloud_payload(F, *keyset->bk);
+    io_guard([&] {
+        put_header(F, KIND_CLOUD, cloud_bytes(keyset->bk->p));
+        put_cloud_payload(F, *keyset->bk);
+        return Done{};
+    });
 }
-TFheGateBootstrappingCloudKeySet *new_tfheGateBootstrappingCloudKeySet_fromFile(FILE *F) {
+static TFheGateBootstrappingCloudKeySet *load_cloud(FILE *F) {
     get_header(F, KIND_CLOUD);
     TfheHipCloudKey *ck = get_cloud_payload(F);
     auto *ks = new TFheGateBootstrappingCloudKeySet();
@@ -108,48 +128,63 @@ TFheGateBootstrappingCloudKeySet *new_tfheGateBootstrappingCloudKeySet_fromFile(
     g_owned_cloud.insert(ks);
     return ks;
 }
+TFheGateBootstrappingCloudKeySet *new_tfheGateBootstrappingCloudKeySet_fromFile(FILE *F) {
+    return io_guard([&] { return load_cloud(F); });
+}
 
 void export_tfheGateBootstrappingSecretKeySet_toFile(FILE *F, const TFheGateBootstrappingSecretKeySet *keyset) {
-    const TfheHipSecretKey &sk = *keyset->lwe_key;
-    put_header(F, KIND_SECRET, cloud_bytes(sk.p) + (sk.lwe_key.size() + sk.tlwe_key.size()) * sizeof(int32_t));
-    put_cloud_payload(F, *keyset->cloud.bk);
-    put_vec(F, sk.lwe_key);
-    put_vec(F, sk.tlwe_key);
+    io_guard([&] {
+        const TfheHipSecretKey &sk = *keyset->lwe_key;
+        put_header(F, KIND_SECRET, cloud_bytes(sk.p) + (sk.lwe_key.size() + sk.tlwe_key.size()) * sizeof(int32_t));
+        put_cloud_payload(F, *keyset->cloud.bk);
+        put_vec(F, sk.lwe_key);
+        put_vec(F, sk.tlwe_key);
+        return Done{};
+    });
 }
-TFheGateBootstrappingSecretKeySet *new_tfheGateBootstrappingSecretKeySet_fromFile(FILE *F) {
+static TFheGateBootstrappingSecretKeySet *load_secret(FILE *F) {
     get_header(F, KIND_SECRET);
-    TfheHipCloudKey *ck = get_cloud_payload(F);
-    auto *sk = new TfheHipSecretKey();
+    std::unique_ptr<TfheHipCloudKey> ck(get_cloud_payload(F));
+    std::unique_ptr<TfheHipSecretKey> sk(new TfheHipSecretKey());
     sk->p = ck->p;
     get_vec(F, sk->lwe_key, (size_t)ck->p.n);
     get_vec(F, sk->tlwe_key, (size_t)ck->p.k * ck->p.N);
     auto *ks = new TFheGateBootstrappingSecretKeySet();
     ks->params = &make_param_bundle(ck->p)->set;
-    ks->lwe_key = sk;
-    ks->tgsw_key = sk;
+    ks->lwe_key = sk.get();
+    ks->tgsw_key = sk.release();
     ks->cloud.params = ks->params;
-    ks->cloud.bk = ck;
-    ks->cloud.bkFFT = ck;
+    ks->cloud.bk = ck.get();
+    ks->cloud.bkFFT = ck.release();
     std::lock_guard<std::mutex> g(g_mtx);
     g_owned_secret.insert(ks);
     return ks;
 }
+TFheGateBootstrappingSecretKeySet *new_tfheGateBootstrappingSecretKeySet_fromFile(FILE *F) {
+    return io_guard([&] { return load_secret(F); });
+}
 
 void export_gate_bootstrapping_ciphertext_toFile(FILE *F, const LweSample *sample,
                                                  const TFheGateBootstrappingParameterSet *params) {
-    const int32_t words = tfhe_hip_sample_words(params);
-    std::vector<Torus32> w((size_t)words);
-    if (tfhe_hip_export_samples(sample, 1, params, w.data()) != 0) fatal("tfhe_io: cannot read ciphertext");
-    put_header(F, KIND_SAMPLE, (uint64_t)words * sizeof(Torus32));
-    put_vec(F, w);
+    io_guard([&] {
+        const int32_t words = tfhe_hip_sample_words(params);
+        std::vector<Torus32> w((size_t)words);
+        if (tfhe_hip_export_samples(sample, 1, params, w.data()) != 0) return Done{};     // error already set
+        put_header(F, KIND_SAMPLE, (uint64_t)words * sizeof(Torus32));
+        put_vec(F, w);
+        return Done{};
+    });
 }
 void import_gate_bootstrapping_ciphertext_fromFile(FILE *F, LweSample *sample,
                                                    const TFheGateBootstrappingParameterSet *params) {
-    const int32_t words = tfhe_hip_sample_words(params);
-    if (get_header(F, KIND_SAMPLE) != (uint64_t)words * sizeof(Torus32)) fatal("tfhe_io: ciphertext of a different LWE dimension");
-    std::vector<Torus32> w;
-    get_vec(F, w, (size_t)words);
-    if (tfhe_hip_import_samples(sample, 1, params, w.data()) != 0) fatal("tfhe_io: cannot store ciphertext");
+    io_guard([&] {
+        const int32_t words = tfhe_hip_sample_words(params);
+        if (get_header(F, KIND_SAMPLE) != (uint64_t)words * sizeof(Torus32)) api_fail("tfhe_io: ciphertext of a different LWE dimension");
+        std::vector<Torus32> w;
+        get_vec(F, w, (size_t)words);
+        (void)tfhe_hip_import_samples(sample, 1, params, w.data());     // sets the error itself
+        return Done{};
+    });
 }
 
 }  // extern "C"

@@ -57,7 +57,7 @@ constexpr int MIRROR_PREFIX_WORDS = 2;   // one pointer
 ArrayHeader *header_of(const LweSample *sample) {
     ArrayHeader *h;
     std::memcpy(&h, sample->a - MIRROR_PREFIX_WORDS, sizeof h);
-    if (!h || h->magic != ARRAY_MAGIC) fatal("LweSample was not allocated by new_gate_bootstrapping_ciphertext_array");
+    if (!h || h->magic != ARRAY_MAGIC) api_fail("LweSample was not allocated by new_gate_bootstrapping_ciphertext_array");
     return h;
 }
 
@@ -65,7 +65,7 @@ ArrayHeader *header_of(const LweSample *sample) {
 void bind_pool(const LweSample *sample, SlotPool *pool) {
     ArrayHeader *h = header_of(sample);
     if (!h->pool) h->pool = pool;
-    else if (h->pool != pool) fatal("ciphertext used with a key of different LWE dimension than the one it was first used with");
+    else if (h->pool != pool) api_fail("ciphertext used with a key of different LWE dimension than the one it was first used with");
 }
 
 // prelude constants of the two-input gates: (c0 in eighths, sa, sb), tfhe boot-gates.cpp
@@ -82,8 +82,9 @@ struct Recorder {
     SlotPool *pool = nullptr;
     std::vector<PendingOp> ops;
     int32_t max_level = 0;
-    Rng enc_rng{0x5EBA1};
-    uint64_t keygen_counter = 0;
+    // Encryption masks and the default keygen draw from OS entropy, as a drop-in for upstream's
+    // API must; fixed seeds exist only behind tfhe_hip_set_encrypt_seed / tfhe_hip_new_secret_keyset_seeded.
+    Rng enc_rng{os_entropy()};
     bool balance_levels = true;   // slack-aware level filling (scheduler.hpp)
     bool dataflow = false;        // opt-in: one dataflow launch per flush instead of per-level launches
     int lanes = 1;                // 2: urgent gates and the rest on two streams (scheduler.hpp assign_lanes)
@@ -97,7 +98,9 @@ struct Recorder {
     std::unordered_map<uint64_t, int32_t> pending_gate;            // two-input gates and NOT: key -> result slot
     std::map<std::array<int32_t, 3>, int32_t> pending_mux;         // MUX: (a, b, c) -> result slot
 };
-// key of a pending gate; symmetric two-input gates (sa == sb in GATE_LIN) with ordered operands
+// key of a pending gate; symmetric two-input gates (sa == sb in GATE_LIN) with ordered operands.
+// Injective: kind < 64 and slot ids < MAX_POOL_SLOTS = 2^29 (enforced where a pool is created).
+static_assert(MAX_POOL_SLOTS <= ((size_t)1 << 29), "slot ids must fit the 29-bit fields of gate_key");
 uint64_t gate_key(int kind, int32_t a, int32_t b) {
     return ((uint64_t)(uint32_t)kind << 58) ^ ((uint64_t)(uint32_t)a << 29) ^ (uint64_t)(uint32_t)b;
 }
@@ -114,8 +117,19 @@ Recorder &rec() {
     return r;
 }
 
+// Every extern "C" entry runs its body through one of these: an ApiError becomes
+// tfhe_hip_last_error() and the call has no effect (void entries) or returns -1.
+template <typename F>
+void guarded(F &&body) {
+    try { body(); } catch (const ApiError &e) { set_error(e.msg); }
+}
+template <typename F>
+int guarded_rc(F &&body) {
+    try { return body(); } catch (const ApiError &e) { set_error(e.msg); return -1; }
+}
+
 SlotPool *pool_of_key(const TFheGateBootstrappingCloudKeySet *bk) {
-    if (!bk || !bk->bk) fatal("null cloud key");
+    if (!bk || !bk->bk) api_fail("null cloud key");
     // keysets made host-only or loaded from a file get their device image at first use
     // (aborts with a clear message when there is no GPU: gates are never evaluated on the CPU)
     if (!bk->bk->dev) bk->bk->dev = Engine::get().upload_key(*bk->bk);
@@ -123,6 +137,10 @@ SlotPool *pool_of_key(const TFheGateBootstrappingCloudKeySet *bk) {
 }
 
 int flush_locked();
+
+// a fresh slot; when the pool is dry, the pending operations (which pin their operands and
+// results) are run first.  Throws ApiError if that frees nothing.
+int32_t alloc_slot(SlotPool *pool);
 
 // make sure `s` has a device slot holding its current value; returns the slot
 int32_t ensure_slot(const LweSample *cs, SlotPool *pool) {
@@ -134,7 +152,7 @@ int32_t ensure_slot(const LweSample *cs, SlotPool *pool) {
         s->slot = pool->const_slot[0];
         return s->slot;
     }
-    const int32_t slot = pool->alloc();
+    const int32_t slot = alloc_slot(pool);
     Engine::get().write_slot(pool, slot, s->a, s->b);
     s->slot = slot;
     return slot;
@@ -167,8 +185,9 @@ void sync_sample_locked(const LweSample *cs) {
     auto *s = const_cast<LweSample *>(cs);
     if (s->slot < 0) return;                       // host mirror is authoritative (fresh: trivial 0)
     SlotPool *pool = header_of(s)->pool;
-    if (pool->level[s->slot] > 0) flush_locked();
-    (void)r;
+    // pending = written by a recorded operation that has not run (a gate, or a NOT riding on
+    // level 0 of an already materialised operand)
+    if (pool->pending[s->slot] && !r.ops.empty()) flush_locked();
     Engine::get().read_slot(pool, s->slot, s->a, &s->b);
 }
 
@@ -180,12 +199,22 @@ void finish_op(LweSample *result) {
     }
 }
 
+void record_gate2_locked(int code, LweSample *result, const LweSample *ca, const LweSample *cb,
+                         const TFheGateBootstrappingCloudKeySet *bk);
 void record_gate2(int code, LweSample *result, const LweSample *ca, const LweSample *cb,
                   const TFheGateBootstrappingCloudKeySet *bk) {
+    guarded([&] {
+        Recorder &r = rec();
+        std::lock_guard<std::recursive_mutex> g(r.mtx);
+        record_gate2_locked(code, result, ca, cb, bk);
+    });
+}
+void record_gate2_locked(int code, LweSample *result, const LweSample *ca, const LweSample *cb,
+                         const TFheGateBootstrappingCloudKeySet *bk) {
     Recorder &r = rec();
-    std::lock_guard<std::recursive_mutex> g(r.mtx);
     begin_op(bk);
     SlotPool *pool = r.pool;
+    bind_pool(result, pool);                  // refuse a foreign / mismatched result before anything changes
     const int32_t sa = ensure_slot(ca, pool), sb = ensure_slot(cb, pool);
     uint64_t key = 0;
     if (r.reuse_gates) {
@@ -200,10 +229,11 @@ void record_gate2(int code, LweSample *result, const LweSample *ca, const LweSam
             return;
         }
     }
-    const int32_t dst = pool->alloc();
+    const int32_t dst = alloc_slot(pool);     // may flush: levels are read after it
     if (r.reuse_gates) r.pending_gate.emplace(key, dst);
     const int32_t level = 1 + std::max(pool->level[sa], pool->level[sb]);
     pool->level[dst] = level;
+    pool->pending[dst] = 1;
     pool->retain(sa); pool->retain(sb); pool->retain(dst);   // pending references
     r.ops.push_back(PendingOp{(uint8_t)code, dst, sa, sb, -1, level});
     r.max_level = std::max(r.max_level, level);
@@ -215,6 +245,12 @@ void record_gate2(int code, LweSample *result, const LweSample *ca, const LweSam
 
 // flush: levelise, build descriptors, execute, release pending references
 namespace {
+int32_t alloc_slot(SlotPool *pool) {
+    Recorder &r = rec();
+    if (pool->in_use() == pool->capacity() && !r.ops.empty() && r.pool == pool) flush_locked();
+    return pool->alloc();
+}
+
 int flush_locked() {
     Recorder &r = rec();
     if (r.ops.empty()) return 0;
@@ -259,6 +295,7 @@ int flush_locked() {
         Engine::get().execute_dataflow(r.key->bk->dev, pool, tasks, levels);
         for (const PendingOp &op : r.ops) {
             pool->level[op.dst] = 0;
+            pool->pending[op.dst] = 0;
             pool->release(op.dst);
             pool->release(op.a);
             if (op.b >= 0) pool->release(op.b);
@@ -351,6 +388,7 @@ int flush_locked() {
     Engine::get().execute(r.key->bk->dev, pool, plan);
     for (const PendingOp &op : r.ops) {
         pool->level[op.dst] = 0;
+        pool->pending[op.dst] = 0;
         pool->release(op.dst);
         pool->release(op.a);
         if (op.b >= 0) pool->release(op.b);
@@ -413,10 +451,9 @@ static TFheGateBootstrappingSecretKeySet *make_keyset(const TFheGateBootstrappin
 }
 
 TFheGateBootstrappingSecretKeySet *new_random_gate_bootstrapping_secret_keyset(const TFheGateBootstrappingParameterSet *params) {
-    // upstream draws from an unseeded global generator; here successive keysets use successive seeds
-    Recorder &r = rec();
-    std::lock_guard<std::recursive_mutex> g(r.mtx);
-    return make_keyset(params, 0x7F4E5EEDull + r.keygen_counter++, true);
+    // upstream draws from its global generator; here every keyset is seeded from OS entropy
+    // (reproducible keys: tfhe_hip_new_secret_keyset_seeded)
+    return make_keyset(params, os_entropy(), true);
 }
 
 void delete_gate_bootstrapping_secret_keyset(TFheGateBootstrappingSecretKeySet *keyset) {
@@ -472,7 +509,10 @@ LweSample *new_gate_bootstrapping_ciphertext_array(int32_t nbelems, const TFheGa
 void delete_gate_bootstrapping_ciphertext_array(int32_t nbelems, LweSample *samples) {
     if (!samples) return;
     auto *h = reinterpret_cast<ArrayHeader *>(reinterpret_cast<char *>(samples) - sizeof(ArrayHeader));
-    if (h->magic != ARRAY_MAGIC) fatal("delete_gate_bootstrapping_ciphertext_array: not an array base pointer");
+    if (h->magic != ARRAY_MAGIC) {      // not ours (or already freed): report, leak rather than abort
+        set_error("delete_gate_bootstrapping_ciphertext_array: not an array base pointer");
+        return;
+    }
     if (h->count != nbelems) set_error("delete_gate_bootstrapping_ciphertext_array: count differs from allocation");
     Recorder &r = rec();
     std::lock_guard<std::recursive_mutex> g(r.mtx);
@@ -488,48 +528,67 @@ LweSample *new_gate_bootstrapping_ciphertext(const TFheGateBootstrappingParamete
 void delete_gate_bootstrapping_ciphertext(LweSample *sample) { delete_gate_bootstrapping_ciphertext_array(1, sample); }
 
 void bootsSymEncrypt(LweSample *result, int32_t message, const TFheGateBootstrappingSecretKeySet *key) {
-    Recorder &r = rec();
-    std::lock_guard<std::recursive_mutex> g(r.mtx);
-    drop_slot(result);
-    encrypt_bit(*key->lwe_key, r.enc_rng, message, result->a, &result->b);
+    guarded([&] {
+        Recorder &r = rec();
+        std::lock_guard<std::recursive_mutex> g(r.mtx);
+        drop_slot(result);
+        encrypt_bit(*key->lwe_key, r.enc_rng, message, result->a, &result->b);
+    });
 }
 
 int32_t bootsSymDecrypt(const LweSample *sample, const TFheGateBootstrappingSecretKeySet *key) {
-    Recorder &r = rec();
-    std::lock_guard<std::recursive_mutex> g(r.mtx);
-    sync_sample_locked(sample);
-    return phase_of(*key->lwe_key, sample->a, sample->b) > 0 ? 1 : 0;
+    int32_t bit = 0;
+    guarded([&] {
+        Recorder &r = rec();
+        std::lock_guard<std::recursive_mutex> g(r.mtx);
+        sync_sample_locked(sample);
+        bit = phase_of(*key->lwe_key, sample->a, sample->b) > 0 ? 1 : 0;
+    });
+    return bit;
 }
 
 void bootsCONSTANT(LweSample *result, int32_t value, const TFheGateBootstrappingCloudKeySet *bk) {
-    Recorder &r = rec();
-    std::lock_guard<std::recursive_mutex> g(r.mtx);
-    begin_op(bk);
-    const int32_t s = r.pool->const_slot[value ? 1 : 0];
-    r.pool->retain(s);
-    repoint(result, r.pool, s);
-    if (!r.deferred) {   // keep the host mirror exact without a device round trip
-        std::memset(result->a, 0, (size_t)bk->params->in_out_params->n * sizeof(Torus32));
-        result->b = value ? (1 << 29) : -(1 << 29);
-    }
+    guarded([&] {
+        Recorder &r = rec();
+        std::lock_guard<std::recursive_mutex> g(r.mtx);
+        begin_op(bk);
+        bind_pool(result, r.pool);          // refuse before anything changes
+        const int32_t s = r.pool->const_slot[value ? 1 : 0];
+        r.pool->retain(s);
+        repoint(result, r.pool, s);
+        if (!r.deferred) {   // keep the host mirror exact without a device round trip
+            std::memset(result->a, 0, (size_t)bk->params->in_out_params->n * sizeof(Torus32));
+            result->b = value ? (1 << 29) : -(1 << 29);
+        }
+    });
 }
 
 void bootsCOPY(LweSample *result, const LweSample *ca, const TFheGateBootstrappingCloudKeySet *bk) {
-    Recorder &r = rec();
-    std::lock_guard<std::recursive_mutex> g(r.mtx);
-    begin_op(bk);
-    if (result == ca) return;
-    const int32_t s = ensure_slot(ca, r.pool);
-    r.pool->retain(s);
-    repoint(result, r.pool, s);
-    if (!r.deferred) sync_sample_locked(result);
+    guarded([&] {
+        Recorder &r = rec();
+        std::lock_guard<std::recursive_mutex> g(r.mtx);
+        begin_op(bk);
+        if (result == ca) return;
+        bind_pool(result, r.pool);
+        const int32_t s = ensure_slot(ca, r.pool);
+        r.pool->retain(s);
+        repoint(result, r.pool, s);
+        if (!r.deferred) sync_sample_locked(result);
+    });
 }
 
+static void not_locked(LweSample *result, const LweSample *ca, const TFheGateBootstrappingCloudKeySet *bk);
 void bootsNOT(LweSample *result, const LweSample *ca, const TFheGateBootstrappingCloudKeySet *bk) {
+    guarded([&] {
+        std::lock_guard<std::recursive_mutex> g(rec().mtx);
+        not_locked(result, ca, bk);
+    });
+}
+static void not_locked(LweSample *result, const LweSample *ca, const TFheGateBootstrappingCloudKeySet *bk) {
     Recorder &r = rec();
-    std::lock_guard<std::recursive_mutex> g(r.mtx);
     begin_op(bk);
     SlotPool *pool = r.pool;
+    bind_pool(result, pool);
     const int32_t sa = ensure_slot(ca, pool);
     {   // NOT of a still-pending NOT: -(-x) = x exactly, so alias the original operand; two NOTs
         // of one level would otherwise sit in the same launch and race
@@ -551,10 +610,11 @@ void bootsNOT(LweSample *result, const LweSample *ca, const TFheGateBootstrappin
             return;
         }
     }
-    const int32_t dst = pool->alloc();
+    const int32_t dst = alloc_slot(pool);      // may flush: the level is read after it
     if (r.reuse_gates) r.pending_gate.emplace(gate_key(OP_NOT, sa, 0), dst);
     const int32_t level = pool->level[sa];     // linear: rides on its operand's level
     pool->level[dst] = level;
+    pool->pending[dst] = 1;                    // pending even at level 0 (NOT of a materialised sample)
     pool->retain(sa); pool->retain(dst);
     r.ops.push_back(PendingOp{OP_NOT, dst, sa, -1, -1, level});
     r.not_origin.emplace(dst, sa);
@@ -574,12 +634,21 @@ void bootsANDYN(LweSample *r_, const LweSample *a, const LweSample *b, const TFh
 void bootsORNY(LweSample *r_, const LweSample *a, const LweSample *b, const TFheGateBootstrappingCloudKeySet *bk) { record_gate2(TFHE_HIP_ORNY, r_, a, b, bk); }
 void bootsORYN(LweSample *r_, const LweSample *a, const LweSample *b, const TFheGateBootstrappingCloudKeySet *bk) { record_gate2(TFHE_HIP_ORYN, r_, a, b, bk); }
 
+static void mux_locked(LweSample *result, const LweSample *a, const LweSample *b, const LweSample *c,
+                       const TFheGateBootstrappingCloudKeySet *bk);
 void bootsMUX(LweSample *result, const LweSample *a, const LweSample *b, const LweSample *c,
               const TFheGateBootstrappingCloudKeySet *bk) {
+    guarded([&] {
+        std::lock_guard<std::recursive_mutex> g(rec().mtx);
+        mux_locked(result, a, b, c, bk);
+    });
+}
+static void mux_locked(LweSample *result, const LweSample *a, const LweSample *b, const LweSample *c,
+                       const TFheGateBootstrappingCloudKeySet *bk) {
     Recorder &r = rec();
-    std::lock_guard<std::recursive_mutex> g(r.mtx);
     begin_op(bk);
     SlotPool *pool = r.pool;
+    bind_pool(result, pool);
     const int32_t sa = ensure_slot(a, pool), sb = ensure_slot(b, pool), sc = ensure_slot(c, pool);
     if (r.reuse_gates) {
         auto it = r.pending_mux.find({sa, sb, sc});
@@ -591,10 +660,11 @@ void bootsMUX(LweSample *result, const LweSample *a, const LweSample *b, const L
             return;
         }
     }
-    const int32_t dst = pool->alloc();
+    const int32_t dst = alloc_slot(pool);
     if (r.reuse_gates) r.pending_mux.emplace(std::array<int32_t, 3>{sa, sb, sc}, dst);
     const int32_t level = 1 + std::max(pool->level[sa], std::max(pool->level[sb], pool->level[sc]));
     pool->level[dst] = level;
+    pool->pending[dst] = 1;
     pool->retain(sa); pool->retain(sb); pool->retain(sc); pool->retain(dst);
     r.ops.push_back(PendingOp{OP_MUX, dst, sa, sb, sc, level});
     r.max_level = std::max(r.max_level, level);
@@ -655,35 +725,60 @@ const Torus32 *tfhe_hip_key_ksk(const TFheGateBootstrappingCloudKeySet *cloud, i
 
 int32_t tfhe_hip_sample_words(const TFheGateBootstrappingParameterSet *params) { return params->in_out_params->n + 1; }
 
-static int export_impl(const LweSample *samples, int32_t count, int32_t n, Torus32 *out, bool device_dst) {
+// The pool a group of samples lives in (or will live in): the one their array is already
+// bound to, else the pool of this parameter set's ciphertext shape if the engine has one, else --
+// only when `create` (a device-side transfer needs one) -- a new pool.  nullptr = no device
+// state for this shape yet: the host mirrors are authoritative.
+static SlotPool *resolve_pool(const LweSample *samples, const TFheGateBootstrappingParameterSet *params, bool create) {
+    if (!params || !params->in_out_params) api_fail("null parameter set");
+    const Params &p = params_of(params);
+    SlotPool *bound = header_of(samples)->pool;
+    if (bound) {
+        if (bound->ct_words() != p.ct_words())
+            api_fail("samples belong to a parameter set of LWE dimension " + std::to_string(bound->ct_words() - 1) +
+                     ", not " + std::to_string(p.n));
+        return bound;
+    }
+    if (SlotPool *pl = Engine::get().find_pool(p)) return pl;
+    return create ? Engine::get().pool_for(p) : nullptr;
+}
+
+static int export_impl(const LweSample *samples, int32_t count, const TFheGateBootstrappingParameterSet *params,
+                       Torus32 *out, bool device_dst) {
     Recorder &r = rec();
     std::lock_guard<std::recursive_mutex> g(r.mtx);
     if (count <= 0) return 0;
-    if (!device_dst) {
-        bool any_dev = false;
-        for (int32_t i = 0; i < count; ++i) any_dev |= samples[i].slot >= 0;
-        if (!any_dev) {
-            for (int32_t i = 0; i < count; ++i) {
-                std::memcpy(out + (size_t)i * (n + 1), samples[i].a, (size_t)n * 4);
-                out[(size_t)i * (n + 1) + n] = samples[i].b;
+    const int32_t n = params_of(params).n;
+    SlotPool *pool = resolve_pool(samples, params, device_dst);
+    bool any_dev = false;
+    for (int32_t i = 0; i < count; ++i) any_dev |= samples[i].slot >= 0;
+    if (!device_dst && (!any_dev || !pool)) {
+        for (int32_t i = 0; i < count; ++i) {
+            if (samples[i].slot == SLOT_ZERO) {          // fresh: trivial encryption of 0
+                std::memset(out + (size_t)i * (n + 1), 0, (size_t)n * 4);
+                out[(size_t)i * (n + 1) + n] = -(1 << 29);
+                continue;
             }
-            return 0;
+            std::memcpy(out + (size_t)i * (n + 1), samples[i].a, (size_t)n * 4);
+            out[(size_t)i * (n + 1) + n] = samples[i].b;
         }
+        return 0;
     }
-    if (!r.pool) { set_error("export to device before any key was created"); return -1; }
     if (!r.ops.empty()) flush_locked();
     std::vector<int32_t> slots(count);
-    for (int32_t i = 0; i < count; ++i) slots[i] = ensure_slot(&samples[i], r.pool);
-    Engine::get().read_slots_packed(r.pool, slots.data(), count, out, device_dst);
+    for (int32_t i = 0; i < count; ++i) slots[i] = ensure_slot(&samples[i], pool);
+    Engine::get().read_slots_packed(pool, slots.data(), count, out, device_dst);
     return 0;
 }
 
-static int import_impl(LweSample *samples, int32_t count, int32_t n, const Torus32 *in, bool device_src) {
+static int import_impl(LweSample *samples, int32_t count, const TFheGateBootstrappingParameterSet *params,
+                       const Torus32 *in, bool device_src) {
     Recorder &r = rec();
     std::lock_guard<std::recursive_mutex> g(r.mtx);
     if (count <= 0) return 0;
-    if (!r.pool) {
-        if (device_src) { set_error("import from device before any key was created"); return -1; }
+    const int32_t n = params_of(params).n;
+    SlotPool *pool = resolve_pool(samples, params, device_src);
+    if (!pool) {                                         // no device state for this shape: host mirrors only
         for (int32_t i = 0; i < count; ++i) {
             std::memcpy(samples[i].a, in + (size_t)i * (n + 1), (size_t)n * 4);
             samples[i].b = in[(size_t)i * (n + 1) + n];
@@ -691,48 +786,51 @@ static int import_impl(LweSample *samples, int32_t count, int32_t n, const Torus
         }
         return 0;
     }
+    for (int32_t i = 0; i < count; ++i) bind_pool(&samples[i], pool);    // refuse before anything changes
     std::vector<int32_t> slots(count);
     for (int32_t i = 0; i < count; ++i) {
-        repoint(&samples[i], r.pool, r.pool->alloc());
+        repoint(&samples[i], pool, alloc_slot(pool));
         slots[i] = samples[i].slot;
         if (!device_src) {
             std::memcpy(samples[i].a, in + (size_t)i * (n + 1), (size_t)n * 4);
             samples[i].b = in[(size_t)i * (n + 1) + n];
         }
     }
-    Engine::get().write_slots_packed(r.pool, slots.data(), count, in, device_src);
+    Engine::get().write_slots_packed(pool, slots.data(), count, in, device_src);
     return 0;
 }
 
 int tfhe_hip_export_samples(const LweSample *samples, int32_t count, const TFheGateBootstrappingParameterSet *params,
                             Torus32 *out_words) {
-    return export_impl(samples, count, params->in_out_params->n, out_words, false);
+    return guarded_rc([&] { return export_impl(samples, count, params, out_words, false); });
 }
 int tfhe_hip_import_samples(LweSample *samples, int32_t count, const TFheGateBootstrappingParameterSet *params,
                             const Torus32 *in_words) {
-    return import_impl(samples, count, params->in_out_params->n, in_words, false);
+    return guarded_rc([&] { return import_impl(samples, count, params, in_words, false); });
 }
 int tfhe_hip_export_samples_device(const LweSample *samples, int32_t count,
                                    const TFheGateBootstrappingParameterSet *params, void *device_words) {
-    return export_impl(samples, count, params->in_out_params->n, static_cast<Torus32 *>(device_words), true);
+    return guarded_rc([&] { return export_impl(samples, count, params, static_cast<Torus32 *>(device_words), true); });
 }
 int tfhe_hip_import_samples_device(LweSample *samples, int32_t count, const TFheGateBootstrappingParameterSet *params,
                                    const void *device_words) {
-    return import_impl(samples, count, params->in_out_params->n, static_cast<const Torus32 *>(device_words), true);
+    return guarded_rc([&] { return import_impl(samples, count, params, static_cast<const Torus32 *>(device_words), true); });
 }
 
 int tfhe_hip_sync_samples(const LweSample *samples, int32_t count) {
-    Recorder &r = rec();
-    std::lock_guard<std::recursive_mutex> g(r.mtx);
-    if (!r.ops.empty()) flush_locked();
-    for (int32_t i = 0; i < count; ++i) sync_sample_locked(&samples[i]);
-    return 0;
+    return guarded_rc([&] {
+        Recorder &r = rec();
+        std::lock_guard<std::recursive_mutex> g(r.mtx);
+        if (!r.ops.empty()) flush_locked();
+        for (int32_t i = 0; i < count; ++i) sync_sample_locked(&samples[i]);
+        return 0;
+    });
 }
 
 void tfhe_hip_set_deferred(int on) {
     Recorder &r = rec();
     std::lock_guard<std::recursive_mutex> g(r.mtx);
-    if (!on && !r.ops.empty()) flush_locked();
+    if (!on && !r.ops.empty()) guarded([&] { flush_locked(); });
     r.deferred = on != 0;
 }
 int tfhe_hip_get_deferred(void) { return rec().deferred ? 1 : 0; }
@@ -740,7 +838,7 @@ int tfhe_hip_get_deferred(void) { return rec().deferred ? 1 : 0; }
 int tfhe_hip_flush(void) {
     Recorder &r = rec();
     std::lock_guard<std::recursive_mutex> g(r.mtx);
-    return flush_locked();
+    return guarded_rc([&] { return flush_locked(); });
 }
 
 int tfhe_hip_gate_batch(int gate, LweSample *result, const LweSample *a, const LweSample *b, int32_t count,
@@ -750,10 +848,13 @@ int tfhe_hip_gate_batch(int gate, LweSample *result, const LweSample *a, const L
     std::lock_guard<std::recursive_mutex> g(r.mtx);
     const bool was = r.deferred;
     r.deferred = true;
-    for (int32_t i = 0; i < count; ++i) record_gate2(gate, &result[i], &a[i], &b[i], bk);
+    const int rc = guarded_rc([&] {
+        for (int32_t i = 0; i < count; ++i) record_gate2_locked(gate, &result[i], &a[i], &b[i], bk);
+        return 0;
+    });
     r.deferred = was;
-    if (!was) flush_locked();
-    return 0;
+    if (!was) flush_locked();      // gates recorded before a refused one still run
+    return rc;
 }
 
 int tfhe_hip_set_tuning(const char *name, int64_t value) {
@@ -774,8 +875,15 @@ int tfhe_hip_set_tuning(const char *name, int64_t value) {
     return -1;
 }
 
-void tfhe_hip_get_stats(TfheHipStats *out) { if (out) *out = Engine::get().stats; }
-void tfhe_hip_reset_stats(void) { Engine::get().stats = TfheHipStats{}; }
+// the statistics are only ever written under the recorder lock (flushes, reuse counters, test paths)
+void tfhe_hip_get_stats(TfheHipStats *out) {
+    std::lock_guard<std::recursive_mutex> g(rec().mtx);
+    if (out) *out = Engine::get().stats;
+}
+void tfhe_hip_reset_stats(void) {
+    std::lock_guard<std::recursive_mutex> g(rec().mtx);
+    Engine::get().stats = TfheHipStats{};
+}
 void tfhe_hip_set_kernel_timing(int on) { Engine::get().kernel_timing = on != 0; }
 
 static int test_build_ops(const int32_t *ops5, int32_t count, std::vector<PendingOp> &ops) {
@@ -819,12 +927,14 @@ int tfhe_hip_test_assign_lanes(const int32_t *ops5, int32_t count, int32_t unit,
 
 double tfhe_hip_test_lane_probe(const TFheGateBootstrappingCloudKeySet *bk, int32_t lanes, int32_t levels, int32_t width) {
     if (!bk || !bk->bk) { set_error("lane_probe: null keyset"); return -1.0; }
+    std::lock_guard<std::recursive_mutex> g(rec().mtx);
     pool_of_key(bk);
     return Engine::get().run_lane_probe(bk->bk->dev, lanes, levels, width);
 }
 
 int tfhe_hip_test_wg_times(const TFheGateBootstrappingCloudKeySet *bk, int32_t width, uint64_t *times2) {
     if (!bk || !bk->bk || !times2 || width <= 0) { set_error("wg_times: bad arguments"); return -1; }
+    std::lock_guard<std::recursive_mutex> g(rec().mtx);
     pool_of_key(bk);
     Engine::get().run_lane_probe(bk->bk->dev, 1, 1, width, reinterpret_cast<unsigned long long *>(times2));
     return 0;
@@ -833,6 +943,7 @@ int tfhe_hip_test_wg_times(const TFheGateBootstrappingCloudKeySet *bk, int32_t w
 int tfhe_hip_kernel_negacyclic(const TFheGateBootstrappingCloudKeySet *bk, const int32_t *ip, const Torus32 *tp,
                                Torus32 *res, int32_t count) {
     if (!bk || !bk->bk) { set_error("negacyclic: null keyset"); return -1; }
+    std::lock_guard<std::recursive_mutex> g(rec().mtx);
     pool_of_key(bk);
     Engine::get().run_negacyclic(bk->bk->dev, ip, tp, res, count);
     return 0;
@@ -840,12 +951,14 @@ int tfhe_hip_kernel_negacyclic(const TFheGateBootstrappingCloudKeySet *bk, const
 int tfhe_hip_kernel_bootstrap_woks(const TFheGateBootstrappingCloudKeySet *bk, const Torus32 *lin, int32_t count,
                                    Torus32 *u_out, Torus32 *acc_out) {
     if (!bk || !bk->bk) { set_error("bootstrap_woks: null keyset"); return -1; }
+    std::lock_guard<std::recursive_mutex> g(rec().mtx);
     pool_of_key(bk);
     Engine::get().run_bootstrap_woks(bk->bk->dev, lin, count, u_out, acc_out);
     return 0;
 }
 int tfhe_hip_kernel_keyswitch(const TFheGateBootstrappingCloudKeySet *bk, const Torus32 *u, int32_t count, Torus32 *out) {
     if (!bk || !bk->bk) { set_error("keyswitch: null keyset"); return -1; }
+    std::lock_guard<std::recursive_mutex> g(rec().mtx);
     pool_of_key(bk);
     Engine::get().run_keyswitch(bk->bk->dev, u, count, out);
     return 0;

@@ -70,6 +70,10 @@ static void report(const char *name, uint64_t value, bool last = false) {
 #define SUBN(r, a, b, n) bootsSUBNbit(r, a, b, n, ck)
 #define MULT(r, a, b, n) bootsMultiply(r, a, b, n, ck)
 #define TWOSC(r, a, n) bootsTwoSComplement(r, a, n, ck)
+#define ABSV(r, a, n) bootsABS(r, a, n, ck)
+#define SHL(r, a, n, s) bootsShiftLeft(r, a, n, s, ck)
+#define SHR(r, a, n, s) bootsShiftRight(r, a, n, s, ck)
+#define SHLNR(a, n, s) bootsShiftLeftNR(a, n, s, ck)
 #define EUCLID(r, a, b, n) HE_EuclideanDistance(r, a, b, n, ck)
 #define FUNC_F(r, a, b, bound, n) Function_f(r, a, b, bound, n, ck)
 #else
@@ -77,6 +81,10 @@ static void report(const char *name, uint64_t value, bool last = false) {
 #define SUBN(r, a, b, n) peba1_sub_nbit(r, a, b, n, ck)
 #define MULT(r, a, b, n) peba1_multiply(r, a, b, n, ck)
 #define TWOSC(r, a, n) peba1_twos_complement(r, a, n, ck)
+#define ABSV(r, a, n) peba1_abs(r, a, n, ck)
+#define SHL(r, a, n, s) peba1_shift_left(r, a, n, s, ck)
+#define SHR(r, a, n, s) peba1_shift_right(r, a, n, s, ck)
+#define SHLNR(a, n, s) peba1_shift_left_inplace(a, n, s, ck)
 #define EUCLID(r, a, b, n) peba1_euclidean_distance(r, a.data(), b.data(), (int)a.size(), n, ck)
 #define FUNC_F(r, a, b, bound, n) peba1_function_f(r, a.data(), b.data(), (int)a.size(), bound, n, ck)
 #endif
@@ -117,6 +125,27 @@ int main() {
         mock_reset();
         MULT(r, a, b, 8);
         report("mult8_122_204", dec(r, 23));
+    }
+    // bootsABS (Math.cpp:97-119; main.cpp:374 calls it on 9-bit two's-complement numbers) and the
+    // three shift helpers (Math.cpp:183-211)
+    for (int which = 0; which < 2; ++which) {
+        const uint64_t v = which == 0 ? ((uint64_t)(-82) & 0x1FF) : 77;      // -82 and +77 in 9 bits
+        LweSample *a = enc(v, 9), *r = new_gate_bootstrapping_ciphertext_array(9, params);
+        mock_reset();
+        ABSV(r, a, 9);
+        report(which == 0 ? "abs9_minus82" : "abs9_plus77", dec(r, 9));
+    }
+    {
+        LweSample *a = enc(0xB5, 8), *r = new_gate_bootstrapping_ciphertext_array(8, params);
+        mock_reset();
+        SHL(r, a, 8, 3);
+        report("shl8_b5_by3", dec(r, 8));
+        mock_reset();
+        SHR(r, a, 8, 3);
+        report("shr8_b5_by3", dec(r, 8));
+        mock_reset();
+        SHLNR(a, 8, 2);
+        report("shlnr8_b5_by2", dec(a, 8));
     }
     std::vector<LweSample *> et(nslots), eg(nslots), ei(nslots);
     for (int i = 0; i < nslots; ++i) { et[i] = enc(tmpl[i], 8); eg[i] = enc(genuine[i], 8); ei[i] = enc(impostor[i], 8); }

@@ -52,6 +52,12 @@ def test_golden_holds_survey_known_answers():
             g["subn8_122_204"]["not"]) == (121, 96, 9, 9)
     assert g["mult8_122_204"]["value"] == 24888
     assert (g["mult8_122_204"]["xor"], g["mult8_122_204"]["and"]) == (704, 592)
+    # bootsABS on 9-bit two's-complement numbers (main.cpp:374) and the shift helpers (Math.cpp:183-211):
+    # values AND gate sequence (the trace hash, compared by test_circuits_match_golden) from the reference
+    assert (g["abs9_minus82"]["value"], g["abs9_plus77"]["value"]) == (82, 77)
+    assert g["abs9_minus82"]["blind_rotates"] == 72 and g["abs9_minus82"]["copy"] == 37
+    assert (g["shl8_b5_by3"]["value"], g["shr8_b5_by3"]["value"], g["shlnr8_b5_by2"]["value"]) == (0xA8, 0x16, 0xD4)
+    assert g["shl8_b5_by3"]["blind_rotates"] == 0 and g["shlnr8_b5_by2"]["copy"] == 14
     assert g["euclid128_genuine"]["value"] == 128
     assert g["euclid128_impostor"]["value"] == 1400950
     e = g["euclid128_impostor"]

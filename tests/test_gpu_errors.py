@@ -1,0 +1,191 @@
+"""GPU tests of the robustness items of VERDICT r1 / ADVICE r1: recoverable conditions are
+reported through tfhe_hip_last_error() instead of aborting the host; a deferred bootsNOT is
+flushed by the next decrypt; import/export follow the parameter set they are given."""
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _err():
+    from peba1_amd import lib
+    return lib.load().tfhe_hip_last_error().decode()
+
+
+def test_deferred_not_is_flushed_by_decrypt(p128_keys, oracle):
+    """ADVICE r1 (shim.cpp:170): bootsNOT of an already materialised ciphertext is pending at
+    level 0; a bootsSymDecrypt / immediate bootsCOPY right after it -- no explicit flush -- must
+    run it first, not read an unwritten slot."""
+    from peba1_amd import api, lib
+    pp, ks, oks = p128_keys
+    L = lib.load()
+    L.tfhe_hip_set_encrypt_seed(61)
+    for bit in (0, 1):
+        x = api.CiphertextArray(pp, 1).encrypt([bit], ks)
+        w = x.words()
+        r = api.CiphertextArray(pp, 2)
+        api.set_deferred(True)
+        try:
+            L.bootsNOT(r.at(0), x.at(0), ks.cloud)
+            assert L.bootsSymDecrypt(r.at(0), ks.ptr) == 1 - bit          # no flush in between
+            L.bootsNOT(r.at(1), x.at(0), ks.cloud)
+        finally:
+            api.set_deferred(False)                                        # leaves deferred mode: flushes
+        assert (r.words()[0] == oks.gate_not(w[0])).all()
+        assert (r.words()[1] == oks.gate_not(w[0])).all()
+    # NOT of a fresh (never written) sample, deferred, then an immediate-mode COPY of the result
+    z = api.CiphertextArray(pp, 1)
+    r = api.CiphertextArray(pp, 2)
+    api.set_deferred(True)
+    L.bootsNOT(r.at(0), z.at(0), ks.cloud)
+    api.set_deferred(False)
+    L.bootsCOPY(r.at(1), r.at(0), ks.cloud)
+    assert list(r.decrypt(ks)) == [1, 1]
+    assert (r.words()[1] == oks.gate_not(oks.constant(0))).all()
+
+
+def test_import_export_alternate_parameter_sets(p128_keys, oracle):
+    """ADVICE r1 (shim.cpp:696): words imported for one parameter set right after gates of another
+    ran must land in their own pool (right stride), and a device import must work before any gate
+    of that set has run."""
+    import torch
+    from peba1_amd import api, lib
+    pp, ks, oks = p128_keys
+    L = lib.load()
+    p80 = api.ParameterSet(80)
+    k80 = api.SecretKeySet(p80, 0x80AA, device=True)
+    o80 = oracle.KeySet(oracle.params("P80"), 0x80AA)
+    try:
+        L.tfhe_hip_set_encrypt_seed(62)
+        a128 = api.CiphertextArray(pp, 2).encrypt([1, 1], ks)
+        a80 = api.CiphertextArray(p80, 2).encrypt([1, 0], k80)
+        w128, w80 = a128.words(), a80.words()
+        # device import of P80 words before any P80 gate (and after P128 gates of the session)
+        t = torch.from_numpy(w80.copy()).cuda()
+        d80 = api.CiphertextArray(p80, 2)
+        assert L.tfhe_hip_import_samples_device(d80.ptr, 2, p80.ptr, t.data_ptr()) == 0, _err()
+        r80 = api.CiphertextArray(p80, 1)
+        L.bootsAND(r80.at(0), d80.at(0), d80.at(1), k80.cloud)           # last key used: P80
+        # now P128 words: must bind to the P128 pool although the last gate was P80
+        b128 = api.CiphertextArray(pp, 2).set_words(w128)
+        r128 = api.CiphertextArray(pp, 1)
+        L.bootsAND(r128.at(0), b128.at(0), b128.at(1), ks.cloud)
+        c80 = api.CiphertextArray(p80, 2).set_words(w80)                  # and back
+        x80 = api.CiphertextArray(p80, 1)
+        L.bootsXOR(x80.at(0), c80.at(0), c80.at(1), k80.cloud)
+        assert (r80.words()[0] == o80.gate("AND", w80[0], w80[1])).all()
+        assert (r128.words()[0] == oks.gate("AND", w128[0], w128[1])).all()
+        assert (x80.words()[0] == o80.gate("XOR", w80[0], w80[1])).all()
+        out = torch.zeros(2 * pp.words, dtype=torch.int32, device="cuda")
+        assert L.tfhe_hip_export_samples_device(b128.ptr, 2, pp.ptr, out.data_ptr()) == 0, _err()
+        assert (out.cpu().numpy().reshape(2, -1) == w128).all()
+        # a P128 array handed over with P80 parameters is refused, not mis-strided
+        L.tfhe_hip_clear_error()
+        bad = np.zeros(2 * p80.words, dtype=np.int32)
+        assert L.tfhe_hip_export_samples(b128.ptr, 2, p80.ptr, bad.ctypes.data_as(lib.I32P)) == -1
+        assert "LWE dimension" in _err()
+    finally:
+        k80.close()
+
+
+def test_sample_used_with_a_key_of_another_dimension_is_refused(p128_keys):
+    """VERDICT r1 item 7 (shim.cpp:68): reported, result untouched, process alive."""
+    from peba1_amd import api, lib
+    pp, ks, _ = p128_keys
+    L = lib.load()
+    p80 = api.ParameterSet(80)
+    k80 = api.SecretKeySet(p80, 0x80AB, device=True)
+    try:
+        L.tfhe_hip_set_encrypt_seed(63)
+        a = api.CiphertextArray(pp, 2).encrypt([1, 1], ks)
+        r = api.CiphertextArray(pp, 1)
+        L.bootsAND(r.at(0), a.at(0), a.at(1), ks.cloud)                   # binds the arrays to P128
+        before = r.words().copy()
+        L.tfhe_hip_clear_error()
+        L.bootsXOR(r.at(0), a.at(0), a.at(1), k80.cloud)                   # wrong key
+        assert "different LWE dimension" in _err()
+        assert (r.words() == before).all() and r.decrypt(ks)[0] == 1
+        L.tfhe_hip_clear_error()
+        L.bootsMUX(r.at(0), a.at(0), a.at(1), a.at(1), k80.cloud)
+        assert "different LWE dimension" in _err() and (r.words() == before).all()
+        L.tfhe_hip_clear_error()
+        L.bootsNOT(r.at(0), a.at(0), k80.cloud)
+        assert "different LWE dimension" in _err() and (r.words() == before).all()
+        # still usable afterwards
+        L.tfhe_hip_clear_error()
+        L.bootsXOR(r.at(0), a.at(0), a.at(1), ks.cloud)
+        assert _err() == "" and r.decrypt(ks)[0] == 0
+    finally:
+        k80.close()
+
+
+POOL_WORKER = r'''
+import sys
+sys.path.insert(0, %r)
+from peba1_amd import api, lib
+L = lib.load()
+pp = api.ParameterSet(128)
+ks = api.SecretKeySet(pp, 7, device=True)
+L.tfhe_hip_set_encrypt_seed(5)
+w = api.CiphertextArray(pp, 3).encrypt([1, 1, 0], ks)
+L.bootsAND(w.at(2), w.at(0), w.at(1), ks.cloud)            # first gate: the slot pool exists from here on
+assert w.decrypt(ks)[2] == 1
+w.close()
+held = []
+# 64-slot pool: hold ciphertext arrays until no slot is left (materialised inputs pin one each)
+refused = None
+for i in range(200):
+    a = api.CiphertextArray(pp, 1).encrypt([1], ks)
+    L.tfhe_hip_clear_error()
+    rc = L.tfhe_hip_import_samples(a.ptr, 1, pp.ptr, a.words().ctypes.data_as(lib.I32P))
+    if rc != 0:
+        refused = (i, L.tfhe_hip_last_error().decode())
+        break
+    held.append(a)
+assert refused is not None and "slot pool exhausted" in refused[1], refused
+assert 40 < refused[0] <= 64, refused
+# a gate while the pool is dry: refused, reported, the result keeps its old value
+r = api.CiphertextArray(pp, 1).encrypt([0], ks)
+L.tfhe_hip_clear_error()
+L.bootsAND(r.at(0), held[0].at(0), held[1].at(0), ks.cloud)
+assert "slot pool exhausted" in L.tfhe_hip_last_error().decode()
+assert r.decrypt(ks)[0] == 0
+# free some arrays: the same call now works
+for a in held[:8]:
+    a.close()
+L.tfhe_hip_clear_error()
+L.bootsAND(r.at(0), held[8].at(0), held[9].at(0), ks.cloud)
+assert L.tfhe_hip_last_error().decode() == "" and r.decrypt(ks)[0] == 1
+print("POOL-OK", refused[0])
+'''
+
+
+def test_pool_exhaustion_is_reported_not_fatal():
+    """VERDICT r1 item 7 (engine.cpp:50): a dry slot pool refuses the call and says so; the
+    process goes on and the call succeeds once arrays are freed."""
+    env = dict(os.environ, TFHE_HIP_POOL_SLOTS="64")
+    out = subprocess.run([sys.executable, "-c", POOL_WORKER % ROOT], env=env, capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-3000:]
+    assert "POOL-OK" in out.stdout
+
+
+def test_pool_size_is_bounded_by_the_gate_key_fields():
+    """TFHE_HIP_POOL_SLOTS beyond what the pending-gate keys can hold (2^29) is
+    clamped and reported instead of letting two gates share a key."""
+    code = ("import sys; sys.path.insert(0, %r)\n"
+            "from peba1_amd import api, lib\n"
+            "L = lib.load(); pp = api.ParameterSet(128)\n"
+            "ks = api.SecretKeySet(pp, 7, device=True)\n"
+            "a = api.CiphertextArray(pp, 2).encrypt([1, 1], ks); r = api.CiphertextArray(pp, 1)\n"
+            "L.bootsAND(r.at(0), a.at(0), a.at(1), ks.cloud)\n"
+            "print('ERR', L.tfhe_hip_last_error().decode()); print('BIT', r.decrypt(ks)[0])\n" % ROOT)
+    env = dict(os.environ, TFHE_HIP_POOL_SLOTS="4")          # below the minimum: clamped up to 8
+    out = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stderr[-3000:]
+    assert "TFHE_HIP_POOL_SLOTS out of range" in out.stdout and "BIT 1" in out.stdout

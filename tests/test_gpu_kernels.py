@@ -233,3 +233,44 @@ def test_p80_blind_rotate_keyswitch_and_gates(oracle):
         assert (m.words()[0] == oks.mux(wa[1], wb[1], wb[0])).all() and m.decrypt(ks)[0] == 0
     finally:
         ks.close()
+
+
+@pytest.mark.parametrize("pname", ["P128", "P80"])
+def test_external_product_single_step(oracle, p128_keys, pname):
+    """a14 in isolation: ONE CMUX step ACC <- ACC + BK_i (.) ((X^abar - 1) ACC) -- gadget
+    decomposition, l forward NTTs per input polynomial, multiply-accumulate against row i of the key
+    image, inverse NTTs, CRT -- against the oracle's orc_cmux_rotate on the same accumulator.
+    The input sample has exactly one non-zero mask word, so every other step of the blind rotation
+    is skipped (tfhe_blindRotate skips abar = 0) and the accumulator that comes back is the test
+    vector after that single external product.  Step indices at both ends and in the middle,
+    rotations by 1, N-1, N, N+1 and 2N-1 (sign wrap of X^abar), several test-vector offsets."""
+    from peba1_amd import api
+    if pname == "P128":
+        pp, ks, oks = p128_keys
+        own = False
+    else:
+        pp = api.ParameterSet(80)
+        ks = api.SecretKeySet(pp, 0x80E1, device=True)
+        oks = oracle.KeySet(oracle.params("P80"), 0x80E1)
+        own = True
+    try:
+        N, n = pp.N, pp.n
+        unit = 1 << (31 - 10)                        # torus value whose modulus switch is 1 (N = 1024)
+        cases = [(0, 1, 0), (n - 1, N - 1, 5), (n // 2, N, 2 * N - 1), (7, N + 1, N), (n - 2, 2 * N - 1, 1),
+                 (3, 517, 1300)]
+        lin = np.zeros((len(cases), pp.words), dtype=np.int32)
+        for c, (i, abar, bbar) in enumerate(cases):
+            lin[c, i] = np.int64(abar * unit).astype(np.int32)
+            lin[c, n] = np.int64(bbar * unit).astype(np.int32)
+        u, acc = api.kernel_bootstrap_woks(ks, lin, want_acc=True)
+        for c, (i, abar, bbar) in enumerate(cases):
+            bar = oks.modswitch_ct(lin[c])
+            assert bar[i] == abar and bar[n] == bbar and np.count_nonzero(bar[:n]) == 1
+            testvec = oks.blind_rotate(np.zeros(n, dtype=np.int32), bbar)          # no step taken
+            want = oks.cmux_rotate(i, abar, testvec)
+            assert (acc[c] == want).all(), f"{pname} step {i} abar {abar} bbar {bbar}"
+            assert (want != testvec).any()
+            assert (u[c] == oks.sample_extract(want)).all()
+    finally:
+        if own:
+            ks.close()

@@ -1,0 +1,146 @@
+"""GPU tests of the two multi-GPU configurations of BASELINE.json on the HIP path, with logical
+ranks on the one device a test box has:
+  configs[2]  one 256-slot x 8-bit match, slots partitioned over N ranks, 24-ciphertext partial
+              sums exchanged, adder tree + comparator on rank 0 (peba1_amd/dist.py);
+  configs[3]  1-to-N identification: independent matches streamed through the slot pool in
+              bounded flushes (bench.py --mode identify runs the same loop at 128 per GPU).
+Ciphertext parity of the sharded DAG against the oracle evaluating the same DAG:
+tests/golden/sharded_match_digest.json (made by tests/golden/make_sharded_digest.py)."""
+import ctypes as C
+import hashlib
+import json
+import os
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_sharded_dag_ciphertexts_match_oracle_digest(p128_keys):
+    """3 slots over 2 logical ranks (2 + 1): the packed partial sums each rank would put on the wire
+    and the 24 output ciphertexts hash to what the CPU oracle produced through the same circuit
+    library for the same DAG -- DESIGN.md section 8's claim, word for word."""
+    import torch
+    from peba1_amd import api, circuits, lib
+    from peba1_amd import dist as pd
+    pp, ks, _ = p128_keys
+    with open(os.path.join(ROOT, "tests", "golden", "sharded_match_digest.json")) as f:
+        g = json.load(f)
+    assert g["key_seed"] == 0x5EBA2 and g["world"] == 2
+    L = lib.load()
+    L.tfhe_hip_set_encrypt_seed(g["encrypt_seed"])
+    bits = g["bits"]
+    T, S = [], []
+    for t, s in zip(g["template"], g["probe"]):          # encryption order is part of the fixture
+        T.append(circuits.encrypt_number(pp, t, bits, ks))
+        S.append(circuits.encrypt_number(pp, s, bits, ks))
+    bound = circuits.encrypt_number(pp, g["bound"], 3 * bits, ks)
+    digests = {}
+
+    def hook(rank, packed):
+        digests[rank] = hashlib.sha256(packed.cpu().numpy().tobytes()).hexdigest()
+
+    api.reset_stats()
+    api.set_deferred(True)
+    try:
+        res = pd.sharded_match_logical(torch, L, circuits.load(), pp.ptr, ks.cloud, pp.words,
+                                       [a.ptr for a in S], [a.ptr for a in T], bound.ptr, bits, g["world"],
+                                       device="cuda", partial_hook=hook)
+        api.flush()
+    finally:
+        api.set_deferred(False)
+    st = api.stats()
+    assert st["blind_rotates"] <= g["blind_rotates"] <= st["blind_rotates"] + 2 * st["reused_gates"]
+    assert [digests[r] for r in range(g["world"])] == g["partial_sha256"]
+    res_ls = C.cast(res, lib.LS)
+    words = np.zeros((24, pp.words), dtype=np.int32)
+    assert L.tfhe_hip_export_samples(res_ls, 24, pp.ptr, words.ctypes.data_as(lib.I32P)) == 0
+    assert hashlib.sha256(words[0].tobytes()).hexdigest() == g["result_b0_sha256"]
+    assert hashlib.sha256(words.tobytes()).hexdigest() == g["result_b_sha256"]
+    assert L.bootsSymDecrypt(res_ls, ks.ptr) == g["match_bit"]
+    L.delete_gate_bootstrapping_ciphertext_array(24, res_ls)
+
+
+@pytest.mark.parametrize("world", [2, 4, 8])
+def test_cfg3_256_slot_match_sharded_over_logical_ranks(p128_keys, world):
+    """BASELINE configs[2] at size: 256 slots x 8 bit, uniform bytes, `world` logical ranks of
+    256/world slots each.  Every rank's decrypted partial sum equals the plaintext sum of squares
+    of its slot range, their total is the distance, and the match bit is (distance > bound)
+     on both sides of the threshold."""
+    import random
+    import torch
+    from peba1_amd import api, circuits, lib
+    from peba1_amd import dist as pd
+    pp, ks, _ = p128_keys
+    L = lib.load()
+    L.tfhe_hip_set_encrypt_seed(2560 + world)
+    rnd = random.Random(world)
+    nslots = 256
+    tmpl = [rnd.randrange(256) for _ in range(nslots)]
+    probe = [(t + rnd.randrange(-9, 10)) % 256 or 1 for t in tmpl]
+    tmpl = [t or 1 for t in tmpl]                        # a zero subtrahend trips the reference's SUBN defect
+    want = [sum((a - b) ** 2 for a, b in zip(probe[lo:hi], tmpl[lo:hi]))
+            for lo, hi in (pd.shard_slots(nslots, world, r) for r in range(world))]
+    d = sum(want)
+    assert d < (1 << 23)
+    T = circuits.EncryptedVector(pp, tmpl, 8, ks).to_device()
+    S = circuits.EncryptedVector(pp, probe, 8, ks).to_device()
+    parts = {}
+    api.reset_stats()
+    api.set_deferred(True)
+    try:
+        outs = []
+        for bound_v in (d, d - 1):
+            bound = circuits.encrypt_number(pp, bound_v, 24, ks)
+            res = pd.sharded_match_logical(torch, L, circuits.load(), pp.ptr, ks.cloud, pp.words,
+                                           [a.ptr for a in S.slots], [a.ptr for a in T.slots], bound.ptr, 8, world,
+                                           device="cuda", partial_hook=lambda r, t: parts.__setitem__(r, t.clone()))
+            api.flush()
+            outs.append((bound_v, C.cast(res, lib.LS)))
+            if bound_v == d:
+                st = api.stats()
+    finally:
+        api.set_deferred(False)
+    # 1,683 blind rotations per slot + the adder tree + the comparator (24 XNOR, 48 MUX = 96 rotations)
+    assert st["blind_rotates"] + 2 * st["reused_gates"] >= nslots * 1683 + (world - 1) * 161 + 24 + 96
+    for bound_v, res in outs:
+        assert L.bootsSymDecrypt(res, ks.ptr) == (1 if d > bound_v else 0), (world, bound_v)
+        L.delete_gate_bootstrapping_ciphertext_array(24, res)
+    tmp = api.CiphertextArray(pp, 24)
+    for r in range(world):
+        assert L.tfhe_hip_import_samples_device(tmp.ptr, 24, pp.ptr, parts[r].data_ptr()) == 0
+        assert circuits.decrypt_number(tmp, ks) == want[r], (world, r)
+
+
+def test_cfg4_identification_streams_matches_through_bounded_flushes(p128_keys):
+    """BASELINE configs[3] shape on one GPU: one probe against M independent 128-slot templates
+    (full reference Function_f each), recorded `group` at a time so the slot pool bounds memory,
+    every match bit equal to the plaintext rule; the genuine template is found."""
+    from peba1_amd import api, circuits, identify, lib
+    pp, ks, _ = p128_keys
+    L = lib.load()
+    L.tfhe_hip_set_encrypt_seed(1024)
+    nslots, M, group = 128, 6, 3
+    base = [(37 * i + 11) % 255 or 1 for i in range(nslots)]
+    probe_v = [v + 1 for v in base]
+    templates_v = [identify.synthetic_template(base, k) for k in range(M)]
+    genuine = 4
+    templates_v[genuine] = base
+    probe = circuits.EncryptedVector(pp, probe_v, 8, ks).to_device()
+    templates = [circuits.EncryptedVector(pp, t, 8, ks).to_device() for t in templates_v]
+    bound = circuits.encrypt_number(pp, 256, 24, ks)
+    bound.set_words(bound.words())
+    api.reset_stats()
+    api.set_tuning("reuse_gates", 0)
+    try:
+        bits_ct = identify.identify(pp, ks, probe, templates, bound, 8, group=group)
+    finally:
+        api.set_tuning("reuse_gates", 1)
+    st = api.stats()
+    assert st["flushes"] == M // group and st["blind_rotates"] == M * 215544
+    got = [int(b) for b in bits_ct.decrypt(ks)]
+    want = [1 if sum((a - b) ** 2 for a, b in zip(probe_v, t)) > 256 else 0 for t in templates_v]
+    assert got == want and got.count(0) == 1 and got[genuine] == 0
