@@ -76,7 +76,10 @@ class ParameterSet:
     @classmethod
     def load(cls, path):
         with _CFile(path, "rb") as fp:
-            return cls(_ptr=_l.load().new_tfheGateBootstrappingParameterSet_fromFile(fp))
+            ptr = _l.load().new_tfheGateBootstrappingParameterSet_fromFile(fp)
+        if not ptr:
+            raise ValueError("cannot load a parameter set from %s: %s" % (path, last_error()))
+        return cls(_ptr=ptr)
 
 
 class SecretKeySet:
@@ -108,6 +111,8 @@ class SecretKeySet:
     def load(cls, path):
         with _CFile(path, "rb") as fp:
             ptr = _l.load().new_tfheGateBootstrappingSecretKeySet_fromFile(fp)
+        if not ptr:
+            raise ValueError("cannot load a secret keyset from %s: %s" % (path, last_error()))
         return cls(ParameterSet(_ptr=C.cast(ptr.contents.params, _l.PS)), None, _ptr=ptr)
 
     def close(self):
@@ -145,7 +150,10 @@ class CloudKeySet(SecretKeySet):
     @classmethod
     def load(cls, path):
         with _CFile(path, "rb") as fp:
-            return cls(_l.load().new_tfheGateBootstrappingCloudKeySet_fromFile(fp))
+            ptr = _l.load().new_tfheGateBootstrappingCloudKeySet_fromFile(fp)
+        if not ptr:
+            raise ValueError("cannot load a cloud keyset from %s: %s" % (path, last_error()))
+        return cls(ptr)
 
     def save(self, path):
         with _CFile(path, "wb") as fp:
@@ -206,7 +214,10 @@ class CiphertextArray:
         L = _l.load()
         with _CFile(path, "rb") as fp:
             for i in range(self.count):
+                L.tfhe_hip_clear_error()
                 L.import_gate_bootstrapping_ciphertext_fromFile(fp, self.at(i), self.params.ptr)
+                if last_error():
+                    raise ValueError("cannot load ciphertext %d from %s: %s" % (i, path, last_error()))
         return self
 
     def words(self):

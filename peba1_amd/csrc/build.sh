@@ -15,7 +15,10 @@ $CXX $HOSTFLAGS -c shim.cpp -o shim.o &
 $CXX $HOSTFLAGS -c scheduler.cpp -o scheduler.o &
 $CXX $HOSTFLAGS -c io.cpp -o io.o &
 wait -n; wait -n; wait -n; wait -n; wait -n; wait -n
-$HIPCC -shared -o $OUT kernels.o host_keys.o engine.o shim.o scheduler.o io.o
+# -Bsymbolic-functions: calls between the library's own exported functions bind inside the library, so
+# another provider of the tfhe API loaded RTLD_GLOBAL in the same process (a CPU tfhe, the tests'
+# plaintext mock) cannot interpose on them
+$HIPCC -shared -Wl,-Bsymbolic-functions -o $OUT kernels.o host_keys.o engine.o shim.o scheduler.o io.o
 echo "built $(realpath $OUT)"
 # circuits: calls only the public tfhe API; symbols resolve at load time against
 # whichever provider is loaded first (libtfhe-hip.so, or the tests' plain mock)

@@ -122,23 +122,39 @@ static uint32_t bitrev32(uint32_t x, int bits) {
     return r;
 }
 
-// twiddles [prime][fwd,inv][N]: psi^{+-brv(i)} * R mod P
+// twiddles [prime][fwd,inv][N]: psi^{+-brv(i)} * R mod P, followed by the radix-4 quads
+// [prime][fwd,inv][N/2][4]: entry e = 2^s + t (stage pair (s, s+1), block t) holds, with
+// w1 = W[e], w2 = W[2e], w3 = W[2e+1]: {w2, w3, w1 w2, P - w1 w3}, all times R mod P
 static std::vector<uint32_t> make_twiddles(int N, uint32_t scale_out[2]) {
     int logn = 0;
     while ((1 << logn) < N) ++logn;
-    std::vector<uint32_t> tw((size_t)4 * N);
+    std::vector<uint32_t> tw((size_t)12 * N);
     for (int q = 0; q < 2; ++q) {
         const uint64_t P = NTT_P[q];
         const uint64_t psi = powmod_c(NTT_GEN[q], (P - 1) / (uint64_t)(2 * N), P);
         const uint64_t ipsi = powmod_c(psi, P - 2, P);
         const uint64_t R = NTT_R[q];
+        std::vector<uint64_t> plain[2] = {std::vector<uint64_t>(N), std::vector<uint64_t>(N)};
         uint64_t a = 1, b = 1;
         for (int i = 0; i < N; ++i) {
             const uint32_t j = bitrev32((uint32_t)i, logn);
-            tw[(size_t)(q * 2 + 0) * N + j] = (uint32_t)(a * R % P);
-            tw[(size_t)(q * 2 + 1) * N + j] = (uint32_t)(b * R % P);
+            plain[0][j] = a;
+            plain[1][j] = b;
             a = a * psi % P;
             b = b * ipsi % P;
+        }
+        for (int dir = 0; dir < 2; ++dir) {
+            const std::vector<uint64_t> &W = plain[dir];
+            uint32_t *t2 = &tw[(size_t)(q * 2 + dir) * N];
+            uint32_t *t4 = &tw[(size_t)4 * N + (size_t)(q * 2 + dir) * 2 * N];
+            for (int i = 0; i < N; ++i) t2[i] = (uint32_t)(W[i] * R % P);
+            for (int e = 1; e < N / 2; ++e) {
+                const uint64_t w1 = W[e], w2 = W[2 * e], w3 = W[2 * e + 1];
+                t4[4 * e + 0] = (uint32_t)(w2 * R % P);
+                t4[4 * e + 1] = (uint32_t)(w3 * R % P);
+                t4[4 * e + 2] = (uint32_t)(w1 * w2 % P * R % P);
+                t4[4 * e + 3] = (uint32_t)((P - w1 * w3 % P) % P * R % P);
+            }
         }
         // image scale: N^-1 (the inverse NTT is unscaled) times R (so that the
         // Montgomery reduction of sum x*img leaves sum x*bk / N)

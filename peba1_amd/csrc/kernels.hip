@@ -41,6 +41,10 @@ __device__ __forceinline__ PrimeCtx make_ctx(int q, const uint32_t *tw, int n_ri
     c.rmod = q ? NTT_R[1] : NTT_R[0];
     c.wf = tw + (size_t)(q * 2 + 0) * n_ring;
     c.wi = tw + (size_t)(q * 2 + 1) * n_ring;
+    // radix-4 quads follow the four radix-2 tables: [prime][fwd, inv][N/2] x 16 bytes
+    const uint4 *quads = reinterpret_cast<const uint4 *>(tw + (size_t)4 * n_ring);
+    c.qf = quads + (size_t)(q * 2 + 0) * (n_ring / 2);
+    c.qi = quads + (size_t)(q * 2 + 1) * (n_ring / 2);
     return c;
 }
 

@@ -25,7 +25,8 @@ struct DevKey {
     const uint32_t *bk_img;  // [n][kpl][prime 2][w 2][N] NTT image, Montgomery form, x N^-1
     const int32_t *ksk;      // [kN][t][base-1][ct_stride]
     const int32_t *ksk_zero; // one more row of ct_stride zeros (digit 0 of the key switch)
-    const uint32_t *tw;      // [prime 2][fwd, inv][N] twiddles, Montgomery form
+    const uint32_t *tw;      // [prime 2][fwd, inv][N] twiddles, Montgomery form, then the radix-4 quads
+                             // [prime 2][fwd, inv][N/2][4] = {w2, w3, w1 w2, P - w1 w3} (ntt_wave.hpp)
 };
 
 // One blind rotation: t = (0, c0) + sa * slot_a + sb * slot_b, then

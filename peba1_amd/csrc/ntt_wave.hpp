@@ -11,20 +11,35 @@
 //   RB stages in L0, transpose, RB stages in L1, transpose, LC stages in L2
 //   (4+4+2 for N=1024, 5+5+1 for N=2048).
 // inverse (Gentleman-Sande) runs the same path backwards and ends in L0.
-// A butterfly always pairs two registers of one lane; the twiddle of stage s is
+// A butterfly always pairs registers of one lane; the twiddle of stage s is
 // W[2^s + (top s bits of j)]: lane-uniform in L0 (scalar loads), per-lane but
-// contiguous in L1/L2 (dwordx2/x4 loads).
+// contiguous in L1/L2 (vector loads).
+//
+// Radix-4 steps with merged Montgomery reductions (tools/ntt_model_r4.py is the exact-integer
+// model).  Two consecutive stages s, s+1 of one pass act on four registers x0, x1 (partner in
+// stage s+1), x2 (partner in stage s), x3.  In a prime field a radix-4 butterfly saves no
+// twiddle product over two radix-2 stages (the fourth root of unity is an ordinary constant),
+// but it lets two products share ONE reduction -- the 64-bit sum x1*w2 + x3*w1w2 is reduced
+// once -- and drops a quarter of the additions:
+//   forward   A = redc(x2 w1)   S = redc(x1 w2 + x3 w1w2)   S' = redc(x1 w3 + x3 (P - w1w3))
+//             (y0, y1, y2, y3) = ((x0+A)+S, (x0+A)-S, (x0-A)+S', (x0-A)-S')
+//   inverse   s0 = x0+x1, s1 = x2+x3, d0 = x0-x1, d1 = x2-x3
+//             y0 = s0+s1   y2 = redc((s0-s1) w1)   y1 = redc(d0 w2 + d1 w3)
+//             y3 = redc(d0 w1w2 + d1 (P - w1w3))
+// 11 multiplier-class + 6 add instructions where two radix-2 stages take 12 + 8 (forward) or
+// 12 + 8 + renormalisations (inverse).  The twiddle products come from a second table
+// ("quads": {w2, w3, w1w2, P - w1w3} per (s, t), Montgomery form, one 16-byte load).
 //
 // Signed lazy arithmetic (values are int32 representatives, not canonical):
-//   Montgomery product r = b*w/R mod P with |r| < P for ANY |b| < 2^31, w in [0,P)
-//   (v_mad_i64_i32, v_mul_lo_u32, v_mad_i64_i32);
-//   forward butterfly (a,b) -> (a + r, a - r): 5 instructions, magnitudes grow by
-//   P per stage: digits (|d| <= 2^11) end below LOGN*P + 2^11 < 2^31, no reductions;
-//   inverse butterfly (a,b) -> (a + b, (a - b)*w): sums double, so the sum is
-//   renormalised (times R mod P, 3 more instructions) only at the stages where the
-//   next doubling would pass 16P < 2^31 (16*P1 = 2,146,828,304), and at the last:
-//   stages 8,4,0 for N=1024 and 9,5,1,0 for N=2048 (inv_renorm_mask below), for any
-//   input below 4P.
+//   Montgomery reduction r = T/R mod P with |r| <= |T|/2^32 + P/2 for any |T| < 2^63
+//   (v_mad_i64_i32 ..., v_mul_lo_u32, v_mad_i64_i32);
+//   forward: magnitudes grow by at most P + 3|x|P/2^32 per radix-4 step: digits (|d| <= 2^11) end
+//   below 6.1P (N=1024) / 6.7P (N=2048), inputs below P below 8.2P; no reductions;
+//   inverse: the plain sum y0 quadruples, so it is renormalised (times R mod P, 3 more
+//   instructions) at the steps where the next step could not take it -- every sum or difference
+//   of four inputs must stay below 2^31, i.e. inputs below 4P -- and at the last; the
+//   schedule (steps 1, 3, 5 of 5 for N=1024) is computed at compile time by make_inv_plan for
+//   inputs below 4P and checked there.
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -39,6 +54,8 @@ struct PrimeCtx {
     uint32_t rmod;     // R mod P: Montgomery multiplication by it is the identity (renormalisation)
     const uint32_t *__restrict__ wf;   // forward twiddles psi^brv(i) * R mod P, [N]
     const uint32_t *__restrict__ wi;   // inverse twiddles psi^-brv(i) * R mod P, [N]
+    const uint4 *__restrict__ qf;      // forward quads [N/2]: entry 2^s + t = {w2, w3, w1 w2, P - w1 w3} of the
+    const uint4 *__restrict__ qi;      // radix-4 step on stages (s, s+1), block t; inverse likewise
 };
 
 // signed Montgomery reduction: T*R^-1 mod P, |result| <= |T|/2^32 + P/2
@@ -79,21 +96,68 @@ __device__ __forceinline__ void gs_bfly(int32_t &a, int32_t &b, uint32_t w, cons
     a = RENORM ? mont_mul(a0 + b0, c.rmod, c.P, c.pinv) : a0 + b0;
     b = mont_mul(a0 - b0, w, c.P, c.pinv);
 }
-
-// stages of the inverse transform whose sums are renormalised (bit s set), for inputs < 4P
-constexpr uint32_t inv_renorm_mask(int logn) {
-    uint32_t mask = 0;
-    int bound = 4;                       // in units of P
-    for (int s = logn - 1; s >= 0; --s) {
-        // this stage forms a +- b < 2*bound*P (must stay <= 16P); without renormalisation the
-        // next stage would form sums below 4*bound*P
-        if (s == 0 || 4 * bound > 16) { mask |= 1u << s; bound = 1; }
-        else bound *= 2;
-    }
-    return mask;
+// two products, one reduction
+__device__ __forceinline__ int32_t mont_mul2(int32_t a, uint32_t wa, int32_t b, uint32_t wb, const PrimeCtx &c) {
+    return mont_redc((int64_t)a * (int64_t)(int32_t)wa + (int64_t)b * (int64_t)(int32_t)wb, c.P, c.pinv);
 }
-static_assert(inv_renorm_mask(10) == ((1u << 8) | (1u << 4) | 1u), "N=1024 renormalisation schedule");
-static_assert(inv_renorm_mask(11) == ((1u << 9) | (1u << 5) | (1u << 1) | 1u), "N=2048 renormalisation schedule");
+// radix-4 steps (header comment); q = {w2, w3, w1 w2, P - w1 w3}
+__device__ __forceinline__ void ct_bfly4(int32_t &x0, int32_t &x1, int32_t &x2, int32_t &x3, uint32_t w1, const uint4 &q,
+                                         const PrimeCtx &c) {
+    const int32_t A = mont_mul(x2, w1, c.P, c.pinv);
+    const int32_t S = mont_mul2(x1, q.x, x3, q.z, c);
+    const int32_t T = mont_mul2(x1, q.y, x3, q.w, c);
+    const int32_t u = x0 + A, v = x0 - A;
+    x0 = u + S; x1 = u - S; x2 = v + T; x3 = v - T;
+}
+template <bool RENORM>
+__device__ __forceinline__ void gs_bfly4(int32_t &x0, int32_t &x1, int32_t &x2, int32_t &x3, uint32_t w1, const uint4 &q,
+                                         const PrimeCtx &c) {
+    const int32_t s0 = x0 + x1, s1 = x2 + x3, d0 = x0 - x1, d1 = x2 - x3;
+    const int32_t sum = s0 + s1;
+    x0 = RENORM ? mont_mul(sum, c.rmod, c.P, c.pinv) : sum;
+    x2 = mont_mul(s0 - s1, w1, c.P, c.pinv);
+    x1 = mont_mul2(d0, q.x, d1, q.y, c);
+    x3 = mont_mul2(d0, q.z, d1, q.w, c);
+}
+
+// The steps of the inverse transform (descending: radix-4 pairs from the top of each pass, a
+// radix-2 stage where a pass has an odd stage left) and which of them renormalise their plain
+// sums, for inputs below 4P; magnitudes in units of the larger prime (tools/ntt_model_r4.py
+// inv_schedule is the same rule, checked there against the emulated 32-bit arithmetic).
+struct InvPlan {
+    int nsteps = 0;
+    int fan[12] = {};          // 4 = radix-4 step, 2 = radix-2 stage
+    bool renorm[12] = {};
+    double out_bound = 0;      // |outputs| / P
+};
+constexpr InvPlan make_inv_plan(int logn) {
+    InvPlan pl;
+    const int rb = logn - 6;
+    const int lo[3] = {2 * rb, rb, 0}, hi[3] = {logn, 2 * rb, rb};
+    for (int p = 0; p < 3; ++p) {
+        int cnt = hi[p] - lo[p];
+        while (cnt >= 2) { pl.fan[pl.nsteps++] = 4; cnt -= 2; }
+        if (cnt) pl.fan[pl.nsteps++] = 2;
+    }
+    const double P = 134176769.0, q = P / 4294967296.0, limit = 2147483647.0 / P;
+    double b = 4.0;
+    for (int k = 0; k < pl.nsteps; ++k) {
+        const double small = pl.fan[k] * b * q + 0.5, big = pl.fan[k] * b;
+        if (big > limit) { pl.out_bound = 1e9; return pl; }            // inputs too large: caught below
+        const bool last = k == pl.nsteps - 1;
+        const double next_in = big > small ? big : small;
+        const bool r = last || pl.fan[k + 1] * next_in > limit;
+        pl.renorm[k] = r;
+        b = r ? small : next_in;
+    }
+    pl.out_bound = b;
+    return pl;
+}
+static_assert(make_inv_plan(10).nsteps == 5 && make_inv_plan(10).renorm[0] && !make_inv_plan(10).renorm[1] &&
+              make_inv_plan(10).renorm[2] && !make_inv_plan(10).renorm[3] && make_inv_plan(10).renorm[4],
+              "N=1024 renormalisation schedule");
+static_assert(make_inv_plan(11).nsteps == 7 && make_inv_plan(10).out_bound < 1.0 && make_inv_plan(11).out_bound < 1.0,
+              "inverse NTT outputs must end below P");
 
 template <int LOGN>
 struct WaveNtt {
@@ -151,109 +215,112 @@ struct WaveNtt {
         }
     }
 
-    // One stage whose butterflies pair register bit RBIT of a lane; `tw` holds the
-    // REGS >> (RBIT+1) twiddles this lane needs, indexed by the register bits above RBIT.
-    template <int RBIT>
-    static __device__ __forceinline__ void fwd_stage(int32_t (&x)[REGS], const uint32_t (&tw)[REGS >> (RBIT + 1)],
-                                                     const PrimeCtx &c) {
-        constexpr int h = 1 << RBIT;
-#pragma unroll
-        for (int r = 0; r < REGS; ++r)
-            if (!(r & h)) ct_bfly(x[r], x[r | h], tw[r >> (RBIT + 1)], c);
+    // ---- steps ---------------------------------------------------------------------
+    // Register bit paired by stage S, and the twiddle-table index of this lane's first block
+    // of stage S (the lane needs REGS >> (rbit + 1) consecutive entries from there, selected by
+    // the register bits above rbit).
+    static constexpr int rbit_of(int S) { return S < RB ? RB - 1 - S : S < 2 * RB ? 2 * RB - 1 - S : LOGN - 1 - S; }
+    static constexpr int pass_end(int S) { return S < RB ? RB : S < 2 * RB ? 2 * RB : LOGN; }
+    static constexpr int pass_begin(int S) { return S < RB ? 0 : S < 2 * RB ? RB : 2 * RB; }
+    template <int S>
+    static __device__ __forceinline__ int tw_base(int lane) {
+        if constexpr (S < RB) return 1 << S;                                           // L0: lane-uniform
+        else if constexpr (S < 2 * RB) return (1 << S) + ((lane >> LC) << (S - RB));   // L1
+        else return (1 << S) + (lane << (S - 6));                                       // L2
     }
-    template <int RBIT, bool RENORM>
-    static __device__ __forceinline__ void inv_stage(int32_t (&x)[REGS], const uint32_t (&tw)[REGS >> (RBIT + 1)],
-                                                     const PrimeCtx &c) {
-        constexpr int h = 1 << RBIT;
+    template <int CNT>
+    static __device__ __forceinline__ void load_quads(uint4 (&q)[CNT], const uint4 *__restrict__ tab) {
 #pragma unroll
-        for (int r = 0; r < REGS; ++r)
-            if (!(r & h)) gs_bfly<RENORM>(x[r], x[r | h], tw[r >> (RBIT + 1)], c);
+        for (int e = 0; e < CNT; ++e) q[e] = tab[e];
     }
 
-    // stage S of the forward transform in the layout it belongs to
-    template <int S>
-    static __device__ __forceinline__ void fwd(int32_t (&x)[REGS], const PrimeCtx &c, int lane) {
-        if constexpr (S < RB) {                                   // L0: lane-uniform twiddles
-            constexpr int RBIT = RB - 1 - S;
-            uint32_t tw[REGS >> (RBIT + 1)];
+    // radix-2 stage S (a pass with an odd stage left)
+    template <int S, bool FWD, bool RENORM>
+    static __device__ __forceinline__ void step2(int32_t (&x)[REGS], const PrimeCtx &c, int lane) {
+        constexpr int RBIT = rbit_of(S), h = 1 << RBIT, CNT = REGS >> (RBIT + 1);
+        uint32_t tw[CNT];
+        load_tw<CNT>(tw, (FWD ? c.wf : c.wi) + tw_base<S>(lane));
 #pragma unroll
-            for (int e = 0; e < (REGS >> (RBIT + 1)); ++e) tw[e] = c.wf[(1 << S) + e];
-            fwd_stage<RBIT>(x, tw, c);
-        } else if constexpr (S < 2 * RB) {                        // L1
-            constexpr int RBIT = 2 * RB - 1 - S;
-            uint32_t tw[REGS >> (RBIT + 1)];
-            load_tw<(REGS >> (RBIT + 1))>(tw, c.wf + (1 << S) + ((lane >> LC) << (S - RB)));
-            fwd_stage<RBIT>(x, tw, c);
-        } else {                                                  // L2
-            constexpr int RBIT = LOGN - 1 - S;
-            uint32_t tw[REGS >> (RBIT + 1)];
-            load_tw<(REGS >> (RBIT + 1))>(tw, c.wf + (1 << S) + (lane << (S - 6)));
-            fwd_stage<RBIT>(x, tw, c);
-        }
+        for (int r = 0; r < REGS; ++r)
+            if (!(r & h)) {
+                if constexpr (FWD) ct_bfly(x[r], x[r | h], tw[r >> (RBIT + 1)], c);
+                else gs_bfly<RENORM>(x[r], x[r | h], tw[r >> (RBIT + 1)], c);
+            }
     }
-    template <int S>
-    static __device__ __forceinline__ void inv(int32_t (&x)[REGS], const PrimeCtx &c, int lane) {
-        constexpr bool RN = (inv_renorm_mask(LOGN) >> S) & 1u;
-        if constexpr (S < RB) {
-            constexpr int RBIT = RB - 1 - S;
-            uint32_t tw[REGS >> (RBIT + 1)];
+    // radix-4 step on stages S, S+1 of one pass
+    template <int S, bool FWD, bool RENORM>
+    static __device__ __forceinline__ void step4(int32_t (&x)[REGS], const PrimeCtx &c, int lane) {
+        static_assert(pass_end(S) == pass_end(S + 1), "a radix-4 step stays inside one pass");
+        constexpr int RBIT = rbit_of(S), h = 1 << RBIT, l = h >> 1, CNT = REGS >> (RBIT + 1);
+        uint32_t tw[CNT];
+        uint4 q[CNT];
+        const int base = tw_base<S>(lane);
+        load_tw<CNT>(tw, (FWD ? c.wf : c.wi) + base);
+        load_quads<CNT>(q, (FWD ? c.qf : c.qi) + base);
 #pragma unroll
-            for (int e = 0; e < (REGS >> (RBIT + 1)); ++e) tw[e] = c.wi[(1 << S) + e];
-            inv_stage<RBIT, RN>(x, tw, c);
-        } else if constexpr (S < 2 * RB) {
-            constexpr int RBIT = 2 * RB - 1 - S;
-            uint32_t tw[REGS >> (RBIT + 1)];
-            load_tw<(REGS >> (RBIT + 1))>(tw, c.wi + (1 << S) + ((lane >> LC) << (S - RB)));
-            inv_stage<RBIT, RN>(x, tw, c);
-        } else {
-            constexpr int RBIT = LOGN - 1 - S;
-            uint32_t tw[REGS >> (RBIT + 1)];
-            load_tw<(REGS >> (RBIT + 1))>(tw, c.wi + (1 << S) + (lane << (S - 6)));
-            inv_stage<RBIT, RN>(x, tw, c);
-        }
-    }
-    template <int S0, int S1>   // stages S0 .. S1-1 ascending
-    static __device__ __forceinline__ void fwd_range(int32_t (&x)[REGS], const PrimeCtx &c, int lane) {
-        if constexpr (S0 < S1) { fwd<S0>(x, c, lane); fwd_range<S0 + 1, S1>(x, c, lane); }
-    }
-    template <int S1, int S0>   // stages S1-1 .. S0 descending
-    static __device__ __forceinline__ void inv_range(int32_t (&x)[REGS], const PrimeCtx &c, int lane) {
-        if constexpr (S1 > S0) { inv<S1 - 1>(x, c, lane); inv_range<S1 - 1, S0>(x, c, lane); }
+        for (int r = 0; r < REGS; ++r)
+            if (!(r & (h | l))) {
+                const int e = r >> (RBIT + 1);
+                if constexpr (FWD) ct_bfly4(x[r], x[r | l], x[r | h], x[r | h | l], tw[e], q[e], c);
+                else gs_bfly4<RENORM>(x[r], x[r | l], x[r | h], x[r | h | l], tw[e], q[e], c);
+            }
     }
 
-    // forward NTT: x in L0 (natural order), |x| <= 2^11 -> L2, |x| < LOGN*P + 2^11
+    // forward stages S .. END-1 of one pass: pairs from the start, a single stage if one is left
+    template <int S, int END>
+    static __device__ __forceinline__ void fwd_pass(int32_t (&x)[REGS], const PrimeCtx &c, int lane) {
+        if constexpr (S + 1 < END) { step4<S, true, false>(x, c, lane); fwd_pass<S + 2, END>(x, c, lane); }
+        else if constexpr (S < END) { step2<S, true, false>(x, c, lane); }
+    }
+    // inverse stages TOP-1 .. BEGIN of one pass, descending: pairs from the top, then a single stage.
+    // K = index of the step in the whole inverse transform (selects its renormalisation, InvPlan).
+    template <int TOP, int BEGIN, int K>
+    static __device__ __forceinline__ void inv_pass(int32_t (&x)[REGS], const PrimeCtx &c, int lane) {
+        constexpr InvPlan plan = make_inv_plan(LOGN);
+        if constexpr (TOP - 2 >= BEGIN) {
+            static_assert(plan.fan[K] == 4, "plan and pass structure agree");
+            step4<TOP - 2, false, plan.renorm[K]>(x, c, lane);
+            inv_pass<TOP - 2, BEGIN, K + 1>(x, c, lane);
+        } else if constexpr (TOP - 1 >= BEGIN) {
+            static_assert(plan.fan[K] == 2, "plan and pass structure agree");
+            step2<TOP - 1, false, plan.renorm[K]>(x, c, lane);
+        }
+    }
+    static constexpr int steps_in(int stages) { return (stages + 1) / 2; }
+
+    // forward NTT: x in L0 (natural order) -> L2; |x| <= 2^11 ends below 6.7P, |x| < P below 8.2P
     static __device__ __forceinline__ void forward(int32_t (&x)[REGS], const PrimeCtx &c, uint32_t *scr, int lane) {
-        fwd_range<0, RB>(x, c, lane);
+        fwd_pass<0, RB>(x, c, lane);
 #pragma unroll
         for (int r = 0; r < REGS; ++r) scr[t1_l0_addr(lane, r)] = (uint32_t)x[r];
         wave_lds_fence();
         read_row(x, scr, lane);
         wave_lds_fence();
-        fwd_range<RB, 2 * RB>(x, c, lane);
+        fwd_pass<RB, 2 * RB>(x, c, lane);
 #pragma unroll
         for (int r = 0; r < REGS; ++r) scr[t2_l1_addr(lane, r)] = (uint32_t)x[r];
         wave_lds_fence();
         read_row(x, scr, lane);
         wave_lds_fence();
-        fwd_range<2 * RB, LOGN>(x, c, lane);
+        fwd_pass<2 * RB, LOGN>(x, c, lane);
     }
 
     // inverse NTT (unscaled: the 1/N is folded into the key image):
     // x in L2, |x| < 4P -> L0 (natural order), |x| < P
     static __device__ __forceinline__ void inverse(int32_t (&x)[REGS], const PrimeCtx &c, uint32_t *scr, int lane) {
-        inv_range<LOGN, 2 * RB>(x, c, lane);
+        inv_pass<LOGN, 2 * RB, 0>(x, c, lane);
         write_row(x, scr, lane);
         wave_lds_fence();
 #pragma unroll
         for (int r = 0; r < REGS; ++r) x[r] = (int32_t)scr[t2_l1_addr(lane, r)];
         wave_lds_fence();
-        inv_range<2 * RB, RB>(x, c, lane);
+        inv_pass<2 * RB, RB, steps_in(LC)>(x, c, lane);
         write_row(x, scr, lane);
         wave_lds_fence();
 #pragma unroll
         for (int r = 0; r < REGS; ++r) x[r] = (int32_t)scr[t1_l0_addr(lane, r)];
         wave_lds_fence();
-        inv_range<RB, 0>(x, c, lane);
+        inv_pass<RB, 0, steps_in(LC) + steps_in(RB)>(x, c, lane);
     }
 };
 

@@ -17,11 +17,23 @@ same numbers, calibrated on the CPU before this test was written) shape the tole
   * the gadget decomposition TRUNCATES (offset = sum Bg/2 * 2^(32-j Bgbit) centres the digits, not the
     remainder): the remainder lies in [0, 2 eps), and its mean, seen through the negacyclic product
     with the key and the later rotations, adds (n/2) (N eps)^2 / 12 to the variance (P80: +38 %);
-  * the bootstrapping key's noise is FIXED per key while (X^abar - 1) ACC is a window of +-mu/2-sized
-    coefficients, so the mean error over many gates under ONE key is not zero but a per-key constant
-    of size ~ sqrt(n N) sigma_bk Bg/8 (P128: 4e-4, observed -6e-4 on the oracle).
+  * the keys' noise is FIXED per key, so the mean error over many gates under ONE key is not zero
+    but a per-key constant.  The key-switching key dominates it: every (coefficient, digit position)
+    subtracts one of its base-1 fixed noise values (or nothing), i.e. on average
+    -(1/base) sum_v e[i][j][v]; summed over kN t positions that is a Gaussian of standard deviation
+    sqrt(kN t (base-1)) / base * sigma_ks = 1.2e-3 at P128 -- a third of the per-gate sigma, seen as
+    -6e-4 / +1.5e-3 for two keys.  The test computes this constant exactly from the KSK and the
+    secret key and removes it; what remains is the bootstrapping key's share, of scale
+    sqrt(n N) sigma_bk Bg/8 (4e-4 at P128).
 A missing key-switch rounding offset would shift the mean by N/2 * 2^-17 = 4e-3 (8e-3 at N = 2048),
-well outside either; a wrong KSK or gadget constant shows as a variance far off the prediction."""
+ten standard errors outside that; a wrong KSK or gadget constant shows as a variance far off the
+prediction.
+
+P2048 (BASELINE configs[4]: N=2048, Bg=2^6, l=3) keeps only 18 bits of the accumulator, so the
+truncation term alone is (n/2)(N eps)^2/12 = 6.5e-4: sigma = 0.026 against the decision margin
+1/8.  Single gates on fresh inputs decrypt (4.9 sigma); chained gates would fail at the percent
+level.  The set is a throughput microbenchmark, as SURVEY.md 8d lists it, not a usable circuit
+parameter set -- stated in DESIGN.md; this test checks that the measured noise is exactly that."""
 import numpy as np
 import pytest
 
@@ -43,6 +55,26 @@ def predicted_variance(pp, ks_stdev, bk_stdev, rotations=1):
     ks_typ = k * N * pp.ks_t * (1 - 2.0 ** -pp.ks_basebit) * ks_stdev ** 2 + k * N / 2 * delta ** 2 / 3
     key_bias = np.sqrt(n * N) * bk_stdev * Bg / 8              # scale of the per-key mean (fixed BK noise)
     return rotations * br_worst + ks_worst, rotations * br_typ + ks_typ, rotations * key_bias
+
+
+def ksk_mean_shift(ks, pp):
+    """The per-key constant the key-switching key adds to every output phase, averaged over uniform
+    digits: -(1/base) sum_{i,j} sum_{v>=1} e[i][j][v], e = phase(KSK[i][j][v]) - v s'_i 2^(32-(j+1)basebit)."""
+    base = 1 << pp.ks_basebit
+    n, kN, t = pp.n, pp.k * pp.N, pp.ks_t
+    ksk = ks.ksk().reshape(kN, t, base, n + 1)
+    s = ks.lwe_key().astype(np.int64)
+    s1 = ks.tlwe_key().astype(np.int64)
+    total = 0.0
+    for j in range(t):
+        rows = ksk[:, j, 1:, :].astype(np.int64)                             # [kN][base-1][n+1]
+        ph = rows[:, :, n] - rows[:, :, :n] @ s
+        msg = (np.arange(1, base)[None, :] * s1[:, None]) << (32 - (j + 1) * pp.ks_basebit)
+        e = (ph - msg) & 0xFFFFFFFF
+        e = np.where(e >= 1 << 31, e - (1 << 32), e)
+        assert np.abs(e).max() < 1 << 22                                      # these really are noise values
+        total += e.sum() / 2.0 ** 32
+    return -total / base
 
 
 def phase_errors(words, key_bits, want_bits):
@@ -69,6 +101,8 @@ def test_gate_output_noise_matches_tfhe_analysis(pname, ks_stdev, bk_stdev):
         rng = np.random.default_rng(pp.n)
         G = 1024                                               # per gate type: 4,096 gate instances per set
         s = ks.lwe_key().copy()
+        worst, typ, kb = predicted_variance(pp, ks_stdev, bk_stdev)
+        shift = ksk_mean_shift(ks, pp)
         errs, report = [], {}
         for name, fn in GATES.items():
             ba, bb = rng.integers(0, 2, G), rng.integers(0, 2, G)
@@ -77,15 +111,16 @@ def test_gate_output_noise_matches_tfhe_analysis(pname, ks_stdev, bk_stdev):
             r = api.CiphertextArray(pp, G)
             api.gate_batch(name, r, a, b, ks)
             e = phase_errors(r.words(), s, fn(ba, bb))
-            assert np.abs(e).max() < 0.05, f"{pname} {name}: an output phase is off by {np.abs(e).max():.4f} (wrong bit)"
+            assert np.abs(e).max() < min(0.124, 7 * np.sqrt(worst)), \
+                f"{pname} {name}: an output phase is off by {np.abs(e).max():.4f} (wrong bit or wrong key material)"
             errs.append(e)
             report[name] = (e.mean(), e.var())
         e = np.concatenate(errs)
-        worst, typ, kb = predicted_variance(pp, ks_stdev, bk_stdev)
         sem = np.sqrt(e.var() / e.size)
-        print(f"\n{pname}: {e.size} gates  mean {e.mean():+.3e} (sem {sem:.1e})  var {e.var():.3e}  "
+        print(f"\n{pname}: {e.size} gates  mean {e.mean():+.3e} = KSK constant {shift:+.3e} + {e.mean() - shift:+.3e} (sem {sem:.1e})  var {e.var():.3e}  "
               f"predicted typical {typ:.3e}  worst-case bound {worst:.3e}  per-key mean scale {kb:.1e}  per gate {report}")
-        assert abs(e.mean()) < 6 * sem + 4 * kb, f"{pname}: phase error is biased: mean {e.mean():.3e}, sem {sem:.1e}, per-key scale {kb:.1e}"
+        assert abs(e.mean() - shift) < 6 * sem + 4 * kb, \
+            f"{pname}: phase error is biased: mean {e.mean():.3e}, KSK constant {shift:.3e}, sem {sem:.1e}, BK scale {kb:.1e}"
         assert e.var() < worst, f"{pname}: output variance {e.var():.3e} above the worst-case bound {worst:.3e}"
         assert 0.7 * typ < e.var() < 1.4 * typ, f"{pname}: output variance {e.var():.3e}, analysis predicts {typ:.3e}"
 
@@ -104,10 +139,10 @@ def test_gate_output_noise_matches_tfhe_analysis(pname, ks_stdev, bk_stdev):
         em = phase_errors(out.words(), s, np.where(bs[0] > 0, bs[1], bs[2]))
         worst_m, typ_m, kbm = predicted_variance(pp, ks_stdev, bk_stdev, rotations=2)
         semm = np.sqrt(em.var() / em.size)
-        print(f"{pname}: {M} MUX  mean {em.mean():+.3e} (sem {semm:.1e})  var {em.var():.3e}  "
+        print(f"{pname}: {M} MUX  mean {em.mean():+.3e} = KSK constant {shift:+.3e} + {em.mean() - shift:+.3e} (sem {semm:.1e})  var {em.var():.3e}  "
               f"predicted typical {typ_m:.3e}  worst-case bound {worst_m:.3e}")
-        assert np.abs(em).max() < 0.06
-        assert abs(em.mean()) < 6 * semm + 4 * kbm
+        assert np.abs(em).max() < min(0.124, 7 * np.sqrt(worst_m))
+        assert abs(em.mean() - shift) < 6 * semm + 4 * kbm
         assert em.var() < worst_m and 0.7 * typ_m < em.var() < 1.4 * typ_m
     finally:
         ks.close()

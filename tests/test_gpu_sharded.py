@@ -126,7 +126,7 @@ def test_cfg4_identification_streams_matches_through_bounded_flushes(p128_keys):
     nslots, M, group = 128, 6, 3
     base = [(37 * i + 11) % 255 or 1 for i in range(nslots)]
     probe_v = [v + 1 for v in base]
-    templates_v = [identify.synthetic_template(base, k) for k in range(M)]
+    templates_v = [identify.synthetic_template(base, k + 1) for k in range(M)]      # k = 0 would be `base` itself
     genuine = 4
     templates_v[genuine] = base
     probe = circuits.EncryptedVector(pp, probe_v, 8, ks).to_device()

@@ -64,17 +64,22 @@ def test_ciphertext_roundtrip(small_key, tmp_path):
 
 
 def test_foreign_or_truncated_file_is_refused(small_key, tmp_path):
-    """fatal conditions abort with a message (the gate API returns void, as upstream)."""
+    """Malformed files are refused through the error channel (loaders return NULL, the Python
+    mirror raises with tfhe_hip_last_error()); the process is NOT aborted."""
+    from peba1_amd import api
     params, key = small_key
     key.save_cloud(tmp_path / "cloud.key")
     blob = (tmp_path / "cloud.key").read_bytes()
     (tmp_path / "foreign.key").write_bytes(b"\x00" * 64)
     (tmp_path / "short.key").write_bytes(blob[: len(blob) // 2])
     (tmp_path / "params.bin").write_bytes(blob)      # a cloud key where a parameter set is expected
-    for name, loader, needle in (("foreign.key", "CloudKeySet", "not a libtfhe-hip file"),
-                                 ("short.key", "CloudKeySet", "short read"),
-                                 ("params.bin", "ParameterSet", "expected 1")):
-        r = subprocess.run([sys.executable, "-c",
-                            "from peba1_amd import api; api.%s.load(%r)" % (loader, str(tmp_path / name))],
-                           capture_output=True, text=True)
-        assert r.returncode != 0 and needle in r.stderr, (name, r.stderr[-300:])
+    for name, loader, needle in (("foreign.key", api.CloudKeySet, "not a libtfhe-hip file"),
+                                 ("short.key", api.CloudKeySet, "short read"),
+                                 ("short.key", api.SecretKeySet, "expected 3"),
+                                 ("params.bin", api.ParameterSet, "expected 1")):
+        with pytest.raises(ValueError, match=needle):
+            loader.load(tmp_path / name)
+    # still alive and working afterwards
+    back = api.CloudKeySet.load(tmp_path / "cloud.key")
+    assert back.params.n == params.n
+    back.close()
