@@ -100,6 +100,7 @@ void Engine::ensure_init() {
     }
     if (const char *env = std::getenv("TFHE_HIP_LANE_PRIO")) lane_prio = std::atoi(env);
     if (const char *env = std::getenv("TFHE_HIP_BR_FAIR")) br_fair = std::atoi(env);
+    if (const char *env = std::getenv("TFHE_HIP_BR_VARIANT")) br_variant = std::atoi(env);
     for (auto &e : ev_) hip_check(hipEventCreate(&e), "hipEventCreate");
     inited_ = true;
 }
@@ -171,6 +172,7 @@ static DevParams make_dev_params(const Params &p) {
     d.mu = 1 << 29;
     d.wave_prio = 0;
     d.fair_shift = 0;
+    d.br_variant = 0;
     d.cu_arrivals = nullptr;
     d.wg_times = nullptr;
     return d;
@@ -308,7 +310,8 @@ void Engine::launch_br(const DeviceKeyImage *key, const int32_t *pool, const Rot
     if (count <= br4_max_rotations) {
         DevParams dp = key->dp;
         dp.wave_prio = wave_prio;
-        if (br_fair > 0 && count > cu_count_ && dp.N <= 1024) {   // only launches that put two workgroups on a CU
+        dp.br_variant = dp.N == 1024 && br_variant == 1 ? 1 : 0;
+        if (br_fair > 0 && count > cu_count_) {                   // only launches that put several workgroups on a CU
             if (!cu_arrivals_) {
                 hip_check(hipMalloc(&cu_arrivals_, 4096 * sizeof(uint32_t)), "hipMalloc(cu arrivals)");
                 hip_check(hipMemset(cu_arrivals_, 0, 4096 * sizeof(uint32_t)), "hipMemset(cu arrivals)");

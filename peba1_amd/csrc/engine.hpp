@@ -127,6 +127,9 @@ public:
     // cycles (0 = off: the hardware's oldest-first issue runs one at full speed and leaves the
     // other to finish alone with one wave per SIMD; measured optimum 2^16..2^20, tools/wg_times.py)
     int br_fair = 18;
+    // N = 1024: which form of the 4-wave blind-rotate kernel runs (kernels.hip BrTraits): 0 = wide
+    // (keeps D and 64-bit partial sums in registers, two workgroups per CU), 1 = lean (three per CU)
+    int br_variant = 0;
     // stream == nullptr: the engine's stream; lane selects the scratch buffer of the partial sums
     void launch_ks(const DeviceKeyImage *key, const int32_t *u_buf, const KsDesc *descs, int count, int32_t *pool,
                    hipStream_t stream = nullptr, int lane = 0);

@@ -27,6 +27,8 @@
 // barriers per step.
 // 2-wave form: wave q does all arithmetic modulo prime q (2l forward and 2 inverse NTTs per
 // step), swaps one residue polynomial with its partner and CRT-recombines the one it owns.
+#include <type_traits>
+
 #include "kernels.hpp"
 #include "ntt_wave.hpp"
 
@@ -146,11 +148,6 @@ __global__ __launch_bounds__(128) void negacyclic_kernel(const int32_t *__restri
 // ---------------------------------------------------------------------------
 // shared pieces of the blind-rotate kernels
 // ---------------------------------------------------------------------------
-struct StepConsts {
-    uint32_t dmask;      // Bg - 1
-    int32_t half;        // Bg/2
-};
-
 // K1: t = (0,c0) + sa*A + sb*B, modulus switch to Z_{2N} (tfhe modSwitchFromTorus32)
 template <int LOGN, int THREADS>
 __device__ __forceinline__ void prelude_modswitch(const DevParams &p, const RotDesc &rd, const int32_t *__restrict__ pool,
@@ -172,67 +169,164 @@ __device__ __forceinline__ uint32_t testvector_coef(int j, int barb, int32_t mu)
     return (idx & N) ? (uint32_t)(-mu) : (uint32_t)mu;
 }
 
+// How the 4-wave kernel trades registers and LDS for instructions.  The kernel is bound by
+// multiplier-class VALU issue plus dependency stalls, not by memory, so the
+// forms differ in what they keep in registers; all were measured at 4,096 rotations per launch
+// (profiles/r02_kernel_forms.txt):
+//   N = 1024, form 0 (default) "wide": D and both 64-bit row sums in registers, a pass's twiddles
+//       loaded one transpose ahead, three exchange buffers per wave: 241 VGPRs, two workgroups per
+//       CU, 43.4-44.7 ms.
+//   N = 1024, form 1 "lean": D recomputed per gadget row, the sum sent to the partner wave reduced per
+//       row (32-bit), one exchange buffer per wave (one more barrier per step): 161 VGPRs, THREE
+//       workgroups per CU -- and slower (50.7 ms: ~8 % more instructions, 45 % longer latency per
+//       workgroup, which the third workgroup does not buy back).  Kept selectable and tested.
+//   N = 2048 (32 coefficients per lane): only the lean form, with BOTH sums reduced per row, fits two
+//       workgroups per CU (256 VGPRs + 27 spilled words); 196 ms against 226-230 ms for the forms
+//       that keep a 64-bit sum or run one workgroup per CU.
+template <int LOGN, int V = 0>
+struct BrTraits {
+    static constexpr bool LEAN = LOGN != 10 || V == 1;
+    static constexpr bool KEEP_D = !LEAN;                       // D in registers across the gadget rows
+    static constexpr bool WIDE_SEND = !LEAN;                    // the sum sent to the partner wave: 64-bit, reduced once
+    static constexpr bool WIDE_KEEP = LOGN == 10;               // the sum this wave keeps: likewise
+    static constexpr bool EARLY_TW = true;                      // twiddles of a pass loaded before the transpose in front of it
+    static constexpr int ACC_RUNS = LOGN == 10 ? 3 : 2;
+    static constexpr bool MERGED_BUFFERS = LEAN;
+    static constexpr int WAVES_PER_SIMD = LOGN == 10 && V == 1 ? 3 : 2;
+};
+
+// The accumulator in LDS.  Each polynomial is kept as runs of N words, (acc, -acc[, acc]):
+// coefficient (j - abar) mod 2N of the negacyclic rotation X^abar * ACC is then word
+// ((lane - abar) mod 2N) + 64 r of that array.  With three runs that is one address per lane and
+// step, the 64 r being the immediate offset of the LDS read: no wrap and no sign selection per
+// coefficient.  With two runs the index is wrapped mod 2N per coefficient (one AND).
+template <int LOGN, int RUNS = BrTraits<LOGN, 0>::ACC_RUNS>
+struct AccLds {
+    static constexpr int N = 1 << LOGN;
+    uint32_t w[2][RUNS * N];
+    __device__ __forceinline__ void set(int u, int j, uint32_t v) {
+        w[u][j] = v; w[u][N + j] = 0u - v;
+        if constexpr (RUNS == 3) w[u][2 * N + j] = v;
+    }
+    __device__ __forceinline__ uint32_t get(int u, int j) const { return w[u][j]; }
+    // D[r] = coefficient 64 r + lane of (X^abar - 1) ACC_u, offset added and digit tops flipped
+    template <int REGS>
+    __device__ __forceinline__ void rotated_difference(uint32_t (&D)[REGS], int u, int lane, int abar, uint32_t offset) const {
+        const uint32_t base = (uint32_t)(lane - abar) & (uint32_t)(2 * N - 1);
+        const uint32_t *own = w[u] + lane;
+        if constexpr (RUNS == 3) {
+            const uint32_t *rot = w[u] + base;
+#pragma unroll
+            for (int r = 0; r < REGS; ++r) D[r] = (rot[r * 64] - own[r * 64] + offset) ^ offset;
+        } else {
+#pragma unroll
+            for (int r = 0; r < REGS; ++r)
+                D[r] = (w[u][(base + r * 64) & (uint32_t)(2 * N - 1)] - own[r * 64] + offset) ^ offset;
+        }
+    }
+};
+
 // One input polynomial u of one blind-rotate step, modulo the wave's prime:
 // D = (X^abar - 1) * ACC_u, its l gadget digits, forward NTT of each, and the
 // multiply-accumulate against key rows u*l+jj for both output polynomials
 // (acc0 <- output poly 0, acc1 <- output poly 1; exchanged when swap_outputs).
-template <int LOGN>
+// FRESH: acc0 / acc1 are written, not accumulated into -- the first row multiplies, the others
+// multiply-add (no zeroing of 4*REGS registers per step); otherwise every row accumulates.
+// Digits (tfhe tGswTorus32PolynomialDecompH): digit_jj = ((D + offset) >> s_jj) & (Bg-1)) - Bg/2.  The
+// offset holds Bg/2 at every digit position, so XOR-ing it back flips the top bit of every digit
+// field, and a digit is then the SIGNED bit field of (D + offset) ^ offset: one v_bfe_i32.
+template <int LOGN, bool FRESH, bool KEEP_D, bool EARLY_TW, typename Acc0T, typename Acc1T>
 __device__ __forceinline__ void forward_poly(const DevParams &p, const DevKey &key, const PrimeCtx &c,
-                                             const StepConsts &sc, const uint32_t *lds_acc_u, uint32_t *scr,
+                                             const AccLds<LOGN> &lds_acc, uint32_t *scr,
                                              int lane, int q, int i, int u, int abar, bool swap_outputs,
-                                             int64_t (&acc0)[WaveNtt<LOGN>::REGS], int64_t (&acc1)[WaveNtt<LOGN>::REGS]) {
+                                             Acc0T (&acc0)[WaveNtt<LOGN>::REGS], Acc1T (&acc1)[WaveNtt<LOGN>::REGS]) {
     using NTT = WaveNtt<LOGN>;
     constexpr int N = NTT::N, REGS = NTT::REGS, G4 = REGS / 4;
-    uint32_t D[REGS];
-#pragma unroll
-    for (int r = 0; r < REGS; ++r) {
-        const int j = r * 64 + lane;
-        const int idx = (j - abar) & (2 * N - 1);
-        const uint32_t v = lds_acc_u[idx & (N - 1)];
-        D[r] = ((idx & N) ? 0u - v : v) - lds_acc_u[j] + p.decomp_offset;   // offset pre-added
-    }
-#pragma unroll 1
-    for (int jj = 0; jj < p.l; ++jj) {
+    // a sum is kept in 64 bits and reduced once, or Montgomery-reduced per row (|.| < 0.72P each)
+    constexpr bool WIDE0 = sizeof(Acc0T) == 8, WIDE1 = sizeof(Acc1T) == 8;
+    uint32_t Dk[KEEP_D ? REGS : 1];
+    if constexpr (KEEP_D) lds_acc.template rotated_difference<REGS>(Dk, u, lane, abar, p.decomp_offset);
+    const int o0 = swap_outputs ? N / 4 : 0, o1 = N / 4 - o0;          // uint4 offset of output poly 0 / 1
+    const int width = p.Bgbit;
+    auto row = [&](int jj, auto first) {
         const int prow = u * p.l + jj;
         const uint4 *bp = reinterpret_cast<const uint4 *>(
                               key.bk_img + ((size_t)((size_t)i * p.kpl + prow) * 2 + q) * 2 * N) + lane;
+        // key rows: both output polynomials are requested before the transform so that their latency
+        // hides under it -- except where registers are short (!KEEP_D: N = 2048), where the second
+        // polynomial's row is requested after the transform and multiplied last
         uint4 b0[G4], b1[G4];
-        const int o0 = swap_outputs ? N / 4 : 0, o1 = N / 4 - o0;      // uint4 offset of output poly 0 / 1
 #pragma unroll
-        for (int g = 0; g < G4; ++g) { b0[g] = bp[o0 + g * 64]; b1[g] = bp[o1 + g * 64]; }
-
-        const int shift = 32 - (jj + 1) * p.Bgbit;
+        for (int g = 0; g < G4; ++g) b0[g] = bp[o0 + g * 64];
+        if constexpr (KEEP_D) {
+#pragma unroll
+            for (int g = 0; g < G4; ++g) b1[g] = bp[o1 + g * 64];
+        }
+        const int shift = 32 - (jj + 1) * width;
         int32_t x[REGS];
+        if constexpr (KEEP_D) {
 #pragma unroll
-        for (int r = 0; r < REGS; ++r) x[r] = (int32_t)((D[r] >> shift) & sc.dmask) - sc.half;   // signed digit
-        NTT::forward(x, c, scr, lane);
+            for (int r = 0; r < REGS; ++r) x[r] = __builtin_amdgcn_sbfe((int32_t)Dk[r], shift, width);   // signed digit
+        } else {
+            uint32_t D[REGS];
+            lds_acc.template rotated_difference<REGS>(D, u, lane, abar, p.decomp_offset);
+#pragma unroll
+            for (int r = 0; r < REGS; ++r) x[r] = __builtin_amdgcn_sbfe((int32_t)D[r], shift, width);
+        }
+        NTT::template forward<EARLY_TW>(x, c, scr, lane);
+        if constexpr (!KEEP_D) {
+#pragma unroll
+            for (int g = 0; g < G4; ++g) b1[g] = bp[o1 + g * 64];
+        }
 #pragma unroll
         for (int g = 0; g < G4; ++g) {
-            acc0[4 * g + 0] += (int64_t)x[4 * g + 0] * (int32_t)b0[g].x;
-            acc0[4 * g + 1] += (int64_t)x[4 * g + 1] * (int32_t)b0[g].y;
-            acc0[4 * g + 2] += (int64_t)x[4 * g + 2] * (int32_t)b0[g].z;
-            acc0[4 * g + 3] += (int64_t)x[4 * g + 3] * (int32_t)b0[g].w;
-            acc1[4 * g + 0] += (int64_t)x[4 * g + 0] * (int32_t)b1[g].x;
-            acc1[4 * g + 1] += (int64_t)x[4 * g + 1] * (int32_t)b1[g].y;
-            acc1[4 * g + 2] += (int64_t)x[4 * g + 2] * (int32_t)b1[g].z;
-            acc1[4 * g + 3] += (int64_t)x[4 * g + 3] * (int32_t)b1[g].w;
+            const int32_t bb0[4] = {(int32_t)b0[g].x, (int32_t)b0[g].y, (int32_t)b0[g].z, (int32_t)b0[g].w};
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const int r = 4 * g + e;
+                if constexpr (decltype(first)::value) {
+                    if constexpr (WIDE0) acc0[r] = (int64_t)x[r] * bb0[e];
+                    else acc0[r] = mont_redc((int64_t)x[r] * bb0[e], c.P, c.pinv);
+                } else {
+                    if constexpr (WIDE0) acc0[r] += (int64_t)x[r] * bb0[e];
+                    else acc0[r] += mont_redc((int64_t)x[r] * bb0[e], c.P, c.pinv);
+                }
+            }
         }
-    }
+#pragma unroll
+        for (int g = 0; g < G4; ++g) {
+            const int32_t bb1[4] = {(int32_t)b1[g].x, (int32_t)b1[g].y, (int32_t)b1[g].z, (int32_t)b1[g].w};
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const int r = 4 * g + e;
+                if constexpr (decltype(first)::value) {
+                    if constexpr (WIDE1) acc1[r] = (int64_t)x[r] * bb1[e];
+                    else acc1[r] = mont_redc((int64_t)x[r] * bb1[e], c.P, c.pinv);
+                } else {
+                    if constexpr (WIDE1) acc1[r] += (int64_t)x[r] * bb1[e];
+                    else acc1[r] += mont_redc((int64_t)x[r] * bb1[e], c.P, c.pinv);
+                }
+            }
+        }
+    };
+    row(0, std::integral_constant<bool, FRESH>{});
+#pragma unroll 1
+    for (int jj = 1; jj < p.l; ++jj) row(jj, std::false_type{});
 }
 
 // sample extract at index 0 (tfhe tLweExtractLweSampleIndex) + optional raw accumulator dump
 template <int LOGN, int THREADS>
 __device__ __forceinline__ void extract_sample(const DevParams &p, const RotDesc &rd,
-                                               const uint32_t (*lds_acc)[1 << LOGN],
+                                               const AccLds<LOGN> &acc,
                                                int32_t *__restrict__ u_buf, int32_t *__restrict__ acc_dbg, int tid) {
     constexpr int N = 1 << LOGN;
     int32_t *u = u_buf + (size_t)rd.u_index * p.u_stride;
     for (int j = tid; j < N; j += THREADS)
-        u[j] = (int32_t)(j == 0 ? lds_acc[0][0] : 0u - lds_acc[0][N - j]);
-    if (tid == 0) u[N] = (int32_t)lds_acc[1][0];
+        u[j] = (int32_t)(j == 0 ? acc.get(0, 0) : 0u - acc.get(0, N - j));
+    if (tid == 0) u[N] = (int32_t)acc.get(1, 0);
     if (acc_dbg) {
         int32_t *d = acc_dbg + (size_t)blockIdx.x * 2 * N;
-        for (int j = tid; j < 2 * N; j += THREADS) d[j] = (int32_t)lds_acc[j >> LOGN][j & (N - 1)];
+        for (int j = tid; j < 2 * N; j += THREADS) d[j] = (int32_t)acc.get(j >> LOGN, j & (N - 1));
     }
 }
 
@@ -248,7 +342,7 @@ __global__ __launch_bounds__(128) void blind_rotate_kernel(DevParams p, DevKey k
                                                            int32_t *__restrict__ u_buf, int32_t *__restrict__ acc_dbg) {
     using NTT = WaveNtt<LOGN>;
     constexpr int N = NTT::N, REGS = NTT::REGS;
-    __shared__ __align__(16) uint32_t lds_acc[2][N];
+    __shared__ __align__(16) AccLds<LOGN> lds_acc;
     __shared__ __align__(16) uint32_t lds_scr[2][NTT::SCRATCH_WORDS];
     __shared__ uint16_t lds_bar[1024 + 8];
 
@@ -267,23 +361,19 @@ __global__ __launch_bounds__(128) void blind_rotate_kernel(DevParams p, DevKey k
 #pragma unroll
         for (int r = 0; r < REGS; ++r) {
             const int j = r * 64 + lane;
-            lds_acc[q][j] = q == 0 ? 0u : testvector_coef<LOGN>(j, barb, p.mu);
+            lds_acc.set(q, j, q == 0 ? 0u : testvector_coef<LOGN>(j, barb, p.mu));
         }
     }
     __syncthreads();
 
-    const StepConsts sc{(1u << p.Bgbit) - 1u, 1 << (p.Bgbit - 1)};
 
     for (int i = 0; i < n; ++i) {
         const int abar = __builtin_amdgcn_readfirstlane((int)lds_bar[i]);
         if (abar == 0) continue;                            // tfhe_blindRotate_FFT skips these too
 
         int64_t acc0[REGS], acc1[REGS];
-#pragma unroll
-        for (int r = 0; r < REGS; ++r) { acc0[r] = 0; acc1[r] = 0; }
-#pragma unroll 1
-        for (int u = 0; u < 2; ++u)
-            forward_poly<LOGN>(p, key, c, sc, lds_acc[u], scr, lane, q, i, u, abar, false, acc0, acc1);
+        forward_poly<LOGN, true, true, true>(p, key, c, lds_acc, scr, lane, q, i, 0, abar, false, acc0, acc1);
+        forward_poly<LOGN, false, true, true>(p, key, c, lds_acc, scr, lane, q, i, 1, abar, false, acc0, acc1);
 
         uint32_t y0[REGS], y1[REGS];
         finish_inverse<LOGN>(acc0, y0, c, scr, lane);
@@ -296,13 +386,15 @@ __global__ __launch_bounds__(128) void blind_rotate_kernel(DevParams p, DevKey k
             for (int r = 0; r < REGS; ++r) scr[r * 64 + lane] = y1[r];
             __syncthreads();
 #pragma unroll
-            for (int r = 0; r < REGS; ++r) lds_acc[0][r * 64 + lane] += crt_to_torus(y0[r], oscr[r * 64 + lane]);
+            for (int r = 0; r < REGS; ++r)
+                lds_acc.set(0, r * 64 + lane, lds_acc.get(0, r * 64 + lane) + crt_to_torus(y0[r], oscr[r * 64 + lane]));
         } else {
 #pragma unroll
             for (int r = 0; r < REGS; ++r) scr[r * 64 + lane] = y0[r];
             __syncthreads();
 #pragma unroll
-            for (int r = 0; r < REGS; ++r) lds_acc[1][r * 64 + lane] += crt_to_torus(oscr[r * 64 + lane], y1[r]);
+            for (int r = 0; r < REGS; ++r)
+                lds_acc.set(1, r * 64 + lane, lds_acc.get(1, r * 64 + lane) + crt_to_torus(oscr[r * 64 + lane], y1[r]));
         }
         __syncthreads();
     }
@@ -341,30 +433,36 @@ __device__ unsigned long long g_stamps[4][8];
 // inverse NTT for output polynomial u, and shares the CRT with wave (1-q,u).
 // Three workgroup barriers per step.  N = 1024: 2 workgroups per CU; N = 2048: 1.
 // ---------------------------------------------------------------------------
-// LDS of one 4-wave workgroup
-template <int LOGN>
+// LDS of one 4-wave workgroup.  Each wave has three exchange areas: scratch of its NTT transposes
+// (private), the partial sums it sends to the wave of the other input polynomial, and the
+// residues of the half its CRT partner recombines.  MERGED_BUFFERS: all three are one buffer (the
+// uses are disjoint in time given one more barrier per step, see blind_rotate4_body).
+template <int LOGN, int V = 0>
 struct Br4Lds {
     using NTT = WaveNtt<LOGN>;
-    uint32_t acc[2][NTT::N];                       // the accumulator, resident for all n steps
-    uint32_t scr[4][NTT::SCRATCH_WORDS];           // wave-private NTT transposes
-    uint32_t x1[4][NTT::SCRATCH_WORDS];            // partial sums of the partner's output poly
-    uint32_t x2[4][NTT::N / 2];                    // residues of the half the partner recombines
+    static constexpr bool MERGED = BrTraits<LOGN, V>::MERGED_BUFFERS;
+    AccLds<LOGN> acc;                              // the accumulator (signed runs), resident for all n steps
+    uint32_t buf[MERGED ? 1 : 3][4][NTT::SCRATCH_WORDS];
     uint16_t bar[1024 + 8];                        // modulus-switched mask and body
+    __device__ __forceinline__ uint32_t *scr(int wv) { return buf[0][wv]; }
+    __device__ __forceinline__ uint32_t *x1(int wv) { return buf[MERGED ? 0 : 1][wv]; }
+    __device__ __forceinline__ uint32_t *x2(int wv) { return buf[MERGED ? 0 : 2][wv]; }
 };
 
 // prelude + modulus switch + the n-step blind rotation of one descriptor; the result is left
 // in sh.acc (complete for every thread on return)
-template <int LOGN>
+template <int LOGN, int V = 0>
 __device__ __forceinline__ void blind_rotate4_body(const DevParams &p, const DevKey &key,
                                                    const int32_t *__restrict__ pool, const RotDesc &rd,
-                                                   Br4Lds<LOGN> &sh, int tid, int parity = 0) {
+                                                   Br4Lds<LOGN, V> &sh, int tid, int parity = 0) {
     using NTT = WaveNtt<LOGN>;
+    using TR = BrTraits<LOGN, V>;
     constexpr int N = NTT::N, REGS = NTT::REGS, HALF = REGS / 2;
     const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int q = wv & 1, u = wv >> 1;
     const int lane = tid & 63;
     const PrimeCtx c = make_ctx(q, key.tw, N);
-    uint32_t *scr = sh.scr[wv];
+    uint32_t *scr = sh.scr(wv);
     const int n = p.n;
 
     prelude_modswitch<LOGN, 256>(p, rd, pool, sh.bar, tid);
@@ -374,70 +472,80 @@ __device__ __forceinline__ void blind_rotate4_body(const DevParams &p, const Dev
 #pragma unroll
         for (int r = 0; r < REGS; ++r) {
             const int j = r * 64 + lane;
-            sh.acc[u][j] = u == 0 ? 0u : testvector_coef<LOGN>(j, barb, p.mu);
+            sh.acc.set(u, j, u == 0 ? 0u : testvector_coef<LOGN>(j, barb, p.mu));
         }
     }
     __syncthreads();
 
-    const StepConsts sc{(1u << p.Bgbit) - 1u, 1 << (p.Bgbit - 1)};
     STAMP_DECL;
 
     for (int i = 0; i < n; ++i) {
         if (p.fair_shift > 0) {
-            // time slices of 2^fair_shift shader cycles: both workgroups read the same CU clock,
+            // time slices of 2^fair_shift shader cycles: the workgroups of a CU read the same clock,
             // so exactly one of them holds the higher priority at any moment
             const uint32_t slice = (uint32_t)(__builtin_amdgcn_s_memtime() >> p.fair_shift);
-            if ((slice ^ (uint32_t)parity) & 1u) __builtin_amdgcn_s_setprio(1);
+            if (slice % (uint32_t)TR::WAVES_PER_SIMD == (uint32_t)parity) __builtin_amdgcn_s_setprio(1);
             else __builtin_amdgcn_s_setprio(0);
         }
         const int abar = __builtin_amdgcn_readfirstlane((int)sh.bar[i]);
         if (abar == 0) continue;
         STAMP(0);
 
-        int64_t acc0[REGS], acc1[REGS];
-#pragma unroll
-        for (int r = 0; r < REGS; ++r) { acc0[r] = 0; acc1[r] = 0; }
         // acc0 accumulates output poly u (kept), acc1 output poly 1-u (sent to wave (q,1-u))
-        forward_poly<LOGN>(p, key, c, sc, sh.acc[u], scr, lane, q, i, u, abar, u != 0, acc0, acc1);
+        using Acc0T = typename std::conditional<TR::WIDE_KEEP, int64_t, int32_t>::type;
+        using Acc1T = typename std::conditional<TR::WIDE_SEND, int64_t, int32_t>::type;
+        Acc0T acc0[REGS];
+        Acc1T acc1[REGS];
+        forward_poly<LOGN, true, TR::KEEP_D, TR::EARLY_TW, Acc0T, Acc1T>(p, key, c, sh.acc, scr, lane, q, i, u, abar, u != 0,
+                                                                        acc0, acc1);
         STAMP(1);
 
-        int32_t t[REGS], send[REGS];
+        int32_t t[REGS];
+        {
+            int32_t send[REGS];
 #pragma unroll
-        for (int r = 0; r < REGS; ++r) {
-            t[r] = mont_redc(acc0[r], c.P, c.pinv);                // l rows: |.| < 1.6P
-            send[r] = mont_redc(acc1[r], c.P, c.pinv);
+            for (int r = 0; r < REGS; ++r) {
+                if constexpr (TR::WIDE_KEEP) t[r] = mont_redc((int64_t)acc0[r], c.P, c.pinv);   // l rows: |.| < 1.2P
+                else t[r] = (int32_t)acc0[r];
+                if constexpr (TR::WIDE_SEND) send[r] = mont_redc((int64_t)acc1[r], c.P, c.pinv);
+                else send[r] = (int32_t)acc1[r];                       // l rows reduced one by one: |.| < 2.2P
+            }
+            NTT::write_row(send, sh.x1(wv), lane);
         }
-        NTT::write_row(send, sh.x1[wv], lane);
         STAMP(2);
         __syncthreads();
         STAMP(3);
         {
             int32_t other[REGS];
-            NTT::read_row(other, sh.x1[wv ^ 2], lane);
+            NTT::read_row(other, sh.x1(wv ^ 2), lane);
 #pragma unroll
-            for (int r = 0; r < REGS; ++r) t[r] += other[r];       // |.| < 3.1P
+            for (int r = 0; r < REGS; ++r) t[r] += other[r];       // |.| < 3.4P (the inverse takes < 4P)
         }
-        NTT::inverse(t, c, scr, lane);
+        if constexpr (TR::MERGED_BUFFERS) __syncthreads();         // partner has read my sums: the buffer is scratch again
+        NTT::template inverse<TR::EARLY_TW>(t, c, scr, lane);
         uint32_t y[REGS];
 #pragma unroll
         for (int r = 0; r < REGS; ++r) y[r] = canon(t[r], c.P);
         STAMP(4);
 
         // CRT of output poly u is split with wave (1-q,u): wave q recombines registers [q*HALF, (q+1)*HALF)
-        const uint32_t *ox = sh.x2[wv ^ 1];
+        const uint32_t *ox = sh.x2(wv ^ 1);
+        uint32_t *mx = sh.x2(wv);
         if (q == 0) {
 #pragma unroll
-            for (int r = 0; r < HALF; ++r) sh.x2[wv][r * 64 + lane] = y[HALF + r];
-            __syncthreads();
-#pragma unroll
-            for (int r = 0; r < HALF; ++r) sh.acc[u][r * 64 + lane] += crt_to_torus(y[r], ox[r * 64 + lane]);
-        } else {
-#pragma unroll
-            for (int r = 0; r < HALF; ++r) sh.x2[wv][r * 64 + lane] = y[r];
+            for (int r = 0; r < HALF; ++r) mx[r * 64 + lane] = y[HALF + r];
             __syncthreads();
 #pragma unroll
             for (int r = 0; r < HALF; ++r)
-                sh.acc[u][(HALF + r) * 64 + lane] += crt_to_torus(ox[r * 64 + lane], y[HALF + r]);
+                sh.acc.set(u, r * 64 + lane, sh.acc.get(u, r * 64 + lane) + crt_to_torus(y[r], ox[r * 64 + lane]));
+        } else {
+#pragma unroll
+            for (int r = 0; r < HALF; ++r) mx[r * 64 + lane] = y[r];
+            __syncthreads();
+#pragma unroll
+            for (int r = 0; r < HALF; ++r)
+                sh.acc.set(u, (HALF + r) * 64 + lane,
+                           sh.acc.get(u, (HALF + r) * 64 + lane) + crt_to_torus(ox[r * 64 + lane], y[HALF + r]));
         }
         STAMP(5);
         __syncthreads();
@@ -446,18 +554,19 @@ __device__ __forceinline__ void blind_rotate4_body(const DevParams &p, const Dev
     STAMP_FLUSH;
 }
 
-template <int LOGN>
-__global__ __launch_bounds__(256, LOGN == 10 ? 2 : 1) void blind_rotate4_kernel(
+template <int LOGN, int V>
+__global__ __launch_bounds__(256, (BrTraits<LOGN, V>::WAVES_PER_SIMD)) void blind_rotate4_kernel(
     DevParams p, DevKey key, const int32_t *__restrict__ pool, const RotDesc *__restrict__ rots,
     int32_t *__restrict__ u_buf, int32_t *__restrict__ acc_dbg) {
-    __shared__ __align__(16) Br4Lds<LOGN> sh;
+    __shared__ __align__(16) Br4Lds<LOGN, V> sh;
+    constexpr int PER_CU = BrTraits<LOGN, V>::WAVES_PER_SIMD;     // workgroups (of 4 waves) that share a CU
     // urgent lane: these waves win issue arbitration against a co-resident workgroup of the
     // other lane, so a critical-chain gate runs at nearly its stand-alone latency
     if (p.wave_prio) __builtin_amdgcn_s_setprio(3);
-    // Two workgroups share a CU, and the hardware issues oldest-wave-first: launched together,
+    // Workgroups share a CU, and the hardware issues oldest-wave-first: launched together,
     // one runs at its stand-alone speed (4.1 ms) and the other gets the leftover issue slots,
     // then finishes alone with one wave per SIMD (6.45 ms in all; tools/wg_times.py).  Letting
-    // the two swap issue priority every few steps keeps both at two waves per SIMD to the end.
+    // them take turns at the higher issue priority keeps all of them running to the end.
     int parity = 0;
     if (p.fair_shift > 0) {
         __shared__ int s_parity;
@@ -465,7 +574,7 @@ __global__ __launch_bounds__(256, LOGN == 10 ? 2 : 1) void blind_rotate4_kernel(
             const uint32_t hw = __builtin_amdgcn_s_getreg((31 << 11) | (0 << 6) | 4);    // HW_ID
             const uint32_t xcc = __builtin_amdgcn_s_getreg((3 << 11) | (0 << 6) | 20);   // XCC_ID
             const uint32_t cu = ((xcc & 0xFu) << 8) | ((hw >> 8) & 0xFFu);              // cu, sh, se
-            s_parity = (int)(atomicAdd(&p.cu_arrivals[cu], 1u) & 1u);
+            s_parity = (int)(atomicAdd(&p.cu_arrivals[cu], 1u) % (uint32_t)PER_CU);
         }
         __syncthreads();
         parity = __builtin_amdgcn_readfirstlane(s_parity);
@@ -478,7 +587,7 @@ __global__ __launch_bounds__(256, LOGN == 10 ? 2 : 1) void blind_rotate4_kernel(
                                      ((((xcc & 0xF) << 8) | ((hw >> 8) & 0xFF)) << 48);
     }
     const RotDesc rd = rots[blockIdx.x];
-    blind_rotate4_body<LOGN>(p, key, pool, rd, sh, threadIdx.x, parity);
+    blind_rotate4_body<LOGN, V>(p, key, pool, rd, sh, threadIdx.x, parity);
     extract_sample<LOGN, 256>(p, rd, sh.acc, u_buf, acc_dbg, threadIdx.x);
     if (p.wg_times && threadIdx.x == 0) p.wg_times[2 * blockIdx.x + 1] = __builtin_amdgcn_s_memtime();
 }
@@ -557,16 +666,16 @@ __device__ __forceinline__ void keyswitch_in_wg(const DevParams &p, const DevKey
             }
         }
     }
-    uint4 *part = reinterpret_cast<uint4 *>(sh.scr[wv]);       // >= ct_stride words per wave
+    uint4 *part = reinterpret_cast<uint4 *>(sh.scr(wv));       // >= ct_stride words per wave
 #pragma unroll
     for (int m = 0; m < NCOL; ++m)
         if (lane + 64 * m < nvec) part[lane + 64 * m] = acc[m];
     __syncthreads();
     for (int col = tid; col < nvec; col += 256) {
-        uint4 s = reinterpret_cast<const uint4 *>(sh.scr[0])[col];
+        uint4 s = reinterpret_cast<const uint4 *>(sh.scr(0))[col];
 #pragma unroll
         for (int w = 1; w < 4; ++w) {
-            const uint4 v = reinterpret_cast<const uint4 *>(sh.scr[w])[col];
+            const uint4 v = reinterpret_cast<const uint4 *>(sh.scr(w))[col];
             s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
         }
         uint32_t o[4] = {s.x, s.y, s.z, s.w};
@@ -581,7 +690,7 @@ __device__ __forceinline__ void keyswitch_in_wg(const DevParams &p, const DevKey
 }
 
 template <int LOGN>
-__global__ __launch_bounds__(256, LOGN == 10 ? 2 : 1) void gate_dataflow_kernel(
+__global__ __launch_bounds__(256, 1) void gate_dataflow_kernel(
     DevParams p, DevKey key, int32_t *__restrict__ pool, const GateTask *__restrict__ tasks, int ntasks,
     int32_t *__restrict__ done, int32_t *__restrict__ ctrl /* [0] next task, [1] error, [2..] debug */) {
     constexpr int N = 1 << LOGN;
@@ -647,15 +756,15 @@ __global__ __launch_bounds__(256, LOGN == 10 ? 2 : 1) void gate_dataflow_kernel(
             const RotDesc r0{task.slot_a, task.slot_b, task.sa, task.sb, task.c0, 0};
             blind_rotate4_body<LOGN>(p, key, pool, r0, sh, tid);
             DF_MARK(3);
-            for (int j = tid; j < N; j += 256) lds_u[j] = j == 0 ? sh.acc[0][0] : 0u - sh.acc[0][N - j];
-            if (tid == 0) lds_u[N] = sh.acc[1][0];
+            for (int j = tid; j < N; j += 256) lds_u[j] = j == 0 ? sh.acc.get(0, 0) : 0u - sh.acc.get(0, N - j);
+            if (tid == 0) lds_u[N] = sh.acc.get(1, 0);
             __syncthreads();
             if (task.kind == TASK_MUX) {
                 // tfhe bootsMUX: second rotation on (-1/8 - a + c), then u1 + u2 + (0, 1/8)
                 const RotDesc r1{task.slot_a, task.slot_c, -1, 1, task.c0, 0};
                 blind_rotate4_body<LOGN>(p, key, pool, r1, sh, tid);
-                for (int j = tid; j < N; j += 256) lds_u[j] += j == 0 ? sh.acc[0][0] : 0u - sh.acc[0][N - j];
-                if (tid == 0) lds_u[N] += sh.acc[1][0] + (uint32_t)p.mu;
+                for (int j = tid; j < N; j += 256) lds_u[j] += j == 0 ? sh.acc.get(0, 0) : 0u - sh.acc.get(0, N - j);
+                if (tid == 0) lds_u[N] += sh.acc.get(1, 0) + (uint32_t)p.mu;
                 __syncthreads();
             }
             DF_MARK(4);
@@ -926,7 +1035,7 @@ void launch_blind_rotate(hipStream_t s, const DevParams &p, const DevKey &key, c
     if (count <= 0) return;
     // the 2-wave form exists for N = 1024 only; N = 2048 always takes the 4-wave form
     if (p.N == 2048)
-        hipLaunchKernelGGL(blind_rotate4_kernel<11>, dim3(count), dim3(256), 0, s, p, key, pool, rots, u_buf, acc_dbg);
+        hipLaunchKernelGGL((blind_rotate4_kernel<11, 0>), dim3(count), dim3(256), 0, s, p, key, pool, rots, u_buf, acc_dbg);
     else
         hipLaunchKernelGGL(blind_rotate_kernel<10>, dim3(count), dim3(128), 0, s, p, key, pool, rots, u_buf, acc_dbg);
 }
@@ -941,10 +1050,11 @@ void read_stamps(unsigned long long *out, bool reset) {
 void launch_blind_rotate4(hipStream_t s, const DevParams &p, const DevKey &key, const int32_t *pool,
                           const RotDesc *rots, int count, int32_t *u_buf, int32_t *acc_dbg) {
     if (count <= 0) return;
-    if (p.N == 2048)
-        hipLaunchKernelGGL(blind_rotate4_kernel<11>, dim3(count), dim3(256), 0, s, p, key, pool, rots, u_buf, acc_dbg);
-    else
-        hipLaunchKernelGGL(blind_rotate4_kernel<10>, dim3(count), dim3(256), 0, s, p, key, pool, rots, u_buf, acc_dbg);
+#define BR4(LN, VV) hipLaunchKernelGGL((blind_rotate4_kernel<LN, VV>), dim3(count), dim3(256), 0, s, p, key, pool, rots, u_buf, acc_dbg)
+    if (p.N == 2048) BR4(11, 0);
+    else if (p.br_variant == 1) BR4(10, 1);
+    else BR4(10, 0);
+#undef BR4
 }
 
 void launch_gate_dataflow(hipStream_t s, const DevParams &p, const DevKey &key, int32_t *pool, const GateTask *tasks,

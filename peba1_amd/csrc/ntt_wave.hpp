@@ -234,93 +234,143 @@ struct WaveNtt {
         for (int e = 0; e < CNT; ++e) q[e] = tab[e];
     }
 
-    // radix-2 stage S (a pass with an odd stage left)
-    template <int S, bool FWD, bool RENORM>
-    static __device__ __forceinline__ void step2(int32_t (&x)[REGS], const PrimeCtx &c, int lane) {
-        constexpr int RBIT = rbit_of(S), h = 1 << RBIT, CNT = REGS >> (RBIT + 1);
+    // The twiddles of one pass, held in registers: loaded as early as the caller can afford --
+    // a pass's loads are issued BEFORE the LDS transpose that precedes it (the compiler cannot
+    // do that itself: the transposes are fenced against memory reordering), so their latency
+    // overlaps the transpose instead of stalling the first butterflies; the first pass's loads are
+    // issued by the caller ahead of whatever it does before the transform.
+    // Forward passes take radix-4 steps from their first stage (S, S+2, ...) and a radix-2 stage if
+    // one is left; inverse passes take radix-4 steps from their top (TOP-2, TOP-4, ...) likewise.
+    template <int S, int END, bool FWD>
+    struct PassTw {
+        static constexpr bool PAIR = FWD ? (S + 1 < END) : (END - 2 >= S);     // inverse: [S, END) descending from END
+        static constexpr int STAGE = FWD ? S : (PAIR ? END - 2 : END - 1);    // the (lower) stage this step starts at
+        static constexpr int CNT = REGS >> (rbit_of(STAGE) + 1);
         uint32_t tw[CNT];
-        load_tw<CNT>(tw, (FWD ? c.wf : c.wi) + tw_base<S>(lane));
-#pragma unroll
-        for (int r = 0; r < REGS; ++r)
-            if (!(r & h)) {
-                if constexpr (FWD) ct_bfly(x[r], x[r | h], tw[r >> (RBIT + 1)], c);
-                else gs_bfly<RENORM>(x[r], x[r | h], tw[r >> (RBIT + 1)], c);
-            }
-    }
-    // radix-4 step on stages S, S+1 of one pass
-    template <int S, bool FWD, bool RENORM>
-    static __device__ __forceinline__ void step4(int32_t (&x)[REGS], const PrimeCtx &c, int lane) {
-        static_assert(pass_end(S) == pass_end(S + 1), "a radix-4 step stays inside one pass");
-        constexpr int RBIT = rbit_of(S), h = 1 << RBIT, l = h >> 1, CNT = REGS >> (RBIT + 1);
-        uint32_t tw[CNT];
-        uint4 q[CNT];
-        const int base = tw_base<S>(lane);
-        load_tw<CNT>(tw, (FWD ? c.wf : c.wi) + base);
-        load_quads<CNT>(q, (FWD ? c.qf : c.qi) + base);
-#pragma unroll
-        for (int r = 0; r < REGS; ++r)
-            if (!(r & (h | l))) {
-                const int e = r >> (RBIT + 1);
-                if constexpr (FWD) ct_bfly4(x[r], x[r | l], x[r | h], x[r | h | l], tw[e], q[e], c);
-                else gs_bfly4<RENORM>(x[r], x[r | l], x[r | h], x[r | h | l], tw[e], q[e], c);
-            }
-    }
-
-    // forward stages S .. END-1 of one pass: pairs from the start, a single stage if one is left
-    template <int S, int END>
-    static __device__ __forceinline__ void fwd_pass(int32_t (&x)[REGS], const PrimeCtx &c, int lane) {
-        if constexpr (S + 1 < END) { step4<S, true, false>(x, c, lane); fwd_pass<S + 2, END>(x, c, lane); }
-        else if constexpr (S < END) { step2<S, true, false>(x, c, lane); }
-    }
-    // inverse stages TOP-1 .. BEGIN of one pass, descending: pairs from the top, then a single stage.
-    // K = index of the step in the whole inverse transform (selects its renormalisation, InvPlan).
-    template <int TOP, int BEGIN, int K>
-    static __device__ __forceinline__ void inv_pass(int32_t (&x)[REGS], const PrimeCtx &c, int lane) {
-        constexpr InvPlan plan = make_inv_plan(LOGN);
-        if constexpr (TOP - 2 >= BEGIN) {
-            static_assert(plan.fan[K] == 4, "plan and pass structure agree");
-            step4<TOP - 2, false, plan.renorm[K]>(x, c, lane);
-            inv_pass<TOP - 2, BEGIN, K + 1>(x, c, lane);
-        } else if constexpr (TOP - 1 >= BEGIN) {
-            static_assert(plan.fan[K] == 2, "plan and pass structure agree");
-            step2<TOP - 1, false, plan.renorm[K]>(x, c, lane);
+        uint4 q[PAIR ? CNT : 1];
+        PassTw<FWD ? S + (PAIR ? 2 : 1) : S, FWD ? END : END - (PAIR ? 2 : 1), FWD> rest;
+        __device__ __forceinline__ void load(const PrimeCtx &c, int lane) {
+            const int base = tw_base<STAGE>(lane);
+            load_tw<CNT>(tw, (FWD ? c.wf : c.wi) + base);
+            if constexpr (PAIR) load_quads<CNT>(q, (FWD ? c.qf : c.qi) + base);
+            rest.load(c, lane);
         }
+    };
+    template <int S, bool FWD>
+    struct PassTw<S, S, FWD> {
+        __device__ __forceinline__ void load(const PrimeCtx &, int) {}
+    };
+    using FwdTw0 = PassTw<0, RB, true>;
+    using FwdTw1 = PassTw<RB, 2 * RB, true>;
+    using FwdTw2 = PassTw<2 * RB, LOGN, true>;
+    using InvTw2 = PassTw<2 * RB, LOGN, false>;
+    using InvTw1 = PassTw<RB, 2 * RB, false>;
+    using InvTw0 = PassTw<0, RB, false>;
+
+    // one step with its twiddles in registers
+    template <int STAGE, bool PAIR, bool FWD, bool RENORM, int CNT>
+    static __device__ __forceinline__ void step(int32_t (&x)[REGS], const uint32_t (&tw)[CNT], const uint4 *q,
+                                                const PrimeCtx &c) {
+        constexpr int RBIT = rbit_of(STAGE), h = 1 << RBIT, l = h >> 1;
+        static_assert(CNT == (REGS >> (RBIT + 1)), "twiddle count of the step");
+        if constexpr (PAIR) {
+            static_assert(pass_end(STAGE) == pass_end(STAGE + 1), "a radix-4 step stays inside one pass");
+#pragma unroll
+            for (int r = 0; r < REGS; ++r)
+                if (!(r & (h | l))) {
+                    const int e = r >> (RBIT + 1);
+                    if constexpr (FWD) ct_bfly4(x[r], x[r | l], x[r | h], x[r | h | l], tw[e], q[e], c);
+                    else gs_bfly4<RENORM>(x[r], x[r | l], x[r | h], x[r | h | l], tw[e], q[e], c);
+                }
+        } else {
+#pragma unroll
+            for (int r = 0; r < REGS; ++r)
+                if (!(r & h)) {
+                    if constexpr (FWD) ct_bfly(x[r], x[r | h], tw[r >> (RBIT + 1)], c);
+                    else gs_bfly<RENORM>(x[r], x[r | h], tw[r >> (RBIT + 1)], c);
+                }
+        }
+    }
+    // all steps of a pass; K = index of the step in the whole inverse transform (InvPlan)
+    template <int S, int END>
+    static __device__ __forceinline__ void fwd_pass(int32_t (&x)[REGS], const PrimeCtx &c, const PassTw<S, END, true> &t) {
+        using T = PassTw<S, END, true>;
+        step<T::STAGE, T::PAIR, true, false, T::CNT>(x, t.tw, t.q, c);
+        if constexpr (S + (T::PAIR ? 2 : 1) < END) fwd_pass(x, c, t.rest);
+    }
+    template <int K, int S, int END>
+    static __device__ __forceinline__ void inv_pass(int32_t (&x)[REGS], const PrimeCtx &c, const PassTw<S, END, false> &t) {
+        using T = PassTw<S, END, false>;
+        constexpr InvPlan plan = make_inv_plan(LOGN);
+        static_assert(plan.fan[K] == (T::PAIR ? 4 : 2), "plan and pass structure agree");
+        step<T::STAGE, T::PAIR, false, plan.renorm[K], T::CNT>(x, t.tw, t.q, c);
+        if constexpr (END - (T::PAIR ? 2 : 1) > S) inv_pass<K + 1>(x, c, t.rest);
     }
     static constexpr int steps_in(int stages) { return (stages + 1) / 2; }
 
-    // forward NTT: x in L0 (natural order) -> L2; |x| <= 2^11 ends below 6.7P, |x| < P below 8.2P
-    static __device__ __forceinline__ void forward(int32_t (&x)[REGS], const PrimeCtx &c, uint32_t *scr, int lane) {
-        fwd_pass<0, RB>(x, c, lane);
+    // forward NTT: x in L0 (natural order) -> L2; |x| <= 2^11 ends below 6.7P, |x| < P below 8.2P.
+    // t0: the first pass's twiddles, loaded by the caller (FwdTw0 t0; t0.load(c, lane);)
+    // EARLY = false: a pass's twiddles are loaded after the transpose instead (fewer live registers).
+    template <bool EARLY = true>
+    static __device__ __forceinline__ void forward(int32_t (&x)[REGS], const PrimeCtx &c, uint32_t *scr, int lane,
+                                                   const FwdTw0 &t0) {
+        fwd_pass(x, c, t0);
+        FwdTw1 t1;
+        if constexpr (EARLY) t1.load(c, lane);
 #pragma unroll
         for (int r = 0; r < REGS; ++r) scr[t1_l0_addr(lane, r)] = (uint32_t)x[r];
         wave_lds_fence();
         read_row(x, scr, lane);
         wave_lds_fence();
-        fwd_pass<RB, 2 * RB>(x, c, lane);
+        if constexpr (!EARLY) t1.load(c, lane);
+        fwd_pass(x, c, t1);
+        FwdTw2 t2;
+        if constexpr (EARLY) t2.load(c, lane);
 #pragma unroll
         for (int r = 0; r < REGS; ++r) scr[t2_l1_addr(lane, r)] = (uint32_t)x[r];
         wave_lds_fence();
         read_row(x, scr, lane);
         wave_lds_fence();
-        fwd_pass<2 * RB, LOGN>(x, c, lane);
+        if constexpr (!EARLY) t2.load(c, lane);
+        fwd_pass(x, c, t2);
+    }
+    template <bool EARLY = true>
+    static __device__ __forceinline__ void forward(int32_t (&x)[REGS], const PrimeCtx &c, uint32_t *scr, int lane) {
+        FwdTw0 t0;
+        t0.load(c, lane);
+        forward<EARLY>(x, c, scr, lane, t0);
     }
 
     // inverse NTT (unscaled: the 1/N is folded into the key image):
-    // x in L2, |x| < 4P -> L0 (natural order), |x| < P
-    static __device__ __forceinline__ void inverse(int32_t (&x)[REGS], const PrimeCtx &c, uint32_t *scr, int lane) {
-        inv_pass<LOGN, 2 * RB, 0>(x, c, lane);
+    // x in L2, |x| < 4P -> L0 (natural order), |x| < P.  t2: the first pass's twiddles (InvTw2), as above
+    template <bool EARLY = true>
+    static __device__ __forceinline__ void inverse(int32_t (&x)[REGS], const PrimeCtx &c, uint32_t *scr, int lane,
+                                                   const InvTw2 &t2) {
+        inv_pass<0>(x, c, t2);
+        InvTw1 t1;
+        if constexpr (EARLY) t1.load(c, lane);
         write_row(x, scr, lane);
         wave_lds_fence();
 #pragma unroll
         for (int r = 0; r < REGS; ++r) x[r] = (int32_t)scr[t2_l1_addr(lane, r)];
         wave_lds_fence();
-        inv_pass<2 * RB, RB, steps_in(LC)>(x, c, lane);
+        if constexpr (!EARLY) t1.load(c, lane);
+        inv_pass<steps_in(LC)>(x, c, t1);
+        InvTw0 t0;
+        if constexpr (EARLY) t0.load(c, lane);
         write_row(x, scr, lane);
         wave_lds_fence();
 #pragma unroll
         for (int r = 0; r < REGS; ++r) x[r] = (int32_t)scr[t1_l0_addr(lane, r)];
         wave_lds_fence();
-        inv_pass<RB, 0, steps_in(LC) + steps_in(RB)>(x, c, lane);
+        if constexpr (!EARLY) t0.load(c, lane);
+        inv_pass<steps_in(LC) + steps_in(RB)>(x, c, t0);
+    }
+    template <bool EARLY = true>
+    static __device__ __forceinline__ void inverse(int32_t (&x)[REGS], const PrimeCtx &c, uint32_t *scr, int lane) {
+        InvTw2 t2;
+        t2.load(c, lane);
+        inverse<EARLY>(x, c, scr, lane, t2);
     }
 };
 

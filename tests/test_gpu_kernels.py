@@ -274,3 +274,39 @@ def test_external_product_single_step(oracle, p128_keys, pname):
     finally:
         if own:
             ks.close()
+
+
+def test_lean_kernel_form_is_bit_exact(p128_keys, oracle):
+    """kernels.hip BrTraits: the lean form of the N = 1024 blind-rotate kernel (three workgroups
+    per CU: D recomputed per gadget row, partial sums reduced per row, one exchange buffer per
+    wave, four barriers per step) computes the same integers as the wide form and the oracle --
+    accumulators of real gate preludes and of the edge inputs, and a 700-gate launch that puts
+    three workgroups on every CU."""
+    from peba1_amd import api
+    pp, ks, oks = p128_keys
+    r = oracle.Rng(29)
+    cts = oks.encrypt(r, [0, 1, 1, 1])
+    lins = [oks.prelude("NAND", cts[0], cts[1]), oks.prelude("XOR", cts[2], cts[3])]
+    edge = np.zeros((3, pp.words), dtype=np.int32)
+    edge[1, :] = np.int32(1 << 21)
+    edge[2, ::2] = np.int32(-(1 << 21))
+    edge[2, 5] = np.int32(-2**31)
+    lins = np.concatenate([np.stack(lins), edge])
+    rng = np.random.default_rng(31)
+    many = rng.integers(-2**31, 2**31, (700, pp.words), dtype=np.int64).astype(np.int32)
+    got = {}
+    try:
+        for v in (0, 1):
+            api.set_tuning("br_variant", v)
+            got[v] = (api.kernel_bootstrap_woks(ks, lins, want_acc=True), api.kernel_bootstrap_woks(ks, many))
+    finally:
+        api.set_tuning("br_variant", 0)
+    for c in range(len(lins)):
+        bar = oks.modswitch_ct(lins[c])
+        want = oks.blind_rotate(bar[:-1], bar[-1])
+        assert (got[1][0][1][c] == want).all(), f"lean form, accumulator {c}"
+        assert (got[1][0][0][c] == oks.sample_extract(want)).all()
+    assert (got[0][0][1] == got[1][0][1]).all()
+    assert (got[0][1] == got[1][1]).all(), "700-wide launch: wide and lean forms differ"
+    for c in (0, 350, 699):
+        assert (got[1][1][c] == oks.bootstrap_woks(many[c])).all()

@@ -50,7 +50,7 @@ def predicted_variance(pp, ks_stdev, bk_stdev, rotations=1):
     br_worst = n * (k + 1) * l * N * (Bg / 2) ** 2 * bk_stdev ** 2 + n * (1 + k * N) * eps ** 2
     br_typ = (n * (k + 1) * l * N * (Bg ** 2 / 12) * bk_stdev ** 2 + n * (1 + k * N / 2) * eps ** 2 / 3
               + (n / 2) * (N * eps) ** 2 / 12)                 # truncating decomposition, see the module docstring
-    br_worst += n * (1 + k * N) * (2 * eps) ** 2
+    br_worst += n * (1 + k * N) * (2 * eps) ** 2 + n * (N * eps) ** 2 / 4     # every key bit 1, every mean at its extreme
     ks_worst = k * N * pp.ks_t * ks_stdev ** 2 + k * N * delta ** 2
     ks_typ = k * N * pp.ks_t * (1 - 2.0 ** -pp.ks_basebit) * ks_stdev ** 2 + k * N / 2 * delta ** 2 / 3
     key_bias = np.sqrt(n * N) * bk_stdev * Bg / 8              # scale of the per-key mean (fixed BK noise)
@@ -111,7 +111,8 @@ def test_gate_output_noise_matches_tfhe_analysis(pname, ks_stdev, bk_stdev):
             r = api.CiphertextArray(pp, G)
             api.gate_batch(name, r, a, b, ks)
             e = phase_errors(r.words(), s, fn(ba, bb))
-            assert np.abs(e).max() < min(0.124, 7 * np.sqrt(worst)), \
+            # (a wrong bit would sit 0.25 away; at P2048 the legitimate noise itself reaches the 1/8 margin)
+            assert np.abs(e).max() < 6.5 * np.sqrt(typ), \
                 f"{pname} {name}: an output phase is off by {np.abs(e).max():.4f} (wrong bit or wrong key material)"
             errs.append(e)
             report[name] = (e.mean(), e.var())
@@ -141,7 +142,7 @@ def test_gate_output_noise_matches_tfhe_analysis(pname, ks_stdev, bk_stdev):
         semm = np.sqrt(em.var() / em.size)
         print(f"{pname}: {M} MUX  mean {em.mean():+.3e} = KSK constant {shift:+.3e} + {em.mean() - shift:+.3e} (sem {semm:.1e})  var {em.var():.3e}  "
               f"predicted typical {typ_m:.3e}  worst-case bound {worst_m:.3e}")
-        assert np.abs(em).max() < min(0.124, 7 * np.sqrt(worst_m))
+        assert np.abs(em).max() < 6.5 * np.sqrt(typ_m)
         assert abs(em.mean() - shift) < 6 * semm + 4 * kbm
         assert em.var() < worst_m and 0.7 * typ_m < em.var() < 1.4 * typ_m
     finally:

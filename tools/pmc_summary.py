@@ -8,8 +8,21 @@ traffic is such a stream (blind rotate: key image, key switch: KSK rows) is doub
 usage: pmc_summary.py <fetch_counter_collection.csv> <write_counter_collection.csv> <out.json>"""
 import collections
 import csv
+import hashlib
 import json
+import os
 import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def kernel_source_hash():
+    """bench.py quotes this summary only while the kernel sources it was measured on are unchanged"""
+    h = hashlib.sha256()
+    for f in ("kernels.hip", "ntt_wave.hpp", "ntt_field.hpp"):
+        with open(os.path.join(ROOT, "peba1_amd", "csrc", f), "rb") as fh:
+            h.update(fh.read())
+    return h.hexdigest()[:16]
 
 WIDE_STREAM = ("blind_rotate_kernel", "blind_rotate4_kernel", "keyswitch_kernel", "keyswitch_tile_kernel")
 
@@ -35,7 +48,8 @@ def main():
     fetch = collect(sys.argv[1], "FETCH_SIZE")
     write = collect(sys.argv[2], "WRITE_SIZE")
     out = {"source": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE, separate passes of: bench.py --steps 1 --warmup 0",
-           "corrections": "KiB -> bytes; FETCH_SIZE x2 for 16 B/lane coalesced streams (gfx950)", "kernels": {}}
+           "corrections": "KiB -> bytes; FETCH_SIZE x2 for 16 B/lane coalesced streams (gfx950)",
+           "kernels_sha16": kernel_source_hash(), "kernels": {}}
     for k in sorted(set(fetch) | set(write)):
         n = fetch.get(k, write.get(k))[0]
         f_raw = fetch.get(k, [0, 0.0])[1] * 1024.0
