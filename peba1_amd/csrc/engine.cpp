@@ -101,6 +101,7 @@ void Engine::ensure_init() {
     if (const char *env = std::getenv("TFHE_HIP_LANE_PRIO")) lane_prio = std::atoi(env);
     if (const char *env = std::getenv("TFHE_HIP_BR_FAIR")) br_fair = std::atoi(env);
     if (const char *env = std::getenv("TFHE_HIP_BR_VARIANT")) br_variant = std::atoi(env);
+    if (const char *env = std::getenv("TFHE_HIP_BR_TABLE")) br_digit_table = std::atoi(env) != 0;
     for (auto &e : ev_) hip_check(hipEventCreate(&e), "hipEventCreate");
     inited_ = true;
 }
@@ -173,6 +174,7 @@ static DevParams make_dev_params(const Params &p) {
     d.wave_prio = 0;
     d.fair_shift = 0;
     d.br_variant = 0;
+    d.digit_table = 1;
     d.cu_arrivals = nullptr;
     d.wg_times = nullptr;
     return d;
@@ -311,6 +313,7 @@ void Engine::launch_br(const DeviceKeyImage *key, const int32_t *pool, const Rot
         DevParams dp = key->dp;
         dp.wave_prio = wave_prio;
         dp.br_variant = dp.N == 1024 && br_variant == 1 ? 1 : 0;
+        dp.digit_table = br_digit_table;
         if (br_fair > 0 && count > cu_count_) {                   // only launches that put several workgroups on a CU
             if (!cu_arrivals_) {
                 hip_check(hipMalloc(&cu_arrivals_, 4096 * sizeof(uint32_t)), "hipMalloc(cu arrivals)");

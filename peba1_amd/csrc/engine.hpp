@@ -130,6 +130,9 @@ public:
     // N = 1024: which form of the 4-wave blind-rotate kernel runs (kernels.hip BrTraits): 0 = wide
     // (keeps D and 64-bit partial sums in registers, two workgroups per CU), 1 = lean (three per CU)
     int br_variant = 0;
+    // 1 = the first radix-4 step of the forward transforms looks digit products up in LDS (gadget digits
+    // of at most 7 bits); 0 = multiplies (env TFHE_HIP_BR_TABLE, tuning "br_digit_table")
+    int br_digit_table = 1;
     // stream == nullptr: the engine's stream; lane selects the scratch buffer of the partial sums
     void launch_ks(const DeviceKeyImage *key, const int32_t *u_buf, const KsDesc *descs, int count, int32_t *pool,
                    hipStream_t stream = nullptr, int lane = 0);

@@ -47,6 +47,7 @@ __device__ __forceinline__ PrimeCtx make_ctx(int q, const uint32_t *tw, int n_ri
     const uint4 *quads = reinterpret_cast<const uint4 *>(tw + (size_t)4 * n_ring);
     c.qf = quads + (size_t)(q * 2 + 0) * (n_ring / 2);
     c.qi = quads + (size_t)(q * 2 + 1) * (n_ring / 2);
+    c.dtab = nullptr;
     return c;
 }
 
@@ -235,7 +236,7 @@ struct AccLds {
 // Digits (tfhe tGswTorus32PolynomialDecompH): digit_jj = ((D + offset) >> s_jj) & (Bg-1)) - Bg/2.  The
 // offset holds Bg/2 at every digit position, so XOR-ing it back flips the top bit of every digit
 // field, and a digit is then the SIGNED bit field of (D + offset) ^ offset: one v_bfe_i32.
-template <int LOGN, bool FRESH, bool KEEP_D, bool EARLY_TW, typename Acc0T, typename Acc1T>
+template <int LOGN, bool FRESH, bool KEEP_D, bool EARLY_TW, bool TABLE, typename Acc0T, typename Acc1T>
 __device__ __forceinline__ void forward_poly(const DevParams &p, const DevKey &key, const PrimeCtx &c,
                                              const AccLds<LOGN> &lds_acc, uint32_t *scr,
                                              int lane, int q, int i, int u, int abar, bool swap_outputs,
@@ -265,15 +266,12 @@ __device__ __forceinline__ void forward_poly(const DevParams &p, const DevKey &k
         const int shift = 32 - (jj + 1) * width;
         int32_t x[REGS];
         if constexpr (KEEP_D) {
-#pragma unroll
-            for (int r = 0; r < REGS; ++r) x[r] = __builtin_amdgcn_sbfe((int32_t)Dk[r], shift, width);   // signed digit
+            NTT::template forward_digits<EARLY_TW, TABLE>(x, Dk, shift, width, c, scr, lane);
         } else {
             uint32_t D[REGS];
             lds_acc.template rotated_difference<REGS>(D, u, lane, abar, p.decomp_offset);
-#pragma unroll
-            for (int r = 0; r < REGS; ++r) x[r] = __builtin_amdgcn_sbfe((int32_t)D[r], shift, width);
+            NTT::template forward_digits<EARLY_TW, TABLE>(x, D, shift, width, c, scr, lane);
         }
-        NTT::template forward<EARLY_TW>(x, c, scr, lane);
         if constexpr (!KEEP_D) {
 #pragma unroll
             for (int g = 0; g < G4; ++g) b1[g] = bp[o1 + g * 64];
@@ -372,8 +370,8 @@ __global__ __launch_bounds__(128) void blind_rotate_kernel(DevParams p, DevKey k
         if (abar == 0) continue;                            // tfhe_blindRotate_FFT skips these too
 
         int64_t acc0[REGS], acc1[REGS];
-        forward_poly<LOGN, true, true, true>(p, key, c, lds_acc, scr, lane, q, i, 0, abar, false, acc0, acc1);
-        forward_poly<LOGN, false, true, true>(p, key, c, lds_acc, scr, lane, q, i, 1, abar, false, acc0, acc1);
+        forward_poly<LOGN, true, true, true, false>(p, key, c, lds_acc, scr, lane, q, i, 0, abar, false, acc0, acc1);
+        forward_poly<LOGN, false, true, true, false>(p, key, c, lds_acc, scr, lane, q, i, 1, abar, false, acc0, acc1);
 
         uint32_t y0[REGS], y1[REGS];
         finish_inverse<LOGN>(acc0, y0, c, scr, lane);
@@ -442,16 +440,20 @@ struct Br4Lds {
     using NTT = WaveNtt<LOGN>;
     static constexpr bool MERGED = BrTraits<LOGN, V>::MERGED_BUFFERS;
     AccLds<LOGN> acc;                              // the accumulator (signed runs), resident for all n steps
-    uint32_t buf[MERGED ? 1 : 3][4][NTT::SCRATCH_WORDS];
+    uint32_t buf[MERGED ? 1 : 2][4][NTT::SCRATCH_WORDS];
+    uint32_t half[MERGED ? 1 : 4][MERGED ? 4 : NTT::N / 2];     // separate buffers: the CRT partner's residues (half a polynomial)
     uint16_t bar[1024 + 8];                        // modulus-switched mask and body
+    uint32_t dtab[2][5 * DIGIT_TAB];               // per prime: first-step products of the gadget digits (ntt_wave.hpp)
     __device__ __forceinline__ uint32_t *scr(int wv) { return buf[0][wv]; }
     __device__ __forceinline__ uint32_t *x1(int wv) { return buf[MERGED ? 0 : 1][wv]; }
-    __device__ __forceinline__ uint32_t *x2(int wv) { return buf[MERGED ? 0 : 2][wv]; }
+    __device__ __forceinline__ uint32_t *x2(int wv) { if constexpr (MERGED) return buf[0][wv]; else return half[wv]; }
 };
 
 // prelude + modulus switch + the n-step blind rotation of one descriptor; the result is left
 // in sh.acc (complete for every thread on return)
-template <int LOGN, int V = 0>
+// TAB: the first radix-4 step of every forward transform reads digit products from an LDS table
+// (gadget digits of at most DIGIT_TAB_BITS bits: every built-in set but the legacy Bg = 2^10 one)
+template <int LOGN, int V = 0, bool TAB = false>
 __device__ __forceinline__ void blind_rotate4_body(const DevParams &p, const DevKey &key,
                                                    const int32_t *__restrict__ pool, const RotDesc &rd,
                                                    Br4Lds<LOGN, V> &sh, int tid, int parity = 0) {
@@ -461,11 +463,16 @@ __device__ __forceinline__ void blind_rotate4_body(const DevParams &p, const Dev
     const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int q = wv & 1, u = wv >> 1;
     const int lane = tid & 63;
-    const PrimeCtx c = make_ctx(q, key.tw, N);
+    PrimeCtx c = make_ctx(q, key.tw, N);
     uint32_t *scr = sh.scr(wv);
     const int n = p.n;
 
     prelude_modswitch<LOGN, 256>(p, rd, pool, sh.bar, tid);
+    if constexpr (TAB) {
+        // the two waves of prime q (tid bits 6 and 7 = q and u) fill that prime's table
+        NTT::build_digit_table(sh.dtab[q], c, p.Bgbit, (u << 6) | lane, 128);
+        c.dtab = sh.dtab[q];
+    }
     __syncthreads();
     if (q == 0) {
         const int barb = sh.bar[n];
@@ -496,8 +503,8 @@ __device__ __forceinline__ void blind_rotate4_body(const DevParams &p, const Dev
         using Acc1T = typename std::conditional<TR::WIDE_SEND, int64_t, int32_t>::type;
         Acc0T acc0[REGS];
         Acc1T acc1[REGS];
-        forward_poly<LOGN, true, TR::KEEP_D, TR::EARLY_TW, Acc0T, Acc1T>(p, key, c, sh.acc, scr, lane, q, i, u, abar, u != 0,
-                                                                        acc0, acc1);
+        forward_poly<LOGN, true, TR::KEEP_D, TR::EARLY_TW, TAB, Acc0T, Acc1T>(p, key, c, sh.acc, scr, lane, q, i, u, abar,
+                                                                             u != 0, acc0, acc1);
         STAMP(1);
 
         int32_t t[REGS];
@@ -554,7 +561,7 @@ __device__ __forceinline__ void blind_rotate4_body(const DevParams &p, const Dev
     STAMP_FLUSH;
 }
 
-template <int LOGN, int V>
+template <int LOGN, int V, bool TAB>
 __global__ __launch_bounds__(256, (BrTraits<LOGN, V>::WAVES_PER_SIMD)) void blind_rotate4_kernel(
     DevParams p, DevKey key, const int32_t *__restrict__ pool, const RotDesc *__restrict__ rots,
     int32_t *__restrict__ u_buf, int32_t *__restrict__ acc_dbg) {
@@ -587,7 +594,7 @@ __global__ __launch_bounds__(256, (BrTraits<LOGN, V>::WAVES_PER_SIMD)) void blin
                                      ((((xcc & 0xF) << 8) | ((hw >> 8) & 0xFF)) << 48);
     }
     const RotDesc rd = rots[blockIdx.x];
-    blind_rotate4_body<LOGN, V>(p, key, pool, rd, sh, threadIdx.x, parity);
+    blind_rotate4_body<LOGN, V, TAB>(p, key, pool, rd, sh, threadIdx.x, parity);
     extract_sample<LOGN, 256>(p, rd, sh.acc, u_buf, acc_dbg, threadIdx.x);
     if (p.wg_times && threadIdx.x == 0) p.wg_times[2 * blockIdx.x + 1] = __builtin_amdgcn_s_memtime();
 }
@@ -1035,7 +1042,7 @@ void launch_blind_rotate(hipStream_t s, const DevParams &p, const DevKey &key, c
     if (count <= 0) return;
     // the 2-wave form exists for N = 1024 only; N = 2048 always takes the 4-wave form
     if (p.N == 2048)
-        hipLaunchKernelGGL((blind_rotate4_kernel<11, 0>), dim3(count), dim3(256), 0, s, p, key, pool, rots, u_buf, acc_dbg);
+        hipLaunchKernelGGL((blind_rotate4_kernel<11, 0, false>), dim3(count), dim3(256), 0, s, p, key, pool, rots, u_buf, acc_dbg);
     else
         hipLaunchKernelGGL(blind_rotate_kernel<10>, dim3(count), dim3(128), 0, s, p, key, pool, rots, u_buf, acc_dbg);
 }
@@ -1050,10 +1057,11 @@ void read_stamps(unsigned long long *out, bool reset) {
 void launch_blind_rotate4(hipStream_t s, const DevParams &p, const DevKey &key, const int32_t *pool,
                           const RotDesc *rots, int count, int32_t *u_buf, int32_t *acc_dbg) {
     if (count <= 0) return;
-#define BR4(LN, VV) hipLaunchKernelGGL((blind_rotate4_kernel<LN, VV>), dim3(count), dim3(256), 0, s, p, key, pool, rots, u_buf, acc_dbg)
-    if (p.N == 2048) BR4(11, 0);
-    else if (p.br_variant == 1) BR4(10, 1);
-    else BR4(10, 0);
+#define BR4(LN, VV, TB) hipLaunchKernelGGL((blind_rotate4_kernel<LN, VV, TB>), dim3(count), dim3(256), 0, s, p, key, pool, rots, u_buf, acc_dbg)
+    const bool tab = p.Bgbit <= DIGIT_TAB_BITS && p.digit_table != 0;
+    if (p.N == 2048) { if (tab) BR4(11, 0, true); else BR4(11, 0, false); }
+    else if (p.br_variant == 1) { if (tab) BR4(10, 1, true); else BR4(10, 1, false); }
+    else { if (tab) BR4(10, 0, true); else BR4(10, 0, false); }
 #undef BR4
 }
 

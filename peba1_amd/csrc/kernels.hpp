@@ -16,6 +16,7 @@ struct DevParams {
     int32_t mu;             // test-vector amplitude, 1/8
     int32_t wave_prio;      // per launch: 1 = the blind-rotate waves raise their issue priority (urgent lane)
     int32_t fair_shift;     // k > 0: the workgroups sharing a CU take turns at the higher issue priority every 2^k shader cycles
+    int32_t digit_table;    // 1 = digit products of the first NTT step from an LDS table where Bgbit allows (kernels.hip)
     int32_t br_variant;     // N = 1024: 0 = wide form (2 workgroups per CU), 1 = lean form (3 per CU); kernels.hip BrTraits
     uint32_t *cu_arrivals;  // [4096] arrival counters per CU (never reset: only the parity of the arrival order is used)
     unsigned long long *wg_times;   // diagnostic: [2 * grid] s_memtime at workgroup start and end, or null

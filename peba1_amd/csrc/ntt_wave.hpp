@@ -56,7 +56,14 @@ struct PrimeCtx {
     const uint32_t *__restrict__ wi;   // inverse twiddles psi^-brv(i) * R mod P, [N]
     const uint4 *__restrict__ qf;      // forward quads [N/2]: entry 2^s + t = {w2, w3, w1 w2, P - w1 w3} of the
     const uint4 *__restrict__ qi;      // radix-4 step on stages (s, s+1), block t; inverse likewise
+    const uint32_t *dtab;              // LDS, or null: first-step products of gadget digits, [5][DIGIT_TAB] (forward_digits)
 };
+
+// The first radix-4 step of a forward transform of gadget digits multiplies 7-bit numbers by five
+// fixed twiddles (stages 0 and 1 have one block): with at most DIGIT_TAB_BITS bits per digit the eleven
+// multiplier-class instructions of a group become five LDS reads of d * w mod P, indexed by the
+// digit's two's-complement bit field.  Rows: w1, w2, w1 w2, w3, P - w1 w3.
+constexpr int DIGIT_TAB_BITS = 7, DIGIT_TAB = 1 << DIGIT_TAB_BITS;
 
 // signed Montgomery reduction: T*R^-1 mod P, |result| <= |T|/2^32 + P/2
 __device__ __forceinline__ int32_t mont_redc(int64_t T, uint32_t P, uint32_t pinv) {
@@ -339,6 +346,73 @@ struct WaveNtt {
         FwdTw0 t0;
         t0.load(c, lane);
         forward<EARLY>(x, c, scr, lane, t0);
+    }
+
+    // Forward NTT of the gadget digit at bit position `shift`, `width` bits wide, of every D[r] (digit
+    // fields in two's complement, i.e. after the (D + offset) ^ offset of kernels.hip).  TABLE: the
+    // first radix-4 step reads its products from c.dtab (width <= DIGIT_TAB_BITS) -- per group 5 LDS
+    // reads, 3 shift+mask index computations and 8 additions instead of 4 bit-field extractions,
+    // 11 multiplier-class instructions and 6 additions; magnitudes after the step are below
+    // 1.5P + 2^6 instead of P, after the transform below 6.8P (N=1024) / 7.4P (N=2048).
+    template <bool EARLY, bool TABLE>
+    static __device__ __forceinline__ void forward_digits(int32_t (&x)[REGS], const uint32_t (&D)[REGS], int shift, int width,
+                                                          const PrimeCtx &c, uint32_t *scr, int lane) {
+        FwdTw0 t0;
+        t0.load(c, lane);
+        if constexpr (!TABLE) {
+#pragma unroll
+            for (int r = 0; r < REGS; ++r) x[r] = __builtin_amdgcn_sbfe((int32_t)D[r], shift, width);
+            forward<EARLY>(x, c, scr, lane, t0);
+        } else {
+            static_assert(FwdTw0::PAIR && FwdTw0::CNT == 1, "the first step is a radix-4 step with one block");
+            constexpr int RBIT = rbit_of(0), h = 1 << RBIT, l = h >> 1;
+            const uint32_t mask4 = ((1u << width) - 1u) << 2;            // byte offset of a table word
+            const int sh = shift - 2;
+            const char *tab = reinterpret_cast<const char *>(c.dtab);
+            auto entry = [&](int k, uint32_t off) { return (int32_t)*reinterpret_cast<const uint32_t *>(tab + k * (DIGIT_TAB * 4) + off); };
+#pragma unroll
+            for (int r = 0; r < REGS; ++r)
+                if (!(r & (h | l))) {
+                    const int32_t x0 = __builtin_amdgcn_sbfe((int32_t)D[r], shift, width);
+                    const uint32_t i1 = (D[r | l] >> sh) & mask4, i2 = (D[r | h] >> sh) & mask4, i3 = (D[r | h | l] >> sh) & mask4;
+                    const int32_t A = entry(0, i2);
+                    const int32_t S = entry(1, i1) + entry(2, i3);
+                    const int32_t T = entry(3, i1) + entry(4, i3);
+                    const int32_t u = x0 + A, v = x0 - A;
+                    x[r] = u + S; x[r | l] = u - S; x[r | h] = v + T; x[r | h | l] = v - T;
+                }
+            if constexpr (RB > 2) fwd_pass(x, c, t0.rest);               // the other steps of the first pass
+            FwdTw1 t1;
+            if constexpr (EARLY) t1.load(c, lane);
+#pragma unroll
+            for (int r = 0; r < REGS; ++r) scr[t1_l0_addr(lane, r)] = (uint32_t)x[r];
+            wave_lds_fence();
+            read_row(x, scr, lane);
+            wave_lds_fence();
+            if constexpr (!EARLY) t1.load(c, lane);
+            fwd_pass(x, c, t1);
+            FwdTw2 t2;
+            if constexpr (EARLY) t2.load(c, lane);
+#pragma unroll
+            for (int r = 0; r < REGS; ++r) scr[t2_l1_addr(lane, r)] = (uint32_t)x[r];
+            wave_lds_fence();
+            read_row(x, scr, lane);
+            wave_lds_fence();
+            if constexpr (!EARLY) t2.load(c, lane);
+            fwd_pass(x, c, t2);
+        }
+    }
+    // fills this prime's digit table for digits of `width` bits (threads tid, tid + nthreads, ... of
+    // the workgroup); entry f of a row is for the digit whose two's-complement bit field is f
+    static __device__ __forceinline__ void build_digit_table(uint32_t *tab, const PrimeCtx &c, int width, int tid, int nthreads) {
+        const uint4 q = c.qf[1];
+        const uint32_t w[5] = {c.wf[1], q.x, q.z, q.y, q.w};                // w1, w2, w1 w2, w3, P - w1 w3
+        const int fields = 1 << width;
+        for (int e = tid; e < 5 * fields; e += nthreads) {
+            const int k = e >> width, f = e & (fields - 1);
+            const int32_t d = f < fields / 2 ? f : f - fields;
+            tab[k * DIGIT_TAB + f] = (uint32_t)mont_mul(d, w[k], c.P, c.pinv);
+        }
     }
 
     // inverse NTT (unscaled: the 1/N is folded into the key image):

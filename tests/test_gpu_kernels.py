@@ -310,3 +310,56 @@ def test_lean_kernel_form_is_bit_exact(p128_keys, oracle):
     assert (got[0][1] == got[1][1]).all(), "700-wide launch: wide and lean forms differ"
     for c in (0, 350, 699):
         assert (got[1][1][c] == oks.bootstrap_woks(many[c])).all()
+
+
+@pytest.mark.parametrize("pname", ["P128", "P80", "P2048"])
+def test_every_selectable_kernel_form_is_bit_exact(oracle, pname):
+    """Tunings never change results: for every parameter set, every combination of the blind-rotate
+    form ("br_variant"), the digit table of the first NTT step ("br_digit_table"; ignored where the
+    gadget digits are wider than 7 bits) and the 2-wave kernel gives the oracle's accumulator, on gate
+    preludes, on the sign-wrap edge inputs and on one random launch wide enough to share CUs."""
+    from peba1_amd import api
+    pp = {"P128": lambda: api.ParameterSet(128), "P80": lambda: api.ParameterSet(80),
+          "P2048": lambda: api.ParameterSet(p2048=True)}[pname]()
+    seed = 0xF0 + pp.n
+    ks = api.SecretKeySet(pp, seed, device=True)
+    oks = oracle.KeySet(oracle.params(pname), seed)
+    try:
+        r = oracle.Rng(3)
+        cts = oks.encrypt(r, [1, 1, 0, 1])
+        unit = np.int64(1) << (31 - (10 if pp.N == 1024 else 11))
+        lins = [oks.prelude("AND", cts[0], cts[1]), oks.prelude("XNOR", cts[2], cts[3])]
+        edge = np.zeros((2, pp.words), dtype=np.int32)
+        edge[0, :] = np.int32(unit)                              # every abar = 1
+        edge[1, ::2] = np.int32(-unit)                           # abar = 2N-1
+        edge[1, 5] = np.int32(-2**31)                            # abar = N
+        lins = np.concatenate([np.stack(lins), edge])
+        want = []
+        for c in range(len(lins)):
+            bar = oks.modswitch_ct(lins[c])
+            want.append(oks.blind_rotate(bar[:-1], bar[-1]))
+        rng = np.random.default_rng(17)
+        many = rng.integers(-2**31, 2**31, (600, pp.words), dtype=np.int64).astype(np.int32)
+        ref_many = None
+        forms = [(v, t, 1 << 30) for v in (0, 1) for t in (1, 0)] + ([(0, 1, 0)] if pp.N == 1024 else [])
+        try:
+            for variant, table, br4_max in forms:
+                api.set_tuning("br_variant", variant)
+                api.set_tuning("br_digit_table", table)
+                api.set_tuning("br4_max_rotations", br4_max)
+                u, acc = api.kernel_bootstrap_woks(ks, lins, want_acc=True)
+                for c in range(len(lins)):
+                    assert (acc[c] == want[c]).all(), (pname, variant, table, br4_max, c)
+                    assert (u[c] == oks.sample_extract(want[c])).all()
+                um = api.kernel_bootstrap_woks(ks, many)
+                if ref_many is None:
+                    ref_many = um
+                    for c in (0, 599):
+                        assert (um[c] == oks.bootstrap_woks(many[c])).all()
+                assert (um == ref_many).all(), (pname, variant, table, br4_max)
+        finally:
+            api.set_tuning("br_variant", 0)
+            api.set_tuning("br_digit_table", 1)
+            api.set_tuning("br4_max_rotations", 1 << 30)
+    finally:
+        ks.close()

@@ -1,7 +1,8 @@
 #!/bin/bash
 # One gpurun call's worth of checks: GPU tests, gate-throughput table, bench line.
 #   gpurun --timeout 1200 -- 'bash tools/gpu_round_check.sh <tag> [tests|fast|none] [variants...]'
-# variants: values of TFHE_HIP_BR_VARIANT to run the throughput table and the bench with (default "0")
+# variants: environment settings (NAME=value, or a bare value of TFHE_HIP_BR_VARIANT) to run the
+# throughput table and the bench with (default "0")
 set -o pipefail
 TAG=${1:-r2x}; WHAT=${2:-tests}; shift; shift
 VARIANTS=${@:-0}
@@ -18,7 +19,7 @@ fi
 echo "pytest rc $rc"; [ -f $OUT/tests.log ] && tail -6 $OUT/tests.log
 if [ $rc -eq 124 ] || [ $rc -eq 137 ]; then exit $rc; fi
 for v in $VARIANTS; do
-  export TFHE_HIP_BR_VARIANT=$v
+  case "$v" in *=*) export "$v";; *) export TFHE_HIP_BR_VARIANT=$v;; esac
   echo "=== variant $v" | tee -a $OUT/gate_throughput.txt
   timeout -k 10 200 python tools/gate_throughput.py 1 256 512 768 1024 4096 >> $OUT/gate_throughput.txt 2>&1 || exit 1
   timeout -k 10 200 python tools/gate_throughput.py --p80 1 256 4096 >> $OUT/gate_throughput.txt 2>&1 || exit 1
