@@ -136,6 +136,10 @@ def main():
     ap.add_argument("--slots", type=int, default=0, help="slots per template (default 128; 256 for --mode sharded)")
     ap.add_argument("--logical-ranks", type=int, default=0,
                     help="--mode sharded at --gpus 1: run the phases of this many logical ranks on the one device")
+    ap.add_argument("--ripple-combine", action="store_true",
+                    help="--mode sharded: rank 0 adds the partial sums with the pairwise tree of the reference's ripple "
+                         "adders and its bit-serial comparator (the DAG the golden digest pins) instead of the "
+                         "carry-save / prefix form (peba1_combine_and_compare_fast)")
     ap.add_argument("--matches", type=int, default=8, help="--mode identify: matches per GPU and step (configs[3]: 128)")
     ap.add_argument("--group", type=int, default=4, help="--mode identify: matches recorded per flush")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -241,10 +245,10 @@ def main():
                 dist.gather(mine, gathered, dst=0)                     # 24 ciphertexts per rank, one collective
                 if rank != 0:
                     return None
-                res = pd.combine(torch, prov, pp.ptr, ks.cloud, gathered, bound.ptr, "cuda")
+                res = pd.combine(torch, prov, pp.ptr, ks.cloud, gathered, bound.ptr, "cuda", fast=not args.ripple_combine)
             else:
                 res = pd.sharded_match_logical(torch, L, circuits.load(), pp.ptr, ks.cloud, pp.words, S, T, bound.ptr,
-                                               bitsize, nranks, device="cuda")
+                                               bitsize, nranks, device="cuda", fast_combine=not args.ripple_combine)
             api.flush()
             return res
 
@@ -257,7 +261,7 @@ def main():
             return "decrypted match bit of the last timed sharded match == plaintext rule (distance > bound)"
         workload = (f"slot-sharded Function_f: ONE {nslots} slots x {bitsize} bit match, slots partitioned over "
                     f"{nranks} {'ranks' if world > 1 else 'logical ranks on one device'}, one gather of 24-ciphertext "
-                    f"partial sums, adder tree + comparator on rank 0")
+                    f"partial sums, {'ripple-adder tree + bit-serial comparator' if args.ripple_combine else 'carry-save compressor + prefix adder + prefix comparator'} on rank 0")
         parallelism = f"{nslots} slots / {nranks} {'GPUs' if world > 1 else 'logical ranks (1 GPU)'}"
         scaling = "strong"
     else:   # identify

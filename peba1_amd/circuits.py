@@ -37,6 +37,7 @@ def load():
             "peba1_function_f_fast": [LS, LSP, LSP, C.c_int, LS, C.c_int, CK],
             "peba1_partial_distance": [LS, LSP, LSP, C.c_int, C.c_int, CK],
             "peba1_combine_and_compare": [LS, LSP, C.c_int, LS, CK],
+            "peba1_combine_and_compare_fast": [LS, LSP, C.c_int, LS, CK],
             "peba1_hamming_distance": [LS, LS, LS, C.c_int, CK],
             "peba1_hamming_match": [LS, LS, LS, C.c_int, LS, CK],
         }

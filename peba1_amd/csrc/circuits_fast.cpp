@@ -219,6 +219,24 @@ void peba1_euclidean_distance_fast(LweSample *result, LweSample *const *a, LweSa
     for (int i = 0; i < width; ++i) store(B, result + i, dist[i]);
 }
 
+// Rank-0 tail of the slot-sharded match with the blocks above: the partial sums of all ranks go
+// into one carry-save column compressor, then one prefix adder and the prefix comparator --
+// depth ~20 for 8 partial sums where the pairwise tree of the reference's ripple adders plus its
+// bit-serial comparator (peba1_combine_and_compare) takes ~290 levels.  Same decrypted bit.
+void peba1_combine_and_compare_fast(LweSample *result_b, LweSample *const *partials, int nparts, LweSample *bound_match,
+                                    CK *ck) {
+    const int width = 24;
+    Builder B(ck);
+    std::vector<std::vector<Net>> cols(width);
+    for (int r = 0; r < nparts; ++r)
+        for (int i = 0; i < width - 1; ++i) cols[i].push_back(B.input(partials[r] + i));   // 23-bit sums
+    compress_columns(B, cols);
+    std::vector<Net> dist = prefix_add(B, cols);
+    dist[width - 1] = Net{};                               // the reference's accumulator is 23 bits wide; bit 23 stays 0
+    store(B, result_b, greater_than(B, dist, bound_match, width));
+    for (int i = 1; i < width; ++i) bootsCONSTANT(result_b + i, 0, ck);
+}
+
 void peba1_function_f_fast(LweSample *result_b, LweSample *const *a, LweSample *const *b, int nslots,
                            LweSample *bound_match, int bitsize, CK *ck) {
     const int width = 3 * bitsize;

@@ -63,8 +63,10 @@ class _Provider:
                 f.argtypes = [V, I, V, V]
         c.peba1_partial_distance.restype = None
         c.peba1_partial_distance.argtypes = [V, V, V, C.c_int, C.c_int, V]
-        c.peba1_combine_and_compare.restype = None
-        c.peba1_combine_and_compare.argtypes = [V, V, C.c_int, V, V]
+        for name in ("peba1_combine_and_compare", "peba1_combine_and_compare_fast"):
+            f = getattr(c, name)
+            f.restype = None
+            f.argtypes = [V, V, C.c_int, V, V]
         self.g, self.c = g, c
         self.new_arr = g.new_gate_bootstrapping_ciphertext_array
         self.del_arr = g.delete_gate_bootstrapping_ciphertext_array
@@ -99,9 +101,12 @@ def local_partial(torch, prov, params_ptr, cloud_ptr, words, sample_slots, templ
     return mine
 
 
-def combine(torch, prov, params_ptr, cloud_ptr, gathered, bound_ptr, device):
-    """Phase 3 (rank 0): import the gathered partial sums, add them pairwise, compare with the
-    bound.  Returns the 24-sample result array pointer (element 0 is the match bit)."""
+def combine(torch, prov, params_ptr, cloud_ptr, gathered, bound_ptr, device, fast=False):
+    """Phase 3 (rank 0): import the gathered partial sums, add them, compare with the bound.
+    Returns the 24-sample result array pointer (element 0 is the match bit).
+    fast=False: pairwise tree of the reference's ripple adders + its comparator (the DAG the golden
+    digest pins); fast=True: carry-save compressor + prefix adder + prefix comparator, ~20 levels
+    instead of ~290 for 8 ranks -- what a latency-bound rank 0 wants."""
     if device == "cuda":
         # The library reads these buffers on its own non-blocking stream.  A c10d collective only
         # orders torch's current stream behind the RCCL stream, so the host must wait for the
@@ -119,14 +124,15 @@ def combine(torch, prov, params_ptr, cloud_ptr, gathered, bound_ptr, device):
                        "import of a gathered partial sum")
         parts.append(p)
     result_b = prov.new_arr(PARTIAL_BITS, params_ptr)
-    prov.c.peba1_combine_and_compare(result_b, _ptr_array(parts), len(parts), bound_ptr, cloud_ptr)
+    (prov.c.peba1_combine_and_compare_fast if fast else prov.c.peba1_combine_and_compare)(
+        result_b, _ptr_array(parts), len(parts), bound_ptr, cloud_ptr)
     for p in parts:
         prov.del_arr(PARTIAL_BITS, p)
     return result_b
 
 
 def sharded_match(dist, torch, gate_lib, circ_lib, params_ptr, cloud_ptr, words, sample_slots, template_slots,
-                  bound_ptr, bitsize, device="cuda"):
+                  bound_ptr, bitsize, device="cuda", fast_combine=False):
     """Slot-sharded Function_f across the ranks of `dist`.  `sample_slots` / `template_slots`: this
     rank's slot arrays (LweSample* each, `bitsize` samples).  Returns the 24-sample result array
     pointer on rank 0 (caller frees it with delete_gate_bootstrapping_ciphertext_array(24, p)),
@@ -139,11 +145,11 @@ def sharded_match(dist, torch, gate_lib, circ_lib, params_ptr, cloud_ptr, words,
     dist.gather(mine, gathered, dst=0)
     if rank != 0:
         return None
-    return combine(torch, prov, params_ptr, cloud_ptr, gathered, bound_ptr, device)
+    return combine(torch, prov, params_ptr, cloud_ptr, gathered, bound_ptr, device, fast=fast_combine)
 
 
 def sharded_match_logical(torch, gate_lib, circ_lib, params_ptr, cloud_ptr, words, sample_slots, template_slots,
-                          bound_ptr, bitsize, world, device="cuda", partial_hook=None):
+                          bound_ptr, bitsize, world, device="cuda", partial_hook=None, fast_combine=False):
     """The same slot-sharded match with `world` LOGICAL ranks on one device: every rank's phase 1
     runs in turn over its slot range of the full `sample_slots` / `template_slots` lists, the packed
     partial sums take the place of the gather's output, rank 0's phase 3 follows.  Gate for gate and
@@ -159,4 +165,4 @@ def sharded_match_logical(torch, gate_lib, circ_lib, params_ptr, cloud_ptr, word
         if partial_hook is not None:
             partial_hook(r, mine)
         gathered.append(mine)
-    return combine(torch, prov, params_ptr, cloud_ptr, gathered, bound_ptr, device)
+    return combine(torch, prov, params_ptr, cloud_ptr, gathered, bound_ptr, device, fast=fast_combine)

@@ -125,6 +125,9 @@ for world in (1, 2, 3, 8, 12):            # 12 > slots: some ranks hold no slot
         res = pd.sharded_match_logical(torch, gate, circ, params, cloud, 2, S, T, enc(bound, 24), 8, world, device="cpu",
                                        partial_hook=lambda r, t: seen.append(r))
         assert gate.bootsSymDecrypt(res, key) == (1 if d > bound else 0), (world, bound)
+        fast = pd.sharded_match_logical(torch, gate, circ, params, cloud, 2, S, T, enc(bound, 24), 8, world, device="cpu",
+                                        fast_combine=True)
+        assert gate.bootsSymDecrypt(fast, key) == (1 if d > bound else 0), ("fast combine", world, bound)
     assert seen == list(range(world)) * 2
 print("LOGICAL-OK")
 '''

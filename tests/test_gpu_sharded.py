@@ -115,6 +115,41 @@ def test_cfg3_256_slot_match_sharded_over_logical_ranks(p128_keys, world):
         assert circuits.decrypt_number(tmp, ks) == want[r], (world, r)
 
 
+def test_fast_combine_gives_the_same_match_bit(p128_keys):
+    """peba1_combine_and_compare_fast (carry-save compressor + prefix adder + prefix comparator on
+    rank 0, ~20 levels instead of ~290 for 8 ranks): same decrypted bit as the ripple-tree combine
+    and the plaintext rule, on both sides of the threshold; 8 logical ranks, one slot each."""
+    import torch
+    from peba1_amd import api, circuits, lib
+    from peba1_amd import dist as pd
+    pp, ks, _ = p128_keys
+    L = lib.load()
+    L.tfhe_hip_set_encrypt_seed(808)
+    tmpl = [12, 200, 77, 255, 1, 90, 131, 64]
+    probe = [15, 190, 78, 1, 255, 91, 140, 60]
+    d = sum((a - b) ** 2 for a, b in zip(probe, tmpl))
+    T = circuits.EncryptedVector(pp, tmpl, 8, ks)
+    S = circuits.EncryptedVector(pp, probe, 8, ks)
+    api.set_deferred(True)
+    try:
+        for bound_v in (d - 1, d, d + 1):
+            bits, levels = [], []
+            for fast in (False, True):
+                bound = circuits.encrypt_number(pp, bound_v, 24, ks)
+                api.reset_stats()
+                res = pd.sharded_match_logical(torch, L, circuits.load(), pp.ptr, ks.cloud, pp.words,
+                                               [a.ptr for a in S.slots], [a.ptr for a in T.slots], bound.ptr, 8, 8,
+                                               device="cuda", fast_combine=fast)
+                levels.append(api.flush())
+                r = C.cast(res, lib.LS)
+                bits.append(L.bootsSymDecrypt(r, ks.ptr))
+                L.delete_gate_bootstrapping_ciphertext_array(24, r)
+            assert bits == [1 if d > bound_v else 0] * 2, (bound_v, bits)
+            assert levels[1] < 40 < levels[0], levels           # depth of rank 0's tail
+    finally:
+        api.set_deferred(False)
+
+
 def test_cfg4_identification_streams_matches_through_bounded_flushes(p128_keys):
     """BASELINE configs[3] shape on one GPU: one probe against M independent 128-slot templates
     (full reference Function_f each), recorded `group` at a time so the slot pool bounds memory,

@@ -15,6 +15,7 @@ import collections
 import hashlib
 import json
 import os
+import re
 import sqlite3
 import sys
 
@@ -27,6 +28,13 @@ def kernel_source_hash():
         with open(os.path.join(ROOT, "peba1_amd", "csrc", f), "rb") as fh:
             h.update(fh.read())
     return h.hexdigest()[:16]
+
+
+def kernel_short_name(name):
+    """'void ns::(anonymous namespace)::kernel<10, 0, true>(args)' -> 'kernel<10, 0, true>'"""
+    base = name.replace("(anonymous namespace)::", "").split("(")[0].strip()
+    m = re.search(r"([A-Za-z_]\w*(?:<.*>)?)$", base.split("::")[-1])
+    return m.group(1) if m else name
 
 
 def main():
@@ -45,14 +53,17 @@ def main():
     for name, counter, value in c.execute(f"select kernel_name, counter_name, value from {view}"):
         if needle not in name:
             continue
-        short = name.split("(")[0].split("::")[-1]
+        short = kernel_short_name(name)
         a = agg[(short, counter)]
         a[0] += 1
         a[1] += value
     for (k, counter), (n, v) in sorted(agg.items()):
         print(f"{k:32s} {counter:24s} dispatches {n:5d}  sum {v:.6g}  per dispatch {v / n:.6g}")
     if out_json:
-        br = {ctr: v for (k, ctr), (n, v) in agg.items() if k.startswith("blind_rotate4_kernel")}
+        br = collections.defaultdict(float)
+        for (k, ctr), (n, v) in agg.items():
+            if k.startswith("blind_rotate4_kernel"):
+                br[ctr] += v
         need = ("SQ_INSTS_VALU", "SQ_ACTIVE_INST_VALU", "SQ_WAVES", "GRBM_GUI_ACTIVE")
         if all(k in br for k in need):
             simd_cycles = br["GRBM_GUI_ACTIVE"] / 8.0 * 256 * 4
