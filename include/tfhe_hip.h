@@ -77,10 +77,15 @@ int tfhe_hip_import_samples_device(LweSample *samples, int32_t count,
 int tfhe_hip_sync_samples(const LweSample *samples, int32_t count);
 
 /* ---- execution mode ----
- * immediate (default): every boots* call is complete on return, as upstream.
- * deferred: boots* calls are recorded (SSA-renamed, so overwritten and freed
- * temporaries are safe), levelised by data dependence, and executed level by
- * level as batched kernels at tfhe_hip_flush() or at the next decrypt/export. */
+ * deferred (default): boots* calls are recorded (SSA-renamed, so overwritten and freed
+ * temporaries are safe), levelised by data dependence, and executed level by level as batched
+ * kernels at the next bootsSymDecrypt / export / tfhe_hip_flush() (and on their own before the
+ * slot pool runs dry).  Everything observable through the API is identical to per-call
+ * execution; only the public struct fields sample->a / sample->b are stale until the sample
+ * is decrypted, exported or passed to tfhe_hip_sync_samples().
+ * immediate (TFHE_HIP_DEFERRED=0 in the environment, or tfhe_hip_set_deferred(0)): every
+ * boots* call is complete on return with the host mirror refreshed, as upstream -- one gate
+ * per kernel launch, 3.9 ms per gate. */
 void tfhe_hip_set_deferred(int on);
 int tfhe_hip_get_deferred(void);
 int tfhe_hip_flush(void);   /* returns the number of levels executed, <0 on error */

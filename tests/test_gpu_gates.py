@@ -38,6 +38,7 @@ def test_single_call_api_immediate_mode(p128_keys, oracle):
     from peba1_amd import api, lib
     pp, ks, oks = p128_keys
     L = lib.load()
+    api.set_deferred(False)                     # strict per-call completion (TFHE_HIP_DEFERRED=0)
     assert L.tfhe_hip_get_deferred() == 0
     L.tfhe_hip_set_encrypt_seed(5)
     x = api.CiphertextArray(pp, 3).encrypt([1, 0, 1], ks)
@@ -58,6 +59,42 @@ def test_single_call_api_immediate_mode(p128_keys, oracle):
     # result aliasing an input (reference: Math.cpp:272)
     L.bootsAND(x.at(0), x.at(0), x.at(2), ks.cloud)
     assert (x.words()[0] == oks.gate("AND", wx[0], wx[2])).all()
+
+
+def test_default_mode_records_and_decrypt_observes(oracle):
+    """A fresh process with no environment switch records gates (tfhe_hip_get_deferred() == 1): an
+    unmodified caller gets batched execution, and everything it can observe through the API --
+    decrypted bits, exported words -- is what per-call execution gives."""
+    import subprocess
+    import sys
+    code = ("import sys; sys.path.insert(0, %r)\n"
+            "import numpy as np\n"
+            "from peba1_amd import api, lib\n"
+            "L = lib.load(); assert L.tfhe_hip_get_deferred() == 1\n"
+            "pp = api.ParameterSet(128); ks = api.SecretKeySet(pp, 0x5EBA2, device=True)\n"
+            "L.tfhe_hip_set_encrypt_seed(77)\n"
+            "x = api.CiphertextArray(pp, 3).encrypt([1, 0, 1], ks); r = api.CiphertextArray(pp, 3)\n"
+            "L.bootsXOR(r.at(0), x.at(0), x.at(1), ks.cloud)\n"
+            "L.bootsAND(r.at(1), r.at(0), x.at(2), ks.cloud)\n"
+            "L.bootsMUX(r.at(2), r.at(1), x.at(1), x.at(0), ks.cloud)\n"
+            "st = api.stats(); assert st['blind_rotates'] == 0, st          # nothing has run yet\n"
+            "bits = [int(b) for b in r.decrypt(ks)]\n"
+            "st = api.stats(); assert st['blind_rotates'] == 4 and st['flushes'] == 1, st\n"
+            "np.save(sys.argv[1], r.words()); print('BITS', bits)\n" % os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    import tempfile
+    with tempfile.TemporaryDirectory() as t:
+        outs = {}
+        for mode in ("default", "0"):
+            env = {k: v for k, v in os.environ.items() if k != "TFHE_HIP_DEFERRED"}
+            body = code
+            if mode == "0":
+                env["TFHE_HIP_DEFERRED"] = "0"
+                body = code.replace("== 1\n", "== 0\n", 1).replace("assert st['blind_rotates'] == 0, st", "pass").replace(
+                    "and st['flushes'] == 1", "")
+            p = subprocess.run([sys.executable, "-c", body, t + "/w_%s.npy" % mode], env=env, capture_output=True, text=True, timeout=300)
+            assert p.returncode == 0 and "BITS [1, 1, 0]" in p.stdout, p.stdout + p.stderr[-2000:]
+            outs[mode] = np.load(t + "/w_%s.npy" % mode)
+        assert (outs["default"] == outs["0"]).all()            # same ciphertexts either way
 
 
 def test_mux_truth_table_deferred(p128_keys, oracle):

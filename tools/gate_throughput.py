@@ -6,6 +6,7 @@ from peba1_amd import api, lib
 
 def main():
     L = lib.load()
+    api.set_deferred(False)      # these timings bracket gate_batch itself: run it to completion
     args = sys.argv[1:]
     p2048, p80 = "--p2048" in args, "--p80" in args
     args = [a for a in args if a not in ("--p2048", "--p80")]

@@ -4,6 +4,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
 from peba1_amd import api, lib
 L = lib.load()
+api.set_deferred(False)      # these timings bracket gate_batch itself: run it to completion
 pp = api.ParameterSet(128)
 ks = api.SecretKeySet(pp, 0x5EBA2)
 rng = np.random.default_rng(0)
