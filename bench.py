@@ -237,6 +237,7 @@ def main():
         S = [a.ptr for a in probe.slots]
         T = [a.ptr for a in tmpl.slots]
         prov = pd._Provider(L, circuits.load())
+        phase_ms = {"ranks": [], "combine": []}
 
         def step():
             if world > 1:
@@ -247,8 +248,19 @@ def main():
                     return None
                 res = pd.combine(torch, prov, pp.ptr, ks.cloud, gathered, bound.ptr, "cuda", fast=not args.ripple_combine)
             else:
-                res = pd.sharded_match_logical(torch, L, circuits.load(), pp.ptr, ks.cloud, pp.words, S, T, bound.ptr,
-                                               bitsize, nranks, device="cuda", fast_combine=not args.ripple_combine)
+                # logical ranks on the one device: the phases of dist.sharded_match_logical, timed one by one
+                gathered, rank_ms = [], []
+                for r in range(nranks):
+                    rlo, rhi = pd.shard_slots(nslots, nranks, r)
+                    tr = time.perf_counter()
+                    gathered.append(pd.local_partial(torch, prov, pp.ptr, ks.cloud, pp.words, S[rlo:rhi], T[rlo:rhi], bitsize, "cuda"))
+                    rank_ms.append((time.perf_counter() - tr) * 1e3)
+                tr = time.perf_counter()
+                res = pd.combine(torch, prov, pp.ptr, ks.cloud, gathered, bound.ptr, "cuda", fast=not args.ripple_combine)
+                api.flush()
+                phase_ms["ranks"].append(rank_ms)
+                phase_ms["combine"].append((time.perf_counter() - tr) * 1e3)
+                return res
             api.flush()
             return res
 
@@ -347,6 +359,17 @@ def main():
                          "ms_blind_rotate_per_step": st["ms_blind_rotate"] / steps,
                          "ms_keyswitch_per_step": st["ms_keyswitch"] / steps},
         }
+        if mode == "sharded" and world == 1 and phase_ms["combine"]:
+            # what the same phases would take with one GPU per rank: the slowest rank's partial sum, then
+            # rank 0's combine (the gather of 24 x 2.5 KB per rank is microseconds) -- a projection from
+            # timings of logical ranks on ONE device, not a multi-GPU measurement
+            k = min(args.steps, len(phase_ms["combine"]))
+            ranks = phase_ms["ranks"][-k:]
+            out["logical_rank_phases"] = {
+                "partial_ms_per_rank": [sum(r[i] for r in ranks) / k for i in range(len(ranks[0]))],
+                "combine_ms": sum(phase_ms["combine"][-k:]) / k,
+                "projected_match_ms_one_gpu_per_rank": sum(max(r) for r in ranks) / k + sum(phase_ms["combine"][-k:]) / k,
+                "note": "projection from logical ranks timed on one device; not measured on several GPUs"}
         if world == 1 and mode == "match" and args.extras > 0:
             out.update(extras(api, circuits, identify, lib, pd, pp, ks, probe, tmpl, bound, base, probe_vals, bitsize,
                               plain_bit, last))
