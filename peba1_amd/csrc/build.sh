@@ -8,7 +8,7 @@ HIPCC=${HIPCC:-$ROCM/bin/hipcc}
 CXX=${HOSTCXX:-$ROCM/lib/llvm/bin/clang++}
 FLAGS="-O3 -std=c++17 -fPIC -ffp-contract=off -Wall -Wno-unused-result"
 HOSTFLAGS="$FLAGS -D__HIP_PLATFORM_AMD__ -I$ROCM/include"
-$HIPCC $FLAGS --offload-arch=gfx950 -c kernels.hip -o kernels.o &
+$HIPCC $FLAGS ${HIP_EXTRA_FLAGS:-} --offload-arch=gfx950 -c kernels.hip -o kernels.o &
 $CXX $HOSTFLAGS -c host_keys.cpp -o host_keys.o &
 $CXX $HOSTFLAGS -c engine.cpp -o engine.o &
 $CXX $HOSTFLAGS -c shim.cpp -o shim.o &

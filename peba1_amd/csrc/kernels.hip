@@ -254,11 +254,14 @@ __device__ __forceinline__ void forward_poly(const DevParams &p, const DevKey &k
         const uint4 *bp = reinterpret_cast<const uint4 *>(
                               key.bk_img + ((size_t)((size_t)i * p.kpl + prow) * 2 + q) * 2 * N) + lane;
         // key rows: both output polynomials are requested before the transform so that their latency
-        // hides under it -- except where registers are short (!KEEP_D: N = 2048), where the second
-        // polynomial's row is requested after the transform and multiplied last
+        // hides under it -- except where registers are short (the lean forms), where the second
+        // polynomial's row, and at N = 2048 both, are requested after the transform
         uint4 b0[G4], b1[G4];
+        constexpr bool LATE_B0 = !KEEP_D && LOGN == 11;     // N = 2048: both rows after the transform (7 instead of 27 spilled words)
+        if constexpr (!LATE_B0) {
 #pragma unroll
-        for (int g = 0; g < G4; ++g) b0[g] = bp[o0 + g * 64];
+            for (int g = 0; g < G4; ++g) b0[g] = bp[o0 + g * 64];
+        }
         if constexpr (KEEP_D) {
 #pragma unroll
             for (int g = 0; g < G4; ++g) b1[g] = bp[o1 + g * 64];
@@ -271,6 +274,10 @@ __device__ __forceinline__ void forward_poly(const DevParams &p, const DevKey &k
             uint32_t D[REGS];
             lds_acc.template rotated_difference<REGS>(D, u, lane, abar, p.decomp_offset);
             NTT::template forward_digits<EARLY_TW, TABLE>(x, D, shift, width, c, scr, lane);
+        }
+        if constexpr (LATE_B0) {
+#pragma unroll
+            for (int g = 0; g < G4; ++g) b0[g] = bp[o0 + g * 64];
         }
         if constexpr (!KEEP_D) {
 #pragma unroll
