@@ -50,12 +50,22 @@ struct alignas(16) ArrayHeader {
     SlotPool *pool;     // set when the first element moves to the device
 };
 
-// Every sample's host mirror is preceded by a back-pointer to its array's header, so the
-// pool a sample lives in can be found from any element pointer (&array[i]).
-constexpr int MIRROR_PREFIX_WORDS = 2;   // one pointer
+// Every sample's host mirror is preceded by a back-pointer to its array's header and a marker, so
+// the pool a sample lives in can be found from any element pointer (&array[i]).  The marker is
+// checked BEFORE the back-pointer is followed.  Why it matters: the reference's Function_g writes
+// bitsize+1 results into a bitsize-sample array (Math.cpp:399-401).  That "sample" one
+// past the end overlays the first mirror prefix of the block, so its `a` field reads as the
+// back-pointer (the block's own start): the words in front of THAT are the allocator's chunk header
+// -- readable, and not the marker -- and the call is refused instead of following garbage.
+constexpr int MIRROR_PREFIX_WORDS = 4;   // one pointer + marker (8 bytes)
+constexpr uint64_t MIRROR_MARKER = 0x7F4E5A3D1E5AA11Cull;
 
 ArrayHeader *header_of(const LweSample *sample) {
+    uint64_t marker;
     ArrayHeader *h;
+    if (!sample || !sample->a) api_fail("LweSample was not allocated by new_gate_bootstrapping_ciphertext_array");
+    std::memcpy(&marker, sample->a - 2, sizeof marker);
+    if (marker != MIRROR_MARKER) api_fail("LweSample was not allocated by new_gate_bootstrapping_ciphertext_array");
     std::memcpy(&h, sample->a - MIRROR_PREFIX_WORDS, sizeof h);
     if (!h || h->magic != ARRAY_MAGIC) api_fail("LweSample was not allocated by new_gate_bootstrapping_ciphertext_array");
     return h;
@@ -505,6 +515,7 @@ LweSample *new_gate_bootstrapping_ciphertext_array(int32_t nbelems, const TFheGa
     for (int32_t i = 0; i < nbelems; ++i) {
         samples[i].a = words + (size_t)i * mirror + MIRROR_PREFIX_WORDS;
         std::memcpy(samples[i].a - MIRROR_PREFIX_WORDS, &h, sizeof h);
+        std::memcpy(samples[i].a - 2, &MIRROR_MARKER, sizeof MIRROR_MARKER);
         samples[i].b = -(1 << 29);      // fresh = trivial encryption of 0, like bootsCONSTANT(.., 0)
         samples[i].slot = SLOT_ZERO;
         samples[i].current_variance = 0.0;

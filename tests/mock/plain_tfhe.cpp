@@ -67,7 +67,10 @@ TFheGateBootstrappingSecretKeySet *new_random_gate_bootstrapping_secret_keyset(c
 void delete_gate_bootstrapping_secret_keyset(TFheGateBootstrappingSecretKeySet *k) { std::free(k); }
 
 LweSample *new_gate_bootstrapping_ciphertext_array(int32_t n, const TFheGateBootstrappingParameterSet *) {
-    auto *p = static_cast<LweSample *>(std::calloc((size_t)(n > 0 ? n : 1), sizeof(LweSample)));
+    // two samples of slack: the reference's Function_g writes bitsize+1 samples into a bitsize-sample
+    // array (Math.cpp:399-401); the slack keeps that inside the block, as upstream's separate
+    // heap blocks usually do by luck, so that the reference's own main() can run to its end over this mock
+    auto *p = static_cast<LweSample *>(std::calloc((size_t)(n > 0 ? n : 1) + 2, sizeof(LweSample)));
     for (int i = 0; i < n; ++i) p[i].slot = -2;   // never written
     g_arrays[reinterpret_cast<uintptr_t>(p)] = ArrInfo{g_serial++, n};
     ++g_counts[C_ALLOC];

@@ -86,3 +86,21 @@ def test_reference_main_and_client_compile_against_our_headers(built):
     for src in ("main.cpp", "Client.cpp"):
         subprocess.check_call(["g++", "-std=gnu++11", "-w", "-c", "-I" + inc, REF + "/src/" + src,
                                "-o", built + "/" + src + ".o"])
+
+
+@pytest.mark.skipif(not os.path.isdir(REF), reason="reference sources not present on this machine")
+def test_reference_program_golden_output_is_current(tmp_path):
+    """tests/golden/reference_main_output.txt is what the reference's own program prints over the
+    plaintext-bit provider with time() fixed (tests/refcompat/make_golden_main.sh): regenerate and
+    compare, so the file the GPU test checks against cannot go stale.  The run itself shows the
+    reference's defects at work: a zero template byte makes its own
+    Euclidean self-check print 65152 instead of 128, Manhattan prints 126, and the protocol still
+    'authenticates'."""
+    out = str(tmp_path / "main_output.txt")
+    subprocess.check_call(["bash", os.path.join(ROOT, "tests/refcompat/make_golden_main.sh"), out])
+    with open(out) as f, open(os.path.join(ROOT, "tests", "golden", "reference_main_output.txt")) as g:
+        got, want = f.read(), g.read()
+    assert got == want
+    for line in ("Addition: 128 success, 0 fails", "Multiplication: 128 success, 0 fails",
+                 "The result for Euclidean distance is 65152 and should be 128", "Client 7 successfully authenticated to the server!"):
+        assert line in want

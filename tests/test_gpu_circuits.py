@@ -273,3 +273,27 @@ def test_reference_object_code_on_the_gpu_library():
         # executed rotations: at most what the circuit records (identical pending gates are shared)
         assert got[name]["blind_rotates"] <= w["blind_rotates"], name
         assert (got[name]["blind_rotates"] > 0) == (w["blind_rotates"] > 0), name     # the shift helpers bootstrap nothing
+
+
+def test_reference_program_runs_unmodified_on_the_gpu_library():
+    """The whole reference program -- src/main.cpp, Math.cpp, Client.cpp, unmodified, compiled where
+    they lie and linked against libtfhe-hip.so (oracle/Makefile `ref` -> oracle/_ref/tfhe_protocol_hip)
+    -- runs on the GPU with no switch of any kind: its 5 x 128 per-operation checks, both
+    128-slot distances and protocol P_1 (about 0.7 M bootstrapped gates) print, line for line, what
+    the same sources print over the plaintext-bit provider on the CPU
+    (tests/golden/reference_main_output.txt; duration lines dropped; time() fixed for both,
+    tests/refcompat/fixed_time.c).  Includes the reference's own overflow (Function_g writes one
+    sample past an array), which the library refuses instead of following."""
+    import re
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = os.path.join(root, "oracle", "_ref", "tfhe_protocol_hip")
+    if not os.path.exists(exe):
+        pytest.skip("oracle/_ref/tfhe_protocol_hip not built (needs /root/reference at build time)")
+    env = {k: v for k, v in os.environ.items() if k != "TFHE_HIP_DEFERRED"}
+    out = subprocess.run([exe], env=env, capture_output=True, text=True, timeout=420)
+    assert out.returncode == 0, out.stdout[-1500:] + out.stderr[-2000:]
+    keep = [l for l in out.stdout.splitlines() if not re.search(r"seconds|Function [fg]( bitwise)?: ", l)]
+    with open(os.path.join(root, "tests", "golden", "reference_main_output.txt")) as f:
+        want = f.read().splitlines()
+    assert keep == want, next(((i, a, b) for i, (a, b) in enumerate(zip(keep, want)) if a != b), (len(keep), len(want)))
