@@ -100,6 +100,7 @@ void Engine::ensure_init() {
     }
     if (const char *env = std::getenv("TFHE_HIP_LANE_PRIO")) lane_prio = std::atoi(env);
     if (const char *env = std::getenv("TFHE_HIP_BR_FAIR")) br_fair = std::atoi(env);
+    if (const char *env = std::getenv("TFHE_HIP_BR8_MAX")) br8_max_rotations = std::atoi(env);
     if (const char *env = std::getenv("TFHE_HIP_BR_VARIANT")) br_variant = std::atoi(env);
     if (const char *env = std::getenv("TFHE_HIP_BR_TABLE")) br_digit_table = std::atoi(env) != 0;
     for (auto &e : ev_) hip_check(hipEventCreate(&e), "hipEventCreate");
@@ -323,7 +324,11 @@ void Engine::launch_br(const DeviceKeyImage *key, const int32_t *pool, const Rot
             dp.cu_arrivals = cu_arrivals_;
         }
         dp.wg_times = wg_times_dbg_;
-        launch_blind_rotate4(stream, dp, key->key, pool, rots, count, u_buf, acc_dbg);
+        // launches that leave CUs with at most one workgroup: the 8-wave form (a second wave per SIMD)
+        if (br8_max_rotations > 0 && count <= std::min(br8_max_rotations, cu_count_) && dp.N == 1024 && dp.l >= 2 && !wg_times_dbg_)
+            launch_blind_rotate8(stream, dp, key->key, pool, rots, count, u_buf, acc_dbg);
+        else
+            launch_blind_rotate4(stream, dp, key->key, pool, rots, count, u_buf, acc_dbg);
         return;
     }
     // (splitting a short last round off to the latency kernel was measured: the kernel

@@ -130,6 +130,9 @@ public:
     // N = 1024: which form of the 4-wave blind-rotate kernel runs (kernels.hip BrTraits): 0 = wide
     // (keeps D and 64-bit partial sums in registers, two workgroups per CU), 1 = lean (three per CU)
     int br_variant = 0;
+    // launches of at most min(this, CU count) rotations (at most one workgroup per CU) use the 8-wave form
+    // of the kernel, N = 1024 only; 0 = never (env TFHE_HIP_BR8_MAX, tuning "br8_max_rotations")
+    int br8_max_rotations = 1 << 30;
     // 1 = the first radix-4 step of the forward transforms looks digit products up in LDS (gadget digits
     // of at most 7 bits); 0 = multiplies (env TFHE_HIP_BR_TABLE, tuning "br_digit_table")
     int br_digit_table = 1;

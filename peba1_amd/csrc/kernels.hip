@@ -240,7 +240,8 @@ template <int LOGN, bool FRESH, bool KEEP_D, bool EARLY_TW, bool TABLE, typename
 __device__ __forceinline__ void forward_poly(const DevParams &p, const DevKey &key, const PrimeCtx &c,
                                              const AccLds<LOGN> &lds_acc, uint32_t *scr,
                                              int lane, int q, int i, int u, int abar, bool swap_outputs,
-                                             Acc0T (&acc0)[WaveNtt<LOGN>::REGS], Acc1T (&acc1)[WaveNtt<LOGN>::REGS]) {
+                                             Acc0T (&acc0)[WaveNtt<LOGN>::REGS], Acc1T (&acc1)[WaveNtt<LOGN>::REGS],
+                                             int jbegin = 0, int jend = -1) {
     using NTT = WaveNtt<LOGN>;
     constexpr int N = NTT::N, REGS = NTT::REGS, G4 = REGS / 4;
     // a sum is kept in 64 bits and reduced once, or Montgomery-reduced per row (|.| < 0.72P each)
@@ -314,9 +315,11 @@ __device__ __forceinline__ void forward_poly(const DevParams &p, const DevKey &k
             }
         }
     };
-    row(0, std::integral_constant<bool, FRESH>{});
+    // gadget rows [jbegin, jend) of this input polynomial (default: all l of them)
+    if (jend < 0) jend = p.l;
+    row(jbegin, std::integral_constant<bool, FRESH>{});
 #pragma unroll 1
-    for (int jj = 1; jj < p.l; ++jj) row(jj, std::false_type{});
+    for (int jj = jbegin + 1; jj < jend; ++jj) row(jj, std::false_type{});
 }
 
 // sample extract at index 0 (tfhe tLweExtractLweSampleIndex) + optional raw accumulator dump
@@ -604,6 +607,134 @@ __global__ __launch_bounds__(256, (BrTraits<LOGN, V>::WAVES_PER_SIMD)) void blin
     blind_rotate4_body<LOGN, V, TAB>(p, key, pool, rd, sh, threadIdx.x, parity);
     extract_sample<LOGN, 256>(p, rd, sh.acc, u_buf, acc_dbg, threadIdx.x);
     if (p.wg_times && threadIdx.x == 0) p.wg_times[2 * blockIdx.x + 1] = __builtin_amdgcn_s_memtime();
+}
+
+// ---------------------------------------------------------------------------
+// K1+K2: blind rotate, 8-wave form for launches that cannot fill the chip (at most one
+// workgroup per CU).  With four waves a CU runs one wave per SIMD, and a lone wave issues its
+// multiplier-class instructions at half the rate two waves share (v_mad_i64_i32: 10 cycles
+// against 5; profiles/r01_valu_rates.txt).  Here a second wave sits on each SIMD: for prime q and
+// input polynomial u, wave A = (q,u,0) transforms and multiplies the gadget rows 0..l-2, wave
+// B = (q,u,1) the last row, then B adds the four partial sums of its output polynomial (its own,
+// A's, and the two the waves of the other input polynomial send), runs the inverse transform,
+// shares the CRT with B of the other prime and updates the accumulator.  A is idle during the
+// inverse: the gain is the forward phase at shared issue rates (~25 % per step), which is what a
+// narrow level, a single gate (immediate mode) or a short circuit between two decryptions
+// (the reference's own test program) are made of.  Same integers as the other forms.  N = 1024,
+// l >= 2; three workgroup barriers per step.
+// ---------------------------------------------------------------------------
+template <int LOGN>
+struct Br8Lds {
+    using NTT = WaveNtt<LOGN>;
+    AccLds<LOGN> acc;
+    uint32_t scr[8][NTT::SCRATCH_WORDS];           // wave-private NTT transposes
+    uint32_t pa0[4][NTT::SCRATCH_WORDS];           // A's sum for its own output polynomial (read by its B)
+    uint32_t pa1[4][NTT::SCRATCH_WORDS];           // A's sum for the other output polynomial (read by the other B)
+    uint32_t pb[4][NTT::SCRATCH_WORDS];            // B's sum for the other output polynomial
+    uint32_t half[4][NTT::N / 2];                  // residues of the half the CRT partner recombines
+    uint16_t bar[1024 + 8];
+    uint32_t dtab[2][5 * DIGIT_TAB];
+};
+
+template <int LOGN, bool TAB>
+__global__ __launch_bounds__(512, 2) void blind_rotate8_kernel(
+    DevParams p, DevKey key, const int32_t *__restrict__ pool, const RotDesc *__restrict__ rots,
+    int32_t *__restrict__ u_buf, int32_t *__restrict__ acc_dbg) {
+    using NTT = WaveNtt<LOGN>;
+    constexpr int N = NTT::N, REGS = NTT::REGS, HALF = REGS / 2;
+    __shared__ __align__(16) Br8Lds<LOGN> sh;
+    const int tid = threadIdx.x;
+    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int base = wv & 3, q = base & 1, u = base >> 1;
+    const bool role_b = wv >= 4;
+    const int lane = tid & 63;
+    PrimeCtx c = make_ctx(q, key.tw, N);
+    uint32_t *scr = sh.scr[wv];
+    const int n = p.n;
+    const RotDesc rd = rots[blockIdx.x];
+
+    prelude_modswitch<LOGN, 512>(p, rd, pool, sh.bar, tid);
+    if constexpr (TAB) {
+        // the four waves of prime q fill that prime's table
+        NTT::build_digit_table(sh.dtab[q], c, p.Bgbit, ((wv >> 1) << 6) | lane, 256);
+        c.dtab = sh.dtab[q];
+    }
+    __syncthreads();
+    if (q == 0 && !role_b) {
+        const int barb = sh.bar[n];
+#pragma unroll
+        for (int r = 0; r < REGS; ++r) {
+            const int j = r * 64 + lane;
+            sh.acc.set(u, j, u == 0 ? 0u : testvector_coef<LOGN>(j, barb, p.mu));
+        }
+    }
+    __syncthreads();
+
+    const int last = p.l - 1;
+    for (int i = 0; i < n; ++i) {
+        const int abar = __builtin_amdgcn_readfirstlane((int)sh.bar[i]);
+        if (abar == 0) continue;
+        int64_t acc0[REGS], acc1[REGS];                 // output poly u (kept in the pair), output poly 1-u (sent)
+        int32_t t[REGS];
+        if (!role_b) {
+            forward_poly<LOGN, true, true, true, TAB, int64_t, int64_t>(p, key, c, sh.acc, scr, lane, q, i, u, abar, u != 0,
+                                                                      acc0, acc1, 0, last);
+            int32_t s1[REGS];
+#pragma unroll
+            for (int r = 0; r < REGS; ++r) {
+                t[r] = mont_redc(acc0[r], c.P, c.pinv);                 // l-1 rows: |.| < 0.93P
+                s1[r] = mont_redc(acc1[r], c.P, c.pinv);
+            }
+            NTT::write_row(t, sh.pa0[base], lane);
+            NTT::write_row(s1, sh.pa1[base], lane);
+        } else {
+            forward_poly<LOGN, true, true, true, TAB, int64_t, int64_t>(p, key, c, sh.acc, scr, lane, q, i, u, abar, u != 0,
+                                                                      acc0, acc1, last, last + 1);
+            int32_t s1[REGS];
+#pragma unroll
+            for (int r = 0; r < REGS; ++r) {
+                t[r] = mont_redc(acc0[r], c.P, c.pinv);                 // one row: |.| < 0.72P
+                s1[r] = mont_redc(acc1[r], c.P, c.pinv);
+            }
+            NTT::write_row(s1, sh.pb[base], lane);
+        }
+        __syncthreads();
+        uint32_t y[REGS];
+        if (role_b) {
+            int32_t o[REGS];
+            NTT::read_row(o, sh.pa0[base], lane);
+#pragma unroll
+            for (int r = 0; r < REGS; ++r) t[r] += o[r];
+            NTT::read_row(o, sh.pa1[base ^ 2], lane);
+#pragma unroll
+            for (int r = 0; r < REGS; ++r) t[r] += o[r];
+            NTT::read_row(o, sh.pb[base ^ 2], lane);
+#pragma unroll
+            for (int r = 0; r < REGS; ++r) t[r] += o[r];                // |.| < 3.3P (the inverse takes < 4P)
+            NTT::template inverse<true>(t, c, scr, lane);
+#pragma unroll
+            for (int r = 0; r < REGS; ++r) y[r] = canon(t[r], c.P);
+            uint32_t *mx = sh.half[base];
+#pragma unroll
+            for (int r = 0; r < HALF; ++r) mx[r * 64 + lane] = q == 0 ? y[HALF + r] : y[r];
+        }
+        __syncthreads();
+        if (role_b) {
+            const uint32_t *ox = sh.half[base ^ 1];
+            if (q == 0) {
+#pragma unroll
+                for (int r = 0; r < HALF; ++r)
+                    sh.acc.set(u, r * 64 + lane, sh.acc.get(u, r * 64 + lane) + crt_to_torus(y[r], ox[r * 64 + lane]));
+            } else {
+#pragma unroll
+                for (int r = 0; r < HALF; ++r)
+                    sh.acc.set(u, (HALF + r) * 64 + lane,
+                               sh.acc.get(u, (HALF + r) * 64 + lane) + crt_to_torus(ox[r * 64 + lane], y[HALF + r]));
+            }
+        }
+        __syncthreads();
+    }
+    extract_sample<LOGN, 512>(p, rd, sh.acc, u_buf, acc_dbg, tid);
 }
 
 // ---------------------------------------------------------------------------
@@ -1052,6 +1183,15 @@ void launch_blind_rotate(hipStream_t s, const DevParams &p, const DevKey &key, c
         hipLaunchKernelGGL((blind_rotate4_kernel<11, 0, false>), dim3(count), dim3(256), 0, s, p, key, pool, rots, u_buf, acc_dbg);
     else
         hipLaunchKernelGGL(blind_rotate_kernel<10>, dim3(count), dim3(128), 0, s, p, key, pool, rots, u_buf, acc_dbg);
+}
+
+void launch_blind_rotate8(hipStream_t s, const DevParams &p, const DevKey &key, const int32_t *pool,
+                          const RotDesc *rots, int count, int32_t *u_buf, int32_t *acc_dbg) {
+    if (count <= 0) return;
+    if (p.Bgbit <= DIGIT_TAB_BITS && p.digit_table != 0)
+        hipLaunchKernelGGL((blind_rotate8_kernel<10, true>), dim3(count), dim3(512), 0, s, p, key, pool, rots, u_buf, acc_dbg);
+    else
+        hipLaunchKernelGGL((blind_rotate8_kernel<10, false>), dim3(count), dim3(512), 0, s, p, key, pool, rots, u_buf, acc_dbg);
 }
 
 #ifdef TFHE_HIP_STAMPS

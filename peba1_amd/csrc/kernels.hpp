@@ -69,6 +69,9 @@ void launch_blind_rotate(hipStream_t s, const DevParams &p, const DevKey &key, c
 // latency form (4 waves per rotation), for launches that cannot fill the chip
 void launch_blind_rotate4(hipStream_t s, const DevParams &p, const DevKey &key, const int32_t *pool,
                           const RotDesc *rots, int count, int32_t *u_buf, int32_t *acc_dbg);
+// 8-wave form (N = 1024, l >= 2) for launches of at most one workgroup per CU: a second wave per SIMD
+void launch_blind_rotate8(hipStream_t s, const DevParams &p, const DevKey &key, const int32_t *pool,
+                          const RotDesc *rots, int count, int32_t *u_buf, int32_t *acc_dbg);
 // splits > 1: each gate's key switch is cut into `splits` ranges of input coefficients
 // (partial sums in `partial[count][splits][ct_stride]`, then a reduce launch).  tile = 16 or
 // 32: launches of at least 2*tile gates use the tiled kernel (one pass over the KSK rows of

@@ -316,8 +316,9 @@ def test_lean_kernel_form_is_bit_exact(p128_keys, oracle):
 def test_every_selectable_kernel_form_is_bit_exact(oracle, pname):
     """Tunings never change results: for every parameter set, every combination of the blind-rotate
     form ("br_variant"), the digit table of the first NTT step ("br_digit_table"; ignored where the
-    gadget digits are wider than 7 bits) and the 2-wave kernel gives the oracle's accumulator, on gate
-    preludes, on the sign-wrap edge inputs and on one random launch wide enough to share CUs."""
+    gadget digits are wider than 7 bits), the 8-wave form for narrow launches ("br8_max_rotations";
+    N = 1024 only) and the 2-wave kernel gives the oracle's accumulator, on gate preludes, on the
+    sign-wrap edge inputs, on a 200-wide launch and on one random launch wide enough to share CUs."""
     from peba1_amd import api
     pp = {"P128": lambda: api.ParameterSet(128), "P80": lambda: api.ParameterSet(80),
           "P2048": lambda: api.ParameterSet(p2048=True)}[pname]()
@@ -341,25 +342,31 @@ def test_every_selectable_kernel_form_is_bit_exact(oracle, pname):
         rng = np.random.default_rng(17)
         many = rng.integers(-2**31, 2**31, (600, pp.words), dtype=np.int64).astype(np.int32)
         ref_many = None
-        forms = [(v, t, 1 << 30) for v in (0, 1) for t in (1, 0)] + ([(0, 1, 0)] if pp.N == 1024 else [])
+        # (form, digit table, 4-wave limit, 8-wave limit): the small batch runs the 8-wave form where enabled
+        forms = [(v, t, 1 << 30, b8) for v in (0, 1) for t in (1, 0) for b8 in (1 << 30, 0)]
+        forms += [(0, 1, 0, 0)] if pp.N == 1024 else []
         try:
-            for variant, table, br4_max in forms:
+            for variant, table, br4_max, br8_max in forms:
                 api.set_tuning("br_variant", variant)
                 api.set_tuning("br_digit_table", table)
                 api.set_tuning("br4_max_rotations", br4_max)
+                api.set_tuning("br8_max_rotations", br8_max)
                 u, acc = api.kernel_bootstrap_woks(ks, lins, want_acc=True)
                 for c in range(len(lins)):
-                    assert (acc[c] == want[c]).all(), (pname, variant, table, br4_max, c)
+                    assert (acc[c] == want[c]).all(), (pname, variant, table, br4_max, br8_max, c)
                     assert (u[c] == oks.sample_extract(want[c])).all()
                 um = api.kernel_bootstrap_woks(ks, many)
                 if ref_many is None:
                     ref_many = um
                     for c in (0, 599):
                         assert (um[c] == oks.bootstrap_woks(many[c])).all()
-                assert (um == ref_many).all(), (pname, variant, table, br4_max)
+                assert (um == ref_many).all(), (pname, variant, table, br4_max, br8_max)
+                ul = api.kernel_bootstrap_woks(ks, many[:200])           # 200 workgroups: one per CU, the 8-wave form's range
+                assert (ul == ref_many[:200]).all(), (pname, variant, table, br4_max, br8_max, "200-wide")
         finally:
             api.set_tuning("br_variant", 0)
             api.set_tuning("br_digit_table", 1)
             api.set_tuning("br4_max_rotations", 1 << 30)
+            api.set_tuning("br8_max_rotations", 1 << 30)
     finally:
         ks.close()
