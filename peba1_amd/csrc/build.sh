@@ -8,7 +8,10 @@ HIPCC=${HIPCC:-$ROCM/bin/hipcc}
 CXX=${HOSTCXX:-$ROCM/lib/llvm/bin/clang++}
 FLAGS="-O3 -std=c++17 -fPIC -ffp-contract=off -Wall -Wno-unused-result"
 HOSTFLAGS="$FLAGS -D__HIP_PLATFORM_AMD__ -I$ROCM/include"
-$HIPCC $FLAGS ${HIP_EXTRA_FLAGS:-} --offload-arch=gfx950 -c kernels.hip -o kernels.o &
+# max-ilp scheduling: the blind-rotate kernel is bound by multiplier-class issue and dependency stalls;
+# measured 1 % faster than the default strategy, max-memory-clause and no clustering 3-4 % slower
+# (tools/diag/sched_flags.sh)
+$HIPCC $FLAGS ${HIP_EXTRA_FLAGS--mllvm -amdgpu-sched-strategy=max-ilp} --offload-arch=gfx950 -c kernels.hip -o kernels.o &
 $CXX $HOSTFLAGS -c host_keys.cpp -o host_keys.o &
 $CXX $HOSTFLAGS -c engine.cpp -o engine.o &
 $CXX $HOSTFLAGS -c shim.cpp -o shim.o &
