@@ -137,6 +137,11 @@ typedef struct TfheHipStats {
     double   ms_blind_rotate_busy; /* time during which at least one blind-rotate launch was running
                                       (== ms_blind_rotate with one lane; less when two lanes overlap) */
     uint64_t reused_gates;      /* recorded gates served by an identical pending gate ("reuse_gates") */
+    /* of the blind-rotate totals above, the part run by the 8-wave form (launches of at most one
+     * workgroup per CU); the rest is the 4-wave kernel */
+    uint64_t br8_launches;
+    uint64_t br8_rotations;
+    double   ms_blind_rotate8;
 } TfheHipStats;
 void tfhe_hip_get_stats(TfheHipStats *out);
 void tfhe_hip_reset_stats(void);

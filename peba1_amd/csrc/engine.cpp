@@ -307,7 +307,7 @@ void Engine::read_slots_packed(SlotPool *pool, const int32_t *slots, int count, 
     hip_check(hipStreamSynchronize(stream_), "gather slots");
 }
 
-void Engine::launch_br(const DeviceKeyImage *key, const int32_t *pool, const RotDesc *rots, int count, int32_t *u_buf,
+bool Engine::launch_br(const DeviceKeyImage *key, const int32_t *pool, const RotDesc *rots, int count, int32_t *u_buf,
                        int32_t *acc_dbg, hipStream_t stream, int wave_prio) {
     if (!stream) stream = stream_;
     if (count <= br4_max_rotations) {
@@ -325,15 +325,17 @@ void Engine::launch_br(const DeviceKeyImage *key, const int32_t *pool, const Rot
         }
         dp.wg_times = wg_times_dbg_;
         // launches that leave CUs with at most one workgroup: the 8-wave form (a second wave per SIMD)
-        if (br8_max_rotations > 0 && count <= std::min(br8_max_rotations, cu_count_) && dp.N == 1024 && dp.l >= 2 && !wg_times_dbg_)
+        if (br8_max_rotations > 0 && count <= std::min(br8_max_rotations, cu_count_) && dp.N == 1024 && dp.l >= 2 && !wg_times_dbg_) {
             launch_blind_rotate8(stream, dp, key->key, pool, rots, count, u_buf, acc_dbg);
-        else
-            launch_blind_rotate4(stream, dp, key->key, pool, rots, count, u_buf, acc_dbg);
-        return;
+            return true;
+        }
+        launch_blind_rotate4(stream, dp, key->key, pool, rots, count, u_buf, acc_dbg);
+        return false;
     }
     // (splitting a short last round off to the latency kernel was measured: the kernel
     // boundary costs more overlap than the faster tail gains -- match 3.99 s -> 4.15 s)
     launch_blind_rotate(stream, key->dp, key->key, pool, rots, count, u_buf, acc_dbg);
+    return false;
 }
 
 void Engine::launch_ks(const DeviceKeyImage *key, const int32_t *u_buf, const KsDesc *descs, int count, int32_t *pool,
@@ -423,7 +425,7 @@ void Engine::execute(const DeviceKeyImage *key, SlotPool *pool, const LevelPlan 
         }
         return timing_events_[nt++];
     };
-    struct Timed { hipEvent_t e0, e1, e2; };
+    struct Timed { hipEvent_t e0, e1, e2; bool wide8; };
     std::vector<Timed> timed;
     hipEvent_t base = nullptr;
     if (kernel_timing) {
@@ -450,9 +452,12 @@ void Engine::execute(const DeviceKeyImage *key, SlotPool *pool, const LevelPlan 
                     waited[s][o] = w;
                 }
             }
-            Timed t{nullptr, nullptr, nullptr};
+            Timed t{nullptr, nullptr, nullptr, false};
             if (kernel_timing) { t.e0 = timing_event(); hip_check(hipEventRecord(t.e0, st), "event"); }
-            if (nrot) launch_br(key, pool->data(), drots + plan.rot_off[gg], nrot, u_buf[s], nullptr, st, K > 1 && s == 0 ? lane_prio : 0);
+            if (nrot) {
+                t.wide8 = launch_br(key, pool->data(), drots + plan.rot_off[gg], nrot, u_buf[s], nullptr, st, K > 1 && s == 0 ? lane_prio : 0);
+                if (t.wide8) { ++stats.br8_launches; stats.br8_rotations += (uint64_t)nrot; }
+            }
             if (kernel_timing) { t.e1 = timing_event(); hip_check(hipEventRecord(t.e1, st), "event"); }
             if (nks) launch_ks(key, u_buf[s], dks + plan.ks_off[gg], nks, pool->data(), st, s);
             if (kernel_timing) { t.e2 = timing_event(); hip_check(hipEventRecord(t.e2, st), "event"); timed.push_back(t); }
@@ -489,6 +494,7 @@ void Engine::execute(const DeviceKeyImage *key, SlotPool *pool, const LevelPlan 
             hip_check(hipEventElapsedTime(&b, base, t.e1), "elapsed");
             hip_check(hipEventElapsedTime(&c, base, t.e2), "elapsed");
             stats.ms_blind_rotate += b - a;
+            if (t.wide8) stats.ms_blind_rotate8 += b - a;
             stats.ms_keyswitch += c - b;
             if (b > a) br.emplace_back(a, b);
         }

@@ -139,7 +139,8 @@ public:
     // stream == nullptr: the engine's stream; lane selects the scratch buffer of the partial sums
     void launch_ks(const DeviceKeyImage *key, const int32_t *u_buf, const KsDesc *descs, int count, int32_t *pool,
                    hipStream_t stream = nullptr, int lane = 0);
-    void launch_br(const DeviceKeyImage *key, const int32_t *pool, const RotDesc *rots, int count, int32_t *u_buf,
+    // returns true when the launch used the 8-wave form
+    bool launch_br(const DeviceKeyImage *key, const int32_t *pool, const RotDesc *rots, int count, int32_t *u_buf,
                    int32_t *acc_dbg, hipStream_t stream = nullptr, int wave_prio = 0);
     // diagnostic (tools/lane_probe.py): `levels` rounds of (blind rotate + key switch) of `width`
     // random gates in total, issued as `lanes` independent chains on `lanes` streams; returns ms

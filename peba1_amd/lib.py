@@ -49,7 +49,8 @@ class Stats(C.Structure):
     _fields_ = [("blind_rotates", C.c_uint64), ("keyswitches", C.c_uint64), ("linear_ops", C.c_uint64),
                 ("levels", C.c_uint64), ("flushes", C.c_uint64), ("br_launches", C.c_uint64),
                 ("ms_blind_rotate", C.c_double), ("ms_keyswitch", C.c_double), ("ms_flush_wall", C.c_double),
-                ("ms_blind_rotate_busy", C.c_double), ("reused_gates", C.c_uint64)]
+                ("ms_blind_rotate_busy", C.c_double), ("reused_gates", C.c_uint64),
+                ("br8_launches", C.c_uint64), ("br8_rotations", C.c_uint64), ("ms_blind_rotate8", C.c_double)]
 
 
 PS = C.POINTER(ParameterSet)
