@@ -29,6 +29,7 @@ rotations (a MUX is two) of ALL ranks per second of the slowest rank.
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
 """
 import argparse
+import ctypes
 import hashlib
 import json
 import os
@@ -148,6 +149,10 @@ def main():
                          "matches, 256-slot match, Hamming, optimised DAG); 0 = skip")
     ap.add_argument("--force-dist", action="store_true",
                     help="initialise the RCCL process group even at world size 1 (exercises the N>1 code path)")
+    ap.add_argument("--backend", choices=["nccl", "gloo"], default="nccl",
+                    help="nccl (= RCCL, one GPU per rank; the default and what the driver runs) or gloo: the exchange "
+                         "goes through host buffers and every rank uses GPU `LOCAL_RANK mod device count`, so the N>1 "
+                         "logic can be rehearsed with several processes on ONE GPU (tests do; never a measurement)")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -165,12 +170,18 @@ def main():
     use_dist = world > 1 or args.force_dist
     if use_dist or mode == "sharded":
         import torch
+    xdev = "cuda"                     # where ciphertexts sit for the exchange
     if use_dist:
         import torch.distributed as dist
         if "MASTER_ADDR" not in os.environ:
             os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT="29577", RANK="0", WORLD_SIZE="1")
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if args.backend == "gloo":
+            xdev = "cpu"
+            local_rank = local_rank % max(1, torch.cuda.device_count())
+            dist.init_process_group("gloo")
+        else:
+            torch.cuda.set_device(local_rank)
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
 
     from peba1_amd import api, circuits, identify, lib
     from peba1_amd import dist as pd
@@ -206,15 +217,16 @@ def main():
         tmpl = circuits.EncryptedVector(pp, tmpl_vals, bitsize, ks).to_device()
         gather_buf = None
         if use_dist:
-            mine = torch.empty(pp.words, dtype=torch.int32, device="cuda")
-            gather_buf = [torch.empty(pp.words, dtype=torch.int32, device="cuda") for _ in range(world)] if rank == 0 else None
+            mine = torch.empty(pp.words, dtype=torch.int32, device=xdev)
+            gather_buf = [torch.empty(pp.words, dtype=torch.int32, device=xdev) for _ in range(world)] if rank == 0 else None
 
         def step():
             rb = api.CiphertextArray(pp, 3 * bitsize)
             circuits.function_f(rb, probe, tmpl, bound, bitsize, ks)   # records ~350k API calls
             api.flush()                                                # levelised batched execution
             if use_dist:    # the only exchange: match-bit ciphertexts to rank 0 over RCCL
-                L.tfhe_hip_export_samples_device(rb.ptr, 1, pp.ptr, mine.data_ptr())
+                (L.tfhe_hip_export_samples_device if xdev == "cuda" else L.tfhe_hip_export_samples)(
+                    rb.ptr, 1, pp.ptr, ctypes.cast(mine.data_ptr(), ctypes.c_void_p if xdev == "cuda" else lib.I32P))
                 dist.gather(mine, gather_buf, dst=0)
             return rb
 
@@ -224,15 +236,16 @@ def main():
             if use_dist and rank == 0:
                 torch.cuda.synchronize()
                 tmp = api.CiphertextArray(pp, 1)
-                L.tfhe_hip_import_samples_device(tmp.ptr, 1, pp.ptr, gather_buf[0].data_ptr())
+                (L.tfhe_hip_import_samples_device if xdev == "cuda" else L.tfhe_hip_import_samples)(
+                    tmp.ptr, 1, pp.ptr, ctypes.cast(gather_buf[0].data_ptr(), ctypes.c_void_p if xdev == "cuda" else lib.I32P))
                 assert (tmp.words()[0] == last.words()[0]).all(), "gathered match-bit ciphertext differs"
             return "decrypted match bit of the last timed match == plaintext rule (distance > bound)"
         workload = (f"Function_f: {nslots} slots x {bitsize} bit template match per GPU, every recorded gate executed")
         parallelism, scaling = f"1 match per GPU x {world}", "weak"
     elif mode == "sharded":
         tmpl_vals = base
-        nranks = world if world > 1 else max(1, logical)
-        lo, hi = pd.shard_slots(nslots, world, rank) if world > 1 else (0, nslots)
+        nranks = world if use_dist else max(1, logical)
+        lo, hi = pd.shard_slots(nslots, world, rank) if use_dist else (0, nslots)
         tmpl = circuits.EncryptedVector(pp, tmpl_vals, bitsize, ks).to_device()
         S = [a.ptr for a in probe.slots]
         T = [a.ptr for a in tmpl.slots]
@@ -240,13 +253,13 @@ def main():
         phase_ms = {"ranks": [], "combine": []}
 
         def step():
-            if world > 1:
-                mine = pd.local_partial(torch, prov, pp.ptr, ks.cloud, pp.words, S[lo:hi], T[lo:hi], bitsize, "cuda")
+            if use_dist:
+                mine = pd.local_partial(torch, prov, pp.ptr, ks.cloud, pp.words, S[lo:hi], T[lo:hi], bitsize, xdev)
                 gathered = [torch.empty_like(mine) for _ in range(world)] if rank == 0 else None
                 dist.gather(mine, gathered, dst=0)                     # 24 ciphertexts per rank, one collective
                 if rank != 0:
                     return None
-                res = pd.combine(torch, prov, pp.ptr, ks.cloud, gathered, bound.ptr, "cuda", fast=not args.ripple_combine)
+                res = pd.combine(torch, prov, pp.ptr, ks.cloud, gathered, bound.ptr, xdev, fast=not args.ripple_combine)
             else:
                 # logical ranks on the one device: the phases of dist.sharded_match_logical, timed one by one
                 gathered, rank_ms = [], []
@@ -272,9 +285,9 @@ def main():
             assert bit == plain_bit(tmpl_vals), f"sharded match bit {bit}"
             return "decrypted match bit of the last timed sharded match == plaintext rule (distance > bound)"
         workload = (f"slot-sharded Function_f: ONE {nslots} slots x {bitsize} bit match, slots partitioned over "
-                    f"{nranks} {'ranks' if world > 1 else 'logical ranks on one device'}, one gather of 24-ciphertext "
+                    f"{nranks} {'ranks' if use_dist else 'logical ranks on one device'}, one gather of 24-ciphertext "
                     f"partial sums, {'ripple-adder tree + bit-serial comparator' if args.ripple_combine else 'carry-save compressor + prefix adder + prefix comparator'} on rank 0")
-        parallelism = f"{nslots} slots / {nranks} {'GPUs' if world > 1 else 'logical ranks (1 GPU)'}"
+        parallelism = f"{nslots} slots / {nranks} {('GPUs' if args.backend == 'nccl' else 'processes (gloo rehearsal)') if use_dist else 'logical ranks (1 GPU)'}"
         scaling = "strong"
     else:   # identify
         M = args.matches
@@ -313,10 +326,10 @@ def main():
     st = api.stats()
     rotations_all = float(st["blind_rotates"])
     if use_dist:
-        tt = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        tt = torch.tensor([elapsed], dtype=torch.float64, device=xdev)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
-        rr = torch.tensor([rotations_all], dtype=torch.float64, device="cuda")
+        rr = torch.tensor([rotations_all], dtype=torch.float64, device=xdev)
         dist.all_reduce(rr, op=dist.ReduceOp.SUM)
         rotations_all = float(rr.item())
     checked = check(last)
@@ -325,12 +338,16 @@ def main():
         a_br, a_ks, ct = algorithmic_bytes(pp)
         steps = max(1, args.steps)
         value = rotations_all / elapsed
-        # the dominant kernel is the 4-wave blind rotate; launches of at most one workgroup per CU run the
-        # 8-wave form, reported beside it (the engine's statistics keep the two apart)
-        rot4 = st["blind_rotates"] - st["br8_rotations"]
-        ms4 = st["ms_blind_rotate"] - st["ms_blind_rotate8"]
-        n4 = st["br_launches"] - st["br8_launches"]
-        br_gbps = rot4 * a_br / (ms4 * 1e-3) / 1e9 if ms4 > 0 else 0.0
+        # two blind-rotate kernels: the 4-wave form, and the 8-wave form for launches of at most one workgroup
+        # per CU (the engine's statistics keep them apart).  The roofline block is for whichever took more time
+        # in this run -- the 4-wave kernel in every single-GPU match; the 8-wave one where every level is
+        # narrow (a few slots per rank) -- and carries the other beside it.
+        rot8, ms8, n8 = st["br8_rotations"], st["ms_blind_rotate8"], st["br8_launches"]
+        rot4, ms4, n4 = st["blind_rotates"] - rot8, st["ms_blind_rotate"] - ms8, st["br_launches"] - n8
+        dom8 = ms8 > ms4
+        drot, dms, dn = (rot8, ms8, n8) if dom8 else (rot4, ms4, n4)
+        orot, oms, on = (rot4, ms4, n4) if dom8 else (rot8, ms8, n8)
+        br_gbps = drot * a_br / (dms * 1e-3) / 1e9 if dms > 0 else 0.0
         ks_gbps = st["keyswitches"] * a_ks / (st["ms_keyswitch"] * 1e-3) / 1e9 if st["ms_keyswitch"] else 0.0
         traffic, valu, khash = committed_counters()
         out = {
@@ -351,15 +368,15 @@ def main():
             # is NOT HBM-bound -- the key image is served from L2 / Infinity Cache (`traffic` = measured
             # HBM-side bytes per launch, ~3 % of the algorithmic bytes) -- it is bound by VALU issue
             # (`valu`: share of SIMD cycles issuing VALU instructions, from the SQ counters).
-            "roofline": {"bound": "valu", "kernel": "blind_rotate4_kernel", "achieved": br_gbps, "peak": HBM_PEAK_GBPS,
+            "roofline": {"bound": "valu", "kernel": "blind_rotate8_kernel" if dom8 else "blind_rotate4_kernel", "achieved": br_gbps, "peak": HBM_PEAK_GBPS,
                          "unit": "GB/s", "frac": br_gbps / HBM_PEAK_GBPS, "traffic": traffic,
                          "achieved_is": "algorithmic bytes / launch time (cache reuse across gates counts as bandwidth)",
                          "valu": valu, "counters_measured_on_kernels_sha16": khash if (traffic or valu) else None,
                          "kernels_sha16": khash,
-                         "launches": int(n4), "avg_launch_ms": ms4 / max(1, n4), "rotations_per_launch": rot4 / max(1, n4),
-                         "narrow_launches_8_wave_form": {"kernel": "blind_rotate8_kernel", "launches": int(st["br8_launches"]),
-                                                         "avg_launch_ms": st["ms_blind_rotate8"] / max(1, st["br8_launches"]),
-                                                         "rotations_per_launch": st["br8_rotations"] / max(1, st["br8_launches"])},
+                         "launches": int(dn), "avg_launch_ms": dms / max(1, dn), "rotations_per_launch": drot / max(1, dn),
+                         "other_blind_rotate_kernel": {"kernel": "blind_rotate4_kernel" if dom8 else "blind_rotate8_kernel",
+                                                       "launches": int(on), "avg_launch_ms": oms / max(1, on),
+                                                       "rotations_per_launch": orot / max(1, on)},
                          "all_blind_rotate_algorithmic_GBps": st["blind_rotates"] * a_br / (st["ms_blind_rotate"] * 1e-3) / 1e9 if st["ms_blind_rotate"] else 0.0,
                          "algorithmic_bytes_per_blind_rotate": a_br,
                          "keyswitch_algorithmic_GBps": ks_gbps, "algorithmic_bytes_per_keyswitch": a_ks,

@@ -132,14 +132,18 @@ def combine(torch, prov, params_ptr, cloud_ptr, gathered, bound_ptr, device, fas
 
 
 def sharded_match(dist, torch, gate_lib, circ_lib, params_ptr, cloud_ptr, words, sample_slots, template_slots,
-                  bound_ptr, bitsize, device="cuda", fast_combine=False):
+                  bound_ptr, bitsize, device="cuda", fast_combine=False, partial_hook=None):
     """Slot-sharded Function_f across the ranks of `dist`.  `sample_slots` / `template_slots`: this
     rank's slot arrays (LweSample* each, `bitsize` samples).  Returns the 24-sample result array
     pointer on rank 0 (caller frees it with delete_gate_bootstrapping_ciphertext_array(24, p)),
-    None elsewhere."""
+    None elsewhere.  device="cuda": the exchange buffers are device tensors (RCCL); "cpu": host tensors
+    (gloo -- how several processes rehearse this on one GPU).  `partial_hook(rank, tensor)` sees this
+    rank's packed partial sums before the gather."""
     rank, world = dist.get_rank(), dist.get_world_size()
     prov = _Provider(gate_lib, circ_lib)
     mine = local_partial(torch, prov, params_ptr, cloud_ptr, words, sample_slots, template_slots, bitsize, device)
+    if partial_hook is not None:
+        partial_hook(rank, mine)
     # the exchange: 24 ciphertexts per rank -> rank 0, one collective
     gathered = [torch.empty_like(mine) for _ in range(world)] if rank == 0 else None
     dist.gather(mine, gathered, dst=0)

@@ -179,3 +179,81 @@ def test_cfg4_identification_streams_matches_through_bounded_flushes(p128_keys):
     got = [int(b) for b in bits_ct.decrypt(ks)]
     want = [1 if sum((a - b) ** 2 for a, b in zip(probe_v, t)) > 256 else 0 for t in templates_v]
     assert got == want and got.count(0) == 1 and got[genuine] == 0
+
+
+TWO_PROCESS_WORKER = r'''
+import ctypes as C, hashlib, json, os, sys
+import numpy as np
+import torch, torch.distributed as dist
+ROOT = os.environ["PEBA1_ROOT"]
+sys.path.insert(0, ROOT)
+from peba1_amd import api, circuits, lib
+from peba1_amd import dist as pd
+dist.init_process_group("gloo")
+rank, world = dist.get_rank(), dist.get_world_size()
+g = json.load(open(os.path.join(ROOT, "tests", "golden", "sharded_match_digest.json")))
+assert world == g["world"]
+L = lib.load()
+pp = api.ParameterSet(128)
+ks = api.SecretKeySet(pp, g["key_seed"], device=True)            # every rank: the same keys from the same seed
+L.tfhe_hip_set_encrypt_seed(g["encrypt_seed"])                     # and the same input ciphertexts (fixture order)
+T, S = [], []
+for t, s in zip(g["template"], g["probe"]):
+    T.append(circuits.encrypt_number(pp, t, g["bits"], ks))
+    S.append(circuits.encrypt_number(pp, s, g["bits"], ks))
+bound = circuits.encrypt_number(pp, g["bound"], 3 * g["bits"], ks)
+lo, hi = pd.shard_slots(len(T), world, rank)
+seen = {}
+res = pd.sharded_match(dist, torch, L, circuits.load(), pp.ptr, ks.cloud, pp.words, [a.ptr for a in S[lo:hi]],
+                       [a.ptr for a in T[lo:hi]], bound.ptr, g["bits"], device="cpu",
+                       partial_hook=lambda r, t: seen.__setitem__(r, hashlib.sha256(t.numpy().tobytes()).hexdigest()))
+assert seen[rank] == g["partial_sha256"][rank], ("partial sums of rank", rank)
+if rank == 0:
+    r = C.cast(res, lib.LS)
+    words = np.zeros((24, pp.words), dtype=np.int32)
+    assert L.tfhe_hip_export_samples(r, 24, pp.ptr, words.ctypes.data_as(lib.I32P)) == 0
+    assert hashlib.sha256(words.tobytes()).hexdigest() == g["result_b_sha256"]
+    assert L.bootsSymDecrypt(r, ks.ptr) == g["match_bit"]
+    print("TWO-PROCESS-OK")
+dist.barrier()
+dist.destroy_process_group()
+'''
+
+
+def _torchrun(nproc, args, port, timeout=400):
+    import subprocess
+    import sys
+    env = dict(os.environ, PEBA1_ROOT=ROOT, MASTER_ADDR="127.0.0.1")
+    return subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={nproc}",
+                           "--master-addr", "127.0.0.1", "--master-port", str(port)] + args,
+                          env=env, capture_output=True, text=True, timeout=timeout, cwd=ROOT)
+
+
+def test_sharded_match_in_two_processes_reproduces_the_oracle_digest(tmp_path):
+    """ADVICE r1: a world >= 2 run of dist.sharded_match on the HIP path.  Two processes (gloo for the
+    exchange, both on the one GPU of a test box) regenerate the same keys and inputs, each evaluates
+    its slot range, ONE gather moves the partial sums, rank 0 combines: the packed partial sums of
+    both ranks and the 24 outputs hash to the oracle's digests of the same DAG
+    (tests/golden/sharded_match_digest.json) -- the real multi-process path, bit for bit."""
+    w = tmp_path / "worker.py"
+    w.write_text(TWO_PROCESS_WORKER)
+    out = _torchrun(2, [str(w)], 29641)
+    assert out.returncode == 0 and "TWO-PROCESS-OK" in out.stdout, out.stdout[-1500:] + out.stderr[-3000:]
+
+
+def test_bench_multi_process_default_mode_rehearsal():
+    """What the driver's `bench.py --gpus N` runs at N > 1 -- mode auto = sharded: slots partitioned
+    over the ranks, one gather, rank 0 combines, barrier + max-over-ranks timing, one JSON line from
+    rank 0 -- rehearsed with two processes on one GPU (--backend gloo), 8 slots.  A rehearsal of the
+    code path, not a measurement."""
+    import json
+    out = _torchrun(2, ["bench.py", "--gpus", "2", "--backend", "gloo", "--steps", "1", "--warmup", "0", "--slots", "8",
+                        "--no-cpu-baseline"], 29643)
+    assert out.returncode == 0, out.stdout[-1500:] + out.stderr[-3000:]
+    line = [l for l in out.stdout.splitlines() if l.startswith("{")][-1]
+    j = json.loads(line)
+    assert j["n_gpus"] == 2 and j["scaling"] == "strong" and j["config"]["mode"] == "sharded"
+    assert j["value"] > 0 and j["roofline"]["frac"] > 0
+    # all ranks' rotations are counted: 8 slots of the reference's loop, one adder on rank 0, the comparator
+    rotations = j["value"] * j["ms_per_step"] / 1e3
+    assert 8 * 1683 - 1 <= rotations <= 8 * 1683 + 1000, rotations
