@@ -85,7 +85,7 @@ int tfhe_hip_sync_samples(const LweSample *samples, int32_t count);
  * is decrypted, exported or passed to tfhe_hip_sync_samples().
  * immediate (TFHE_HIP_DEFERRED=0 in the environment, or tfhe_hip_set_deferred(0)): every
  * boots* call is complete on return with the host mirror refreshed, as upstream -- one gate
- * per kernel launch, 3.9 ms per gate. */
+ * per kernel launch, 3.4 ms per gate. */
 void tfhe_hip_set_deferred(int on);
 int tfhe_hip_get_deferred(void);
 int tfhe_hip_flush(void);   /* returns the number of levels executed, <0 on error */

@@ -90,8 +90,8 @@ struct Recorder {
     // Default: deferred.  The reference (and any caller that stays inside the tfhe C API) never
     // reads a field of LweSample -- results are only ever observed through bootsSymDecrypt or an
     // export, and both run the pending gates first -- so recording is transparent to it and is
-    // what lets an UNMODIFIED caller run at batch throughput (one gate per launch is 3.9 ms:
-    // 260 gates/s).  TFHE_HIP_DEFERRED=0 / tfhe_hip_set_deferred(0) restores strict per-call
+    // what lets an UNMODIFIED caller run at batch throughput (one gate per launch is 3.4 ms:
+    // 290 gates/s).  TFHE_HIP_DEFERRED=0 / tfhe_hip_set_deferred(0) restores strict per-call
     // completion with the host mirror (a, b) refreshed on return, as upstream's own struct has it.
     bool deferred = true;
     const TFheGateBootstrappingCloudKeySet *key = nullptr;   // key of the pending operations
