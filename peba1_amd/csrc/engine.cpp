@@ -131,7 +131,7 @@ static uint32_t bitrev32(uint32_t x, int bits) {
 static std::vector<uint32_t> make_twiddles(int N, uint32_t scale_out[2]) {
     int logn = 0;
     while ((1 << logn) < N) ++logn;
-    std::vector<uint32_t> tw((size_t)12 * N);
+    std::vector<uint32_t> tw((size_t)24 * N);
     for (int q = 0; q < 2; ++q) {
         const uint64_t P = NTT_P[q];
         const uint64_t psi = powmod_c(NTT_GEN[q], (P - 1) / (uint64_t)(2 * N), P);
@@ -157,6 +157,34 @@ static std::vector<uint32_t> make_twiddles(int N, uint32_t scale_out[2]) {
                 t4[4 * e + 1] = (uint32_t)(w3 * R % P);
                 t4[4 * e + 2] = (uint32_t)(w1 * w2 % P * R % P);
                 t4[4 * e + 3] = (uint32_t)((P - w1 * w3 % P) % P * R % P);
+            }
+        }
+        // Sub-transform tables of the split kernels (kernels.hip blind_rotate_split_kernel): after
+        // stage 0 the two halves of the index range are independent N/2-point transforms whose stage
+        // s' twiddle of block t' is W[(2 + h) 2^s' + t'].  Block h (6N words at 12N + 6N h) is laid
+        // out exactly like the table of a stand-alone N/2-point transform, so the same code walks it.
+        for (int h = 0; h < 2; ++h) {
+            const int M = N / 2;
+            uint32_t *blk = &tw[(size_t)12 * N + (size_t)h * 12 * M];
+            for (int dir = 0; dir < 2; ++dir) {
+                const std::vector<uint64_t> &W = plain[dir];
+                uint32_t *t2 = blk + (size_t)(q * 2 + dir) * M;
+                uint32_t *t4 = blk + (size_t)4 * M + (size_t)(q * 2 + dir) * 2 * M;
+                auto full = [&](int e) {                 // e = 2^s' + t' -> (2 + h) 2^s' + t'
+                    int top = 1;
+                    while (top * 2 <= e) top *= 2;
+                    return (2 + h) * top + (e - top);
+                };
+                t2[0] = 0;
+                for (int e = 1; e < M; ++e) t2[e] = (uint32_t)(W[full(e)] * R % P);
+                for (int e = 1; e < M / 2; ++e) {
+                    const int f = full(e);
+                    const uint64_t w1 = W[f], w2 = W[2 * f], w3 = W[2 * f + 1];
+                    t4[4 * e + 0] = (uint32_t)(w2 * R % P);
+                    t4[4 * e + 1] = (uint32_t)(w3 * R % P);
+                    t4[4 * e + 2] = (uint32_t)(w1 * w2 % P * R % P);
+                    t4[4 * e + 3] = (uint32_t)((P - w1 * w3 % P) % P * R % P);
+                }
             }
         }
         // image scale: N^-1 (the inverse NTT is unscaled) times R (so that the
@@ -315,6 +343,10 @@ bool Engine::launch_br(const DeviceKeyImage *key, const int32_t *pool, const Rot
         dp.wave_prio = wave_prio;
         dp.br_variant = dp.N == 1024 && br_variant == 1 ? 1 : 0;
         dp.digit_table = br_digit_table;
+        if (br_variant == 2 || (br_variant < 0 && dp.N == 2048 && br_split_auto_2048)) {
+            launch_blind_rotate_split(stream, dp, key->key, pool, rots, count, u_buf, acc_dbg);
+            return false;
+        }
         if (br_fair > 0 && count > cu_count_) {                   // only launches that put several workgroups on a CU
             if (!cu_arrivals_) {
                 hip_check(hipMalloc(&cu_arrivals_, 4096 * sizeof(uint32_t)), "hipMalloc(cu arrivals)");
@@ -669,7 +701,8 @@ double Engine::run_lane_probe(const DeviceKeyImage *key, int lanes, int levels, 
 }
 
 void Engine::run_negacyclic(const DeviceKeyImage *key, const int32_t *ip, const Torus32 *tp, Torus32 *res, int count) {
-    const DevParams &dp = key->dp;
+    DevParams dp = key->dp;
+    dp.br_variant = br_variant == 2 ? 2 : 0;             // 2: through the split transforms
     const size_t words = (size_t)count * dp.N;
     uint32_t scale[2];
     (void)make_twiddles(dp.N, scale);

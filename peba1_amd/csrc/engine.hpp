@@ -127,9 +127,12 @@ public:
     // cycles (0 = off: the hardware's oldest-first issue runs one at full speed and leaves the
     // other to finish alone with one wave per SIMD; measured optimum 2^16..2^20, tools/wg_times.py)
     int br_fair = 18;
-    // N = 1024: which form of the 4-wave blind-rotate kernel runs (kernels.hip BrTraits): 0 = wide
-    // (keeps D and 64-bit partial sums in registers, two workgroups per CU), 1 = lean (three per CU)
-    int br_variant = 0;
+    // which form of the blind-rotate kernel runs wide launches (kernels.hip): -1 = the fastest measured
+    // for the ring size, 0 = 4-wave wide at N = 1024 (D and 64-bit partial sums in registers, two
+    // workgroups per CU) / 4-wave lean at N = 2048, 1 = 4-wave lean at N = 1024 (three per CU),
+    // 2 = split (8 waves, half transforms); env TFHE_HIP_BR_VARIANT, tuning "br_variant"
+    int br_variant = -1;
+    bool br_split_auto_2048 = true;     // measured: 21.9k against 19.1k rotations/s, and half the latency
     // launches of at most min(this, CU count) rotations (at most one workgroup per CU) use the 8-wave form
     // of the kernel, N = 1024 only; 0 = never (env TFHE_HIP_BR8_MAX, tuning "br8_max_rotations")
     int br8_max_rotations = 1 << 30;

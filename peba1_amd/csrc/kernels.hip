@@ -51,6 +51,12 @@ __device__ __forceinline__ PrimeCtx make_ctx(int q, const uint32_t *tw, int n_ri
     return c;
 }
 
+// context of half h of a split transform (engine.cpp make_twiddles: the sub-transform tables follow
+// the 12N words of the full-size ones, 6N words per half, laid out like an N/2-point table)
+__device__ __forceinline__ PrimeCtx make_sub_ctx(int q, int h, const uint32_t *tw, int n_ring) {
+    return make_ctx(q, tw + (size_t)12 * n_ring + (size_t)h * 6 * n_ring, n_ring / 2);
+}
+
 // acc64 (sum of <= 6 products x*bk, |x| < 11.1P, 0 <= bk < P, so |acc| < 2^61) ->
 // Montgomery reduction (|.| < 2.6P), inverse NTT, canonical residue in [0,P)
 template <int LOGN>
@@ -323,9 +329,9 @@ __device__ __forceinline__ void forward_poly(const DevParams &p, const DevKey &k
 }
 
 // sample extract at index 0 (tfhe tLweExtractLweSampleIndex) + optional raw accumulator dump
-template <int LOGN, int THREADS>
+template <int LOGN, int THREADS, typename AccT>
 __device__ __forceinline__ void extract_sample(const DevParams &p, const RotDesc &rd,
-                                               const AccLds<LOGN> &acc,
+                                               const AccT &acc,
                                                int32_t *__restrict__ u_buf, int32_t *__restrict__ acc_dbg, int tid) {
     constexpr int N = 1 << LOGN;
     int32_t *u = u_buf + (size_t)rd.u_index * p.u_stride;
@@ -735,6 +741,245 @@ __global__ __launch_bounds__(512, 2) void blind_rotate8_kernel(
         __syncthreads();
     }
     extract_sample<LOGN, 512>(p, rd, sh.acc, u_buf, acc_dbg, tid);
+}
+
+// ---------------------------------------------------------------------------
+// K1+K2: blind rotate, split form.  grid = rotations, 512 threads: wave (q, u, h) works modulo
+// prime q on input polynomial u and on HALF h of every transform, N/128 coefficients per lane.
+// A Cooley-Tukey transform splits after its first stage: y_h[j] = x[j] +/- W[1] x[j + N/2] (j < N/2)
+// are the inputs of two independent N/2-point transforms whose twiddles are those of the subtree
+// below block h (engine.cpp make_twiddles lays them out like an N/2-point table, so WaveNtt<LOGN-1>
+// runs them unchanged), and their outputs are halves [h N/2, (h+1) N/2) of the full spectrum in the
+// same order -- the key image is read as it is, each lane fetching its 16-byte groups from two rows.
+// The inverse runs the two half transforms and ends with the stage-0 butterflies
+// (a0 + a1, (a0 - a1) W^-1[1]) on outputs of BOTH halves: every wave leaves its half-transform
+// outputs in LDS, and each of the four waves of output polynomial u finishes coefficients 64 r + lane
+// and N/2 + 64 r + lane for a quarter of the register rows r -- for both primes, so that last stage,
+// the recombination and the accumulator update need one exchange, three workgroup barriers per step
+// as in the 4-wave form.
+// What it buys: at N = 2048 a wave holds 16 coefficients per lane instead of 32, both row sums stay in
+// 64 bits and two waves per SIMD fit (the 4-wave form runs lean there); at N = 1024, 8 coefficients
+// per lane and four waves per SIMD.  What it costs: stage 0 is outside the radix-4 pairing (digits:
+// one table read and one addition per coefficient and gadget row), D is computed by both halves,
+// 8 waves meet at each barrier.  Same integers as the other forms.
+// ---------------------------------------------------------------------------
+template <int LOGN>
+struct BrSplitLds {
+    using SUB = WaveNtt<LOGN - 1>;
+    AccLds<LOGN, 3> acc;
+    uint32_t scr[8][SUB::SCRATCH_WORDS];           // wave-private NTT transposes; from the end of the inverse to the
+                                                   // step's last barrier: its outputs (natural order), read by 3 waves
+    uint32_t x1[8][SUB::SCRATCH_WORDS];            // partial sums sent to the wave of the other input polynomial
+    uint16_t bar[1024 + 8];
+    uint32_t tab0[2][2][DIGIT_TAB];                // [prime][h]: (+/-) W[1] * digit, signed residues
+};
+
+// representative in (-2P, 2P) -> canonical
+__device__ __forceinline__ uint32_t canon2(int32_t x, uint32_t P) {
+    return csub((uint32_t)x + (((uint32_t)(x >> 31)) & (2u * P)), P);
+}
+// last inverse stage on half-transform outputs (a0, a1 modulo P0; b0, b1 modulo P1) of one coefficient
+// pair, canonical residues, CRT: the Torus32 increment of coefficient j (h = 0) or j + N/2 (h = 1)
+__device__ __forceinline__ uint32_t split_finish(int h, int32_t a0, int32_t a1, int32_t b0, int32_t b1, uint32_t iw1_0,
+                                                 uint32_t iw1_1) {
+    uint32_t y0, y1;
+    if (h == 0) {
+        y0 = canon2(a0 + a1, NTT_P0);
+        y1 = canon2(b0 + b1, NTT_P1);
+    } else {
+        y0 = canon(mont_mul(a0 - a1, iw1_0, NTT_P0, NTT_PINV0), NTT_P0);
+        y1 = canon(mont_mul(b0 - b1, iw1_1, NTT_P1, NTT_PINV1), NTT_P1);
+    }
+    return crt_to_torus(y0, y1);
+}
+
+template <int LOGN, bool TAB>
+__global__ __launch_bounds__(512, (LOGN == 10 ? 4 : 2)) void blind_rotate_split_kernel(
+    DevParams p, DevKey key, const int32_t *__restrict__ pool, const RotDesc *__restrict__ rots,
+    int32_t *__restrict__ u_buf, int32_t *__restrict__ acc_dbg) {
+    using SUB = WaveNtt<LOGN - 1>;
+    constexpr int N = 1 << LOGN, M = N / 2, RS = SUB::REGS, RF = 2 * RS, G4 = RS / 4, QUARTER = RS / 4;
+    __shared__ __align__(16) BrSplitLds<LOGN> sh;
+    const int tid = threadIdx.x;
+    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int q = wv & 1, u = (wv >> 1) & 1, h = wv >> 2;
+    const int lane = tid & 63;
+    const PrimeCtx c = make_sub_ctx(q, h, key.tw, N);
+    uint32_t *scr = sh.scr[wv];
+    const int n = p.n;
+    const RotDesc rd = rots[blockIdx.x];
+    // stage-0 twiddles (entry 1 of the full-size tables): forward of this wave's prime, inverse of both
+    const uint32_t w1 = key.tw[(size_t)(q * 2 + 0) * N + 1];
+    const uint32_t iw1_0 = key.tw[(size_t)1 * N + 1], iw1_1 = key.tw[(size_t)3 * N + 1];
+
+    prelude_modswitch<LOGN, 512>(p, rd, pool, sh.bar, tid);
+    if constexpr (TAB) {
+        // the two waves (q, 0, h) and (q, 1, h) fill the table of (q, h)
+        const int fields = 1 << p.Bgbit;
+        for (int f = (u << 6) | lane; f < fields; f += 128) {
+            const int32_t d = f < fields / 2 ? f : f - fields;
+            const int32_t v = mont_mul(d, w1, c.P, c.pinv);
+            sh.tab0[q][h][f] = (uint32_t)(h ? -v : v);
+        }
+    }
+    __syncthreads();
+    if (q == 0) {
+        const int barb = sh.bar[n];
+#pragma unroll
+        for (int r = 0; r < RS; ++r) {
+            const int j = h * M + r * 64 + lane;
+            sh.acc.set(u, j, u == 0 ? 0u : testvector_coef<LOGN>(j, barb, p.mu));
+        }
+    }
+    __syncthreads();
+
+    const int width = p.Bgbit;
+    // where the 16-byte groups of this lane's slice of spectrum half h sit in a row of the key image
+    // (full-size layout L2: slot j = 2 RS * lane' + reg; this lane holds slots h N/2 + RS * lane + reg)
+    const int lane_off = G4 * (lane & 1) * 64 + h * 32 + (lane >> 1);
+    const int o0 = u ? N / 4 : 0, o1 = N / 4 - o0;          // acc0 <- output polynomial u (kept), acc1 <- 1-u (sent)
+    for (int i = 0; i < n; ++i) {
+        const int abar = __builtin_amdgcn_readfirstlane((int)sh.bar[i]);
+        if (abar == 0) continue;
+        uint32_t D[RF];                                      // coefficients 64 r + lane, r < 2 RS: both halves of the input
+        sh.acc.template rotated_difference<RF>(D, u, lane, abar, p.decomp_offset);
+        int64_t acc0[RS], acc1[RS];
+        auto row = [&](int jj, auto first) {
+            const int prow = u * p.l + jj;
+            const uint4 *bp = reinterpret_cast<const uint4 *>(
+                                  key.bk_img + ((size_t)((size_t)i * p.kpl + prow) * 2 + q) * 2 * N) + lane_off;
+            uint4 b0[G4], b1[G4];
+#pragma unroll
+            for (int g = 0; g < G4; ++g) b0[g] = bp[o0 + g * 64];
+#pragma unroll
+            for (int g = 0; g < G4; ++g) b1[g] = bp[o1 + g * 64];
+            typename SUB::FwdTw0 t0;
+            t0.load(c, lane);
+            const int shift = 32 - (jj + 1) * width;
+            int32_t x[RS];
+            if constexpr (TAB) {
+                const uint32_t mask4 = ((1u << width) - 1u) << 2;
+                const int sh2 = shift - 2;
+                const char *tab = reinterpret_cast<const char *>(sh.tab0[q][h]);
+#pragma unroll
+                for (int r = 0; r < RS; ++r)
+                    x[r] = __builtin_amdgcn_sbfe((int32_t)D[r], shift, width) +
+                           (int32_t)*reinterpret_cast<const uint32_t *>(tab + ((D[r + RS] >> sh2) & mask4));
+            } else {
+#pragma unroll
+                for (int r = 0; r < RS; ++r) {
+                    const int32_t v = mont_mul(__builtin_amdgcn_sbfe((int32_t)D[r + RS], shift, width), w1, c.P, c.pinv);
+                    x[r] = __builtin_amdgcn_sbfe((int32_t)D[r], shift, width) + (h ? -v : v);
+                }
+            }
+            SUB::template forward<true>(x, c, scr, lane, t0);         // |x| < P + 2^11 in, < 8.3P out
+#pragma unroll
+            for (int g = 0; g < G4; ++g) {
+                const int32_t bb0[4] = {(int32_t)b0[g].x, (int32_t)b0[g].y, (int32_t)b0[g].z, (int32_t)b0[g].w};
+                const int32_t bb1[4] = {(int32_t)b1[g].x, (int32_t)b1[g].y, (int32_t)b1[g].z, (int32_t)b1[g].w};
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const int r = 4 * g + e;
+                    if constexpr (decltype(first)::value) {
+                        acc0[r] = (int64_t)x[r] * bb0[e];
+                        acc1[r] = (int64_t)x[r] * bb1[e];
+                    } else {
+                        acc0[r] += (int64_t)x[r] * bb0[e];
+                        acc1[r] += (int64_t)x[r] * bb1[e];
+                    }
+                }
+            }
+        };
+        row(0, std::true_type{});
+#pragma unroll 1
+        for (int jj = 1; jj < p.l; ++jj) row(jj, std::false_type{});
+
+        int32_t t[RS];
+        {
+            int32_t send[RS];
+#pragma unroll
+            for (int r = 0; r < RS; ++r) {
+                t[r] = mont_redc(acc0[r], c.P, c.pinv);              // l <= 4 rows of |x| < 8.3P: |.| < 1.6P
+                send[r] = mont_redc(acc1[r], c.P, c.pinv);
+            }
+            SUB::write_row(send, sh.x1[wv], lane);
+        }
+        __syncthreads();
+        {
+            int32_t other[RS];
+            SUB::read_row(other, sh.x1[wv ^ 2], lane);
+#pragma unroll
+            for (int r = 0; r < RS; ++r) t[r] += other[r];          // |.| < 3.2P (the inverse takes < 4P)
+        }
+        SUB::template inverse<true>(t, c, scr, lane);
+#pragma unroll
+        for (int r = 0; r < RS; ++r) scr[r * 64 + lane] = (uint32_t)t[r];
+        __syncthreads();
+        {
+            // the four waves of output polynomial u take a quarter of the register rows each and finish
+            // coefficients j and j + N/2 of it (equal work for every wave; the four words read serve both)
+            const uint32_t *a0 = sh.scr[(u << 1)], *a1 = sh.scr[(u << 1) | 4];
+            const uint32_t *b0 = sh.scr[(u << 1) | 1], *b1 = sh.scr[(u << 1) | 5];
+            const int part = q | (h << 1);
+#pragma unroll
+            for (int r = 0; r < QUARTER; ++r) {
+                const int jl = (part * QUARTER + r) * 64 + lane;
+                const int32_t va0 = (int32_t)a0[jl], va1 = (int32_t)a1[jl], vb0 = (int32_t)b0[jl], vb1 = (int32_t)b1[jl];
+                sh.acc.set(u, jl, sh.acc.get(u, jl) + split_finish(0, va0, va1, vb0, vb1, iw1_0, iw1_1));
+                sh.acc.set(u, M + jl, sh.acc.get(u, M + jl) + split_finish(1, va0, va1, vb0, vb1, iw1_0, iw1_1));
+            }
+        }
+        __syncthreads();
+    }
+    extract_sample<LOGN, 512>(p, rd, sh.acc, u_buf, acc_dbg, tid);
+}
+
+// test kernel: the negacyclic product of negacyclic_kernel through split transforms (4 waves: prime, half)
+template <int LOGN>
+__global__ __launch_bounds__(256) void negacyclic_split_kernel(const int32_t *__restrict__ ip, const uint32_t *__restrict__ img,
+                                                               const uint32_t *__restrict__ tw, int32_t *__restrict__ res) {
+    using SUB = WaveNtt<LOGN - 1>;
+    constexpr int N = 1 << LOGN, M = N / 2, RS = SUB::REGS, G4 = RS / 4, HALF = RS / 2;
+    __shared__ __align__(16) uint32_t lds_scr[4][SUB::SCRATCH_WORDS];
+    const int tid = threadIdx.x;
+    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int q = wv & 1, h = wv >> 1;
+    const int lane = tid & 63;
+    const PrimeCtx c = make_sub_ctx(q, h, tw, N);
+    uint32_t *scr = lds_scr[wv];
+    const uint32_t w1 = tw[(size_t)(q * 2 + 0) * N + 1];
+    const uint32_t iw1_0 = tw[(size_t)1 * N + 1], iw1_1 = tw[(size_t)3 * N + 1];
+    const int32_t *src = ip + (size_t)blockIdx.x * N;
+    int32_t x[RS];
+#pragma unroll
+    for (int r = 0; r < RS; ++r) {
+        const int32_t lo = src[r * 64 + lane] % (int32_t)c.P, hi = src[M + r * 64 + lane] % (int32_t)c.P;
+        const int32_t v = mont_mul(hi, w1, c.P, c.pinv);
+        x[r] = lo + (h ? -v : v);                                       // |x| < 2P
+    }
+    SUB::forward(x, c, scr, lane);
+    const int lane_off = G4 * (lane & 1) * 64 + h * 32 + (lane >> 1);
+    const uint4 *bp = reinterpret_cast<const uint4 *>(img + (size_t)(blockIdx.x * 2 + q) * N) + lane_off;
+    int32_t t[RS];
+#pragma unroll
+    for (int g = 0; g < G4; ++g) {
+        const uint4 b = bp[g * 64];
+        t[4 * g + 0] = mont_redc((int64_t)x[4 * g + 0] * (int32_t)b.x, c.P, c.pinv);
+        t[4 * g + 1] = mont_redc((int64_t)x[4 * g + 1] * (int32_t)b.y, c.P, c.pinv);
+        t[4 * g + 2] = mont_redc((int64_t)x[4 * g + 2] * (int32_t)b.z, c.P, c.pinv);
+        t[4 * g + 3] = mont_redc((int64_t)x[4 * g + 3] * (int32_t)b.w, c.P, c.pinv);
+    }
+    SUB::inverse(t, c, scr, lane);
+#pragma unroll
+    for (int r = 0; r < RS; ++r) scr[r * 64 + lane] = (uint32_t)t[r];
+    __syncthreads();
+#pragma unroll
+    for (int r = 0; r < HALF; ++r) {
+        const int jl = (q * HALF + r) * 64 + lane;
+        res[(size_t)blockIdx.x * N + h * M + jl] =
+            (int32_t)split_finish(h, (int32_t)lds_scr[0][jl], (int32_t)lds_scr[2][jl], (int32_t)lds_scr[1][jl],
+                                  (int32_t)lds_scr[3][jl], iw1_0, iw1_1);
+    }
 }
 
 // ---------------------------------------------------------------------------
@@ -1185,13 +1430,29 @@ void launch_blind_rotate(hipStream_t s, const DevParams &p, const DevKey &key, c
         hipLaunchKernelGGL(blind_rotate_kernel<10>, dim3(count), dim3(128), 0, s, p, key, pool, rots, u_buf, acc_dbg);
 }
 
+// the LDS digit tables index by (D >> (shift - 2)) & mask: digits of at most DIGIT_TAB_BITS bits whose
+// lowest field starts at bit 2 or higher
+static bool digit_table_usable(const DevParams &p) {
+    return p.Bgbit <= DIGIT_TAB_BITS && p.digit_table != 0 && 32 - p.l * p.Bgbit >= 2;
+}
+
 void launch_blind_rotate8(hipStream_t s, const DevParams &p, const DevKey &key, const int32_t *pool,
                           const RotDesc *rots, int count, int32_t *u_buf, int32_t *acc_dbg) {
     if (count <= 0) return;
-    if (p.Bgbit <= DIGIT_TAB_BITS && p.digit_table != 0)
+    if (digit_table_usable(p))
         hipLaunchKernelGGL((blind_rotate8_kernel<10, true>), dim3(count), dim3(512), 0, s, p, key, pool, rots, u_buf, acc_dbg);
     else
         hipLaunchKernelGGL((blind_rotate8_kernel<10, false>), dim3(count), dim3(512), 0, s, p, key, pool, rots, u_buf, acc_dbg);
+}
+
+void launch_blind_rotate_split(hipStream_t s, const DevParams &p, const DevKey &key, const int32_t *pool,
+                               const RotDesc *rots, int count, int32_t *u_buf, int32_t *acc_dbg) {
+    if (count <= 0) return;
+#define BRS(LN, TB) hipLaunchKernelGGL((blind_rotate_split_kernel<LN, TB>), dim3(count), dim3(512), 0, s, p, key, pool, rots, u_buf, acc_dbg)
+    const bool tab = digit_table_usable(p);
+    if (p.N == 2048) { if (tab) BRS(11, true); else BRS(11, false); }
+    else { if (tab) BRS(10, true); else BRS(10, false); }
+#undef BRS
 }
 
 #ifdef TFHE_HIP_STAMPS
@@ -1205,7 +1466,7 @@ void launch_blind_rotate4(hipStream_t s, const DevParams &p, const DevKey &key, 
                           const RotDesc *rots, int count, int32_t *u_buf, int32_t *acc_dbg) {
     if (count <= 0) return;
 #define BR4(LN, VV, TB) hipLaunchKernelGGL((blind_rotate4_kernel<LN, VV, TB>), dim3(count), dim3(256), 0, s, p, key, pool, rots, u_buf, acc_dbg)
-    const bool tab = p.Bgbit <= DIGIT_TAB_BITS && p.digit_table != 0;
+    const bool tab = digit_table_usable(p);
     if (p.N == 2048) { if (tab) BR4(11, 0, true); else BR4(11, 0, false); }
     else if (p.br_variant == 1) { if (tab) BR4(10, 1, true); else BR4(10, 1, false); }
     else { if (tab) BR4(10, 0, true); else BR4(10, 0, false); }
@@ -1256,6 +1517,11 @@ void launch_not(hipStream_t s, const DevParams &p, const NotDesc *descs, int cou
 void launch_negacyclic(hipStream_t s, const DevParams &p, const uint32_t *tw, const int32_t *ip,
                        const uint32_t *img, int32_t *res, int count) {
     if (count <= 0) return;
+    if (p.br_variant == 2) {
+        if (p.N == 2048) hipLaunchKernelGGL(negacyclic_split_kernel<11>, dim3(count), dim3(256), 0, s, ip, img, tw, res);
+        else hipLaunchKernelGGL(negacyclic_split_kernel<10>, dim3(count), dim3(256), 0, s, ip, img, tw, res);
+        return;
+    }
     if (p.N == 2048) hipLaunchKernelGGL(negacyclic_kernel<11>, dim3(count), dim3(128), 0, s, ip, img, tw, res);
     else hipLaunchKernelGGL(negacyclic_kernel<10>, dim3(count), dim3(128), 0, s, ip, img, tw, res);
 }

@@ -18,6 +18,7 @@ struct DevParams {
     int32_t fair_shift;     // k > 0: the workgroups sharing a CU take turns at the higher issue priority every 2^k shader cycles
     int32_t digit_table;    // 1 = digit products of the first NTT step from an LDS table where Bgbit allows (kernels.hip)
     int32_t br_variant;     // N = 1024: 0 = wide form (2 workgroups per CU), 1 = lean form (3 per CU); kernels.hip BrTraits
+                            // (2 = split transforms: only read by the negacyclic test launcher)
     uint32_t *cu_arrivals;  // [4096] arrival counters per CU (never reset: only the parity of the arrival order is used)
     unsigned long long *wg_times;   // diagnostic: [2 * grid] s_memtime at workgroup start and end, or null
 };
@@ -28,7 +29,8 @@ struct DevKey {
     const int32_t *ksk;      // [kN][t][base-1][ct_stride]
     const int32_t *ksk_zero; // one more row of ct_stride zeros (digit 0 of the key switch)
     const uint32_t *tw;      // [prime 2][fwd, inv][N] twiddles, Montgomery form, then the radix-4 quads
-                             // [prime 2][fwd, inv][N/2][4] = {w2, w3, w1 w2, P - w1 w3} (ntt_wave.hpp)
+                             // [prime 2][fwd, inv][N/2][4] = {w2, w3, w1 w2, P - w1 w3} (ntt_wave.hpp): 12N words;
+                             // then the same for the two half transforms of the split kernels, 6N words each
 };
 
 // One blind rotation: t = (0, c0) + sa * slot_a + sb * slot_b, then
@@ -72,6 +74,9 @@ void launch_blind_rotate4(hipStream_t s, const DevParams &p, const DevKey &key, 
 // 8-wave form (N = 1024, l >= 2) for launches of at most one workgroup per CU: a second wave per SIMD
 void launch_blind_rotate8(hipStream_t s, const DevParams &p, const DevKey &key, const int32_t *pool,
                           const RotDesc *rots, int count, int32_t *u_buf, int32_t *acc_dbg);
+// split form (8 waves per rotation, every transform as two half-size ones; N = 1024 or 2048)
+void launch_blind_rotate_split(hipStream_t s, const DevParams &p, const DevKey &key, const int32_t *pool,
+                               const RotDesc *rots, int count, int32_t *u_buf, int32_t *acc_dbg);
 // splits > 1: each gate's key switch is cut into `splits` ranges of input coefficients
 // (partial sums in `partial[count][splits][ct_stride]`, then a reduce launch).  tile = 16 or
 // 32: launches of at least 2*tile gates use the tiled kernel (one pass over the KSK rows of

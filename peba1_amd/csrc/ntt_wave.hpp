@@ -163,7 +163,8 @@ constexpr InvPlan make_inv_plan(int logn) {
 static_assert(make_inv_plan(10).nsteps == 5 && make_inv_plan(10).renorm[0] && !make_inv_plan(10).renorm[1] &&
               make_inv_plan(10).renorm[2] && !make_inv_plan(10).renorm[3] && make_inv_plan(10).renorm[4],
               "N=1024 renormalisation schedule");
-static_assert(make_inv_plan(11).nsteps == 7 && make_inv_plan(10).out_bound < 1.0 && make_inv_plan(11).out_bound < 1.0,
+static_assert(make_inv_plan(11).nsteps == 7 && make_inv_plan(10).out_bound < 1.0 && make_inv_plan(11).out_bound < 1.0 &&
+              make_inv_plan(9).nsteps == 6 && make_inv_plan(9).out_bound < 1.0,
               "inverse NTT outputs must end below P");
 
 template <int LOGN>
@@ -173,7 +174,7 @@ struct WaveNtt {
     static constexpr int REGS = 1 << RB;             // coefficients per lane
     static constexpr int LC = LOGN - 2 * RB;         // stages of the last pass
     static constexpr int SCRATCH_WORDS = N + 4 * (64 >> LC);   // rows of REGS words, padded
-    static_assert(LOGN == 10 || LOGN == 11, "wave NTT is laid out for N = 1024 or 2048");
+    static_assert(LOGN >= 9 && LOGN <= 11, "wave NTT is laid out for N = 512 (half of a split 1024-point transform), 1024 or 2048");
 
     // ---- transposes through wave-private LDS scratch ---------------------------
     // row of `lane` in the layout being read: REGS contiguous words

@@ -35,6 +35,40 @@ def test_negacyclic_ntt_exact(p128_keys, oracle):
         assert (got[c] == want).all(), f"poly {c}"
 
 
+@pytest.mark.parametrize("pname", ["P128", "P2048"])
+def test_split_transform_negacyclic_exact(oracle, pname):
+    """a15 through the split transforms of the 8-wave kernel form: stage 0 outside, two half-size
+    transforms on the sub-tree twiddle tables, the key image read in place, the last inverse stage
+    and the CRT after one exchange == schoolbook mod 2^32 (N = 1024 -> two 512-point transforms,
+    N = 2048 -> two 1024-point ones)."""
+    from peba1_amd import api
+    pp = api.ParameterSet(128) if pname == "P128" else api.ParameterSet(p2048=True)
+    ks = api.SecretKeySet(pp, 0x51, device=True)
+    try:
+        rng = np.random.default_rng(11)
+        count, N = 8, pp.N
+        # gadget-digit sized multiplicands (the product must stay inside the two-prime range, ntt_field.hpp)
+        ip = rng.integers(-64, 64, (count, N), dtype=np.int64).astype(np.int32)
+        tp = rng.integers(-2**31, 2**31, (count, N), dtype=np.int64).astype(np.int32)
+        ip[0, :] = -64; tp[0, :] = -2**31
+        ip[1, :] = 63; tp[1, :] = 2**31 - 1
+        ip[2, :] = 0
+        ip[3, :] = 0; ip[3, N - 1] = 1
+        ip[4, :] = 0; ip[4, N // 2] = 1                       # only the upper half: stage 0 alone
+        ip[5, :] = rng.integers(-512, 512, N)                  # the widest digits any accepted set has (Bg = 2^10)
+        ip[6, :] = 0; ip[6, 1] = -512; ip[6, N // 2 + 1] = 511
+        try:
+            api.set_tuning("br_variant", 2)
+            got = api.kernel_negacyclic(ks, ip, tp)
+        finally:
+            api.set_tuning("br_variant", -1)
+        assert (got == api.kernel_negacyclic(ks, ip, tp)).all(), "split and unsplit transforms differ"
+        for c in range(count):
+            assert (got[c] == oracle.negacyclic(ip[c], tp[c], ntt=False)).all(), f"poly {c}"
+    finally:
+        ks.close()
+
+
 def test_blind_rotate_matches_oracle(p128_keys, oracle):
     """a11-a14, a16: modswitch + blind rotate + extract on real ciphertext combinations."""
     from peba1_amd import api
@@ -300,7 +334,7 @@ def test_lean_kernel_form_is_bit_exact(p128_keys, oracle):
             api.set_tuning("br_variant", v)
             got[v] = (api.kernel_bootstrap_woks(ks, lins, want_acc=True), api.kernel_bootstrap_woks(ks, many))
     finally:
-        api.set_tuning("br_variant", 0)
+        api.set_tuning("br_variant", -1)
     for c in range(len(lins)):
         bar = oks.modswitch_ct(lins[c])
         want = oks.blind_rotate(bar[:-1], bar[-1])
@@ -315,7 +349,7 @@ def test_lean_kernel_form_is_bit_exact(p128_keys, oracle):
 @pytest.mark.parametrize("pname", ["P128", "P80", "P2048"])
 def test_every_selectable_kernel_form_is_bit_exact(oracle, pname):
     """Tunings never change results: for every parameter set, every combination of the blind-rotate
-    form ("br_variant"), the digit table of the first NTT step ("br_digit_table"; ignored where the
+    form ("br_variant": wide, lean, split), the digit table of the first NTT step ("br_digit_table"; ignored where the
     gadget digits are wider than 7 bits), the 8-wave form for narrow launches ("br8_max_rotations";
     N = 1024 only) and the 2-wave kernel gives the oracle's accumulator, on gate preludes, on the
     sign-wrap edge inputs, on a 200-wide launch and on one random launch wide enough to share CUs."""
@@ -344,6 +378,7 @@ def test_every_selectable_kernel_form_is_bit_exact(oracle, pname):
         ref_many = None
         # (form, digit table, 4-wave limit, 8-wave limit): the small batch runs the 8-wave form where enabled
         forms = [(v, t, 1 << 30, b8) for v in (0, 1) for t in (1, 0) for b8 in (1 << 30, 0)]
+        forms += [(2, t, 1 << 30, 0) for t in (1, 0)]               # the split form (8 waves, half transforms)
         forms += [(0, 1, 0, 0)] if pp.N == 1024 else []
         try:
             for variant, table, br4_max, br8_max in forms:
@@ -364,7 +399,7 @@ def test_every_selectable_kernel_form_is_bit_exact(oracle, pname):
                 ul = api.kernel_bootstrap_woks(ks, many[:200])           # 200 workgroups: one per CU, the 8-wave form's range
                 assert (ul == ref_many[:200]).all(), (pname, variant, table, br4_max, br8_max, "200-wide")
         finally:
-            api.set_tuning("br_variant", 0)
+            api.set_tuning("br_variant", -1)
             api.set_tuning("br_digit_table", 1)
             api.set_tuning("br4_max_rotations", 1 << 30)
             api.set_tuning("br8_max_rotations", 1 << 30)
