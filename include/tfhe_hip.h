@@ -98,6 +98,13 @@ int tfhe_hip_gate_batch(int gate, LweSample *result, const LweSample *a, const L
  * "br4_max_rotations": launches of at most this many blind rotations use the
  * 4-wave kernel (one wave per prime and input polynomial) instead of the 2-wave
  * kernel (one wave per prime); default 2^30 = always, env TFHE_HIP_BR4_MAX; 0 = never.
+ * "br_variant": which form of the blind-rotate kernel runs (env TFHE_HIP_BR_VARIANT): -1 (default) =
+ * the fastest measured for the ring size (N = 1024: 4 waves per rotation, wide; N = 2048: split),
+ * 0 = 4 waves wide (N = 2048: lean), 1 = 4 waves lean, 2 = split (8 waves, every transform as two
+ * half-size ones).  "br8_max_rotations": launches of at most min(this, CU count) rotations use the
+ * 8-wave form at N = 1024 (default 2^30, env TFHE_HIP_BR8_MAX; 0 = never).  "br_digit_table": 1
+ * (default, env TFHE_HIP_BR_TABLE) = products of gadget digits with the first twiddles come from
+ * LDS tables where the digits are at most 7 bits wide.
  * "ks_target_blocks": a launch's key switches are each cut into 2^s <= 32 ranges of
  * input coefficients until about this many workgroups exist (default 32768, env
  * TFHE_HIP_KS_BLOCKS); 0 disables splitting.

@@ -2,10 +2,10 @@
 # One gpurun call's worth of checks: GPU tests, gate-throughput table, bench line.
 #   gpurun --timeout 1200 -- 'bash tools/gpu_round_check.sh <tag> [tests|fast|none] [variants...]'
 # variants: environment settings (NAME=value, or a bare value of TFHE_HIP_BR_VARIANT) to run the
-# throughput table and the bench with (default "0")
+# throughput table and the bench with (default "-1": the library's own choice of kernel forms)
 set -o pipefail
 TAG=${1:-r2x}; WHAT=${2:-tests}; shift; shift
-VARIANTS=${@:-0}
+VARIANTS=${@:--1}
 OUT=gpurun_out/$TAG; mkdir -p $OUT
 export TMPDIR=/tmp
 rc=0
