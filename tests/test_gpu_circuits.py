@@ -141,14 +141,16 @@ def test_sharded_match_over_rccl_world1(p128_keys):
 
 @pytest.mark.parametrize("fixture,circuit,lanes", [("function_f_digest.json", "function_f", 1),
                                                    ("function_f_fast_digest.json", "function_f_fast", 1),
-                                                   ("function_f_digest.json", "function_f", 2)])
+                                                   ("function_f_digest.json", "function_f", 2),
+                                                   ("function_f_p2048_digest.json", "function_f", 1)])
 def test_function_f_ciphertexts_match_oracle_digest(p128_keys, fixture, circuit, lanes):
     """Whole-circuit ciphertext parity: a complete 2-slot Function_f (3,438 bootstrapped gates,
     incl. 24 XNOR + 48 MUX) on the GPU reproduces, bit for bit, the SHA-256 of the 24 output
     ciphertexts that the CPU oracle produced through the same circuit library
     (tests/golden/make_function_f_digest.py, ~10 CPU-minutes).  Same for the optimised DAG
     (542 blind rotations incl. ANDNY/ANDYN and MUX full adders), and for the experimental
-    two-lane execution (urgent gates and the rest on two streams)."""
+    two-lane execution (urgent gates and the rest on two streams), and for the same circuit under the
+    N = 2048 parameter set of BASELINE configs[4] (the split kernel form; oracle: ~35 CPU-minutes)."""
     import hashlib
     import json
     from types import SimpleNamespace
@@ -158,6 +160,10 @@ def test_function_f_ciphertexts_match_oracle_digest(p128_keys, fixture, circuit,
     with open(os.path.join(root, "tests", "golden", fixture)) as f:
         g = json.load(f)
     assert g["key_seed"] == 0x5EBA2                      # the session keyset of conftest.py
+    own_keys = None
+    if g["params"] == "P2048":
+        pp = api.ParameterSet(p2048=True)
+        own_keys = ks = api.SecretKeySet(pp, g["key_seed"], device=True)
     L = lib.load()
     L.tfhe_hip_set_encrypt_seed(g["encrypt_seed"])
     bits = g["bits"]
@@ -184,9 +190,13 @@ def test_function_f_ciphertexts_match_oracle_digest(p128_keys, fixture, circuit,
     # the recorder shares the result of a gate recorded twice with the same operands (reuse_gates)
     assert st["blind_rotates"] <= g["blind_rotates"] <= st["blind_rotates"] + 2 * st["reused_gates"]
     words = rb.words()
-    assert hashlib.sha256(words[0].tobytes()).hexdigest() == g["result_b0_sha256"]
-    assert hashlib.sha256(words.tobytes()).hexdigest() == g["result_b_sha256"]
-    assert rb.decrypt(ks)[0] == g["match_bit"]
+    try:
+        assert hashlib.sha256(words[0].tobytes()).hexdigest() == g["result_b0_sha256"]
+        assert hashlib.sha256(words.tobytes()).hexdigest() == g["result_b_sha256"]
+        assert rb.decrypt(ks)[0] == g["match_bit"]
+    finally:
+        if own_keys is not None:
+            own_keys.close()
 
 
 def test_gate_reuse_is_transparent(p128_keys):
