@@ -104,7 +104,7 @@ int tfhe_hip_gate_batch(int gate, LweSample *result, const LweSample *a, const L
  * half-size ones).  "br8_max_rotations": launches of at most min(this, CU count) rotations use the
  * 8-wave form at N = 1024 (default 2^30, env TFHE_HIP_BR8_MAX; 0 = never).  "br_digit_table": 1
  * (default, env TFHE_HIP_BR_TABLE) = products of gadget digits with the first twiddles come from
- * LDS tables where the digits are at most 7 bits wide.
+ * LDS tables where the digits are at most 7 bits wide (split form: 2 = the stage-0 table only).
  * "ks_target_blocks": a launch's key switches are each cut into 2^s <= 32 ranges of
  * input coefficients until about this many workgroups exist (default 32768, env
  * TFHE_HIP_KS_BLOCKS); 0 disables splitting.

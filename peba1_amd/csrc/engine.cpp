@@ -102,7 +102,7 @@ void Engine::ensure_init() {
     if (const char *env = std::getenv("TFHE_HIP_BR_FAIR")) br_fair = std::atoi(env);
     if (const char *env = std::getenv("TFHE_HIP_BR8_MAX")) br8_max_rotations = std::atoi(env);
     if (const char *env = std::getenv("TFHE_HIP_BR_VARIANT")) br_variant = std::atoi(env);
-    if (const char *env = std::getenv("TFHE_HIP_BR_TABLE")) br_digit_table = std::atoi(env) != 0;
+    if (const char *env = std::getenv("TFHE_HIP_BR_TABLE")) br_digit_table = std::atoi(env);
     for (auto &e : ev_) hip_check(hipEventCreate(&e), "hipEventCreate");
     inited_ = true;
 }

@@ -137,7 +137,8 @@ public:
     // of the kernel, N = 1024 only; 0 = never (env TFHE_HIP_BR8_MAX, tuning "br8_max_rotations")
     int br8_max_rotations = 1 << 30;
     // 1 = the first radix-4 step of the forward transforms looks digit products up in LDS (gadget digits
-    // of at most 7 bits); 0 = multiplies (env TFHE_HIP_BR_TABLE, tuning "br_digit_table")
+    // of at most 7 bits; split form: stage 0, and the first radix-4 step too where digits have at most 6
+    // bits); 2 = split form: stage 0 only; 0 = multiplies (env TFHE_HIP_BR_TABLE, tuning "br_digit_table")
     int br_digit_table = 1;
     // stream == nullptr: the engine's stream; lane selects the scratch buffer of the partial sums
     void launch_ks(const DeviceKeyImage *key, const int32_t *u_buf, const KsDesc *descs, int count, int32_t *pool,

@@ -763,7 +763,17 @@ __global__ __launch_bounds__(512, 2) void blind_rotate8_kernel(
 // one table read and one addition per coefficient and gadget row), D is computed by both halves,
 // 8 waves meet at each barrier.  Same integers as the other forms.
 // ---------------------------------------------------------------------------
-template <int LOGN>
+// Digit tables of the split form (TM = table mode).  Stage 0 and the first radix-4 step of a half transform
+// multiply gadget digits by constants only (stage 0 has one twiddle, the step's stages one block each):
+//   TM = 1: stage 0 from a table, [prime][h][2^Bgbit] words (+/- W[1] d);
+//   TM = 2: stage 0 AND the first radix-4 step from eleven tables: with x_i = lo_i +/- W[1] hi_i the step's
+//           A = w1 x2, S = w2 x1 + w1w2 x3, S' = w3 x1 - w1w3 x3 are sums of two or four products digit x
+//           constant -- 11 reads and 14 additions per group of four outputs instead of 4 reads, 11
+//           multiplier-class instructions and 10 additions.  Entries are centred (|.| <= P/2) so that the
+//           sums of up to seven of them stay small: below 3.5P + 2^11 after the step, 9.7P after the transform.
+//           Digits of at most SPLIT_TAB2_BITS bits (the N = 2048 set: 11 KB of tables).
+constexpr int SPLIT_TAB2_BITS = 6;
+template <int LOGN, int TM>
 struct BrSplitLds {
     using SUB = WaveNtt<LOGN - 1>;
     AccLds<LOGN, 3> acc;
@@ -771,7 +781,7 @@ struct BrSplitLds {
                                                    // step's last barrier: its outputs (natural order), read by 3 waves
     uint32_t x1[8][SUB::SCRATCH_WORDS];            // partial sums sent to the wave of the other input polynomial
     uint16_t bar[1024 + 8];
-    uint32_t tab0[2][2][DIGIT_TAB];                // [prime][h]: (+/-) W[1] * digit, signed residues
+    uint32_t tab[2][2][TM == 2 ? 11 << SPLIT_TAB2_BITS : DIGIT_TAB];     // [prime][h][table][digit field]
 };
 
 // representative in (-2P, 2P) -> canonical
@@ -793,13 +803,14 @@ __device__ __forceinline__ uint32_t split_finish(int h, int32_t a0, int32_t a1, 
     return crt_to_torus(y0, y1);
 }
 
-template <int LOGN, bool TAB>
+template <int LOGN, int TM>
 __global__ __launch_bounds__(512, (LOGN == 10 ? 4 : 2)) void blind_rotate_split_kernel(
     DevParams p, DevKey key, const int32_t *__restrict__ pool, const RotDesc *__restrict__ rots,
     int32_t *__restrict__ u_buf, int32_t *__restrict__ acc_dbg) {
     using SUB = WaveNtt<LOGN - 1>;
     constexpr int N = 1 << LOGN, M = N / 2, RS = SUB::REGS, RF = 2 * RS, G4 = RS / 4, QUARTER = RS / 4;
-    __shared__ __align__(16) BrSplitLds<LOGN> sh;
+    __shared__ __align__(16) BrSplitLds<LOGN, TM> sh;
+    constexpr bool TAB = TM == 1;
     const int tid = threadIdx.x;
     const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int q = wv & 1, u = (wv >> 1) & 1, h = wv >> 2;
@@ -819,7 +830,25 @@ __global__ __launch_bounds__(512, (LOGN == 10 ? 4 : 2)) void blind_rotate_split_
         for (int f = (u << 6) | lane; f < fields; f += 128) {
             const int32_t d = f < fields / 2 ? f : f - fields;
             const int32_t v = mont_mul(d, w1, c.P, c.pinv);
-            sh.tab0[q][h][f] = (uint32_t)(h ? -v : v);
+            sh.tab[q][h][f] = (uint32_t)(h ? -v : v);
+        }
+    }
+    if constexpr (TM == 2) {
+        // table k of (q, h), entry f: digit(f) * [W[1] * (+1 | -1 for h = 1)] * constant_k, centred
+        const uint4 qd = c.qf[1];                            // {w2, w3, w1 w2, P - w1 w3} of the half transform's first step
+        const uint32_t cst[6] = {0u, c.wf[1], qd.x, qd.z, qd.y, qd.w};          // k = 0 | 1,2 | 3,4 | 5,6 | 7,8 | 9,10
+        const int fields = 1 << p.Bgbit;
+        for (int e = (u << 6) | lane; e < 11 * fields; e += 128) {
+            const int k = e / fields, f = e - k * fields;
+            const int32_t d = f < fields / 2 ? f : f - fields;
+            const bool hi = k == 0 || (k & 1) == 0;          // tables of the upper-half digits carry +/- W[1]
+            int32_t v = d;
+            if (hi) { v = mont_mul(v, w1, c.P, c.pinv); if (h) v = -v; }
+            if (k > 0) v = mont_mul(v, cst[(k + 1) >> 1], c.P, c.pinv);
+            const int32_t half = (int32_t)(c.P >> 1);
+            if (v > half) v -= (int32_t)c.P;
+            if (v < -half) v += (int32_t)c.P;
+            sh.tab[q][h][(k << SPLIT_TAB2_BITS) + f] = (uint32_t)v;
         }
     }
     __syncthreads();
@@ -857,10 +886,32 @@ __global__ __launch_bounds__(512, (LOGN == 10 ? 4 : 2)) void blind_rotate_split_
             t0.load(c, lane);
             const int shift = 32 - (jj + 1) * width;
             int32_t x[RS];
-            if constexpr (TAB) {
+            if constexpr (TM == 2) {
+                constexpr int RBIT = SUB::rbit_of(0), hb = 1 << RBIT, lb = hb >> 1;
                 const uint32_t mask4 = ((1u << width) - 1u) << 2;
                 const int sh2 = shift - 2;
-                const char *tab = reinterpret_cast<const char *>(sh.tab0[q][h]);
+                const char *tab = reinterpret_cast<const char *>(sh.tab[q][h]);
+                auto entry = [&](int k, uint32_t off) {
+                    return (int32_t)*reinterpret_cast<const uint32_t *>(tab + (k << (SPLIT_TAB2_BITS + 2)) + off);
+                };
+                auto field = [&](int i) { return (D[i] >> sh2) & mask4; };
+#pragma unroll
+                for (int r = 0; r < RS; ++r)
+                    if (!(r & (hb | lb))) {
+                        const uint32_t l1 = field(r | lb), l2 = field(r | hb), l3 = field(r | hb | lb);
+                        const uint32_t h0 = field(RS + r), h1 = field(RS + (r | lb)), h2 = field(RS + (r | hb)),
+                                       h3 = field(RS + (r | hb | lb));
+                        const int32_t x0 = __builtin_amdgcn_sbfe((int32_t)D[r], shift, width) + entry(0, h0);
+                        const int32_t A = entry(1, l2) + entry(2, h2);
+                        const int32_t S = (entry(3, l1) + entry(4, h1)) + (entry(5, l3) + entry(6, h3));
+                        const int32_t T = (entry(7, l1) + entry(8, h1)) + (entry(9, l3) + entry(10, h3));
+                        const int32_t uu = x0 + A, vv = x0 - A;
+                        x[r] = uu + S; x[r | lb] = uu - S; x[r | hb] = vv + T; x[r | hb | lb] = vv - T;
+                    }
+            } else if constexpr (TAB) {
+                const uint32_t mask4 = ((1u << width) - 1u) << 2;
+                const int sh2 = shift - 2;
+                const char *tab = reinterpret_cast<const char *>(sh.tab[q][h]);
 #pragma unroll
                 for (int r = 0; r < RS; ++r)
                     x[r] = __builtin_amdgcn_sbfe((int32_t)D[r], shift, width) +
@@ -872,7 +923,8 @@ __global__ __launch_bounds__(512, (LOGN == 10 ? 4 : 2)) void blind_rotate_split_
                     x[r] = __builtin_amdgcn_sbfe((int32_t)D[r], shift, width) + (h ? -v : v);
                 }
             }
-            SUB::template forward<true>(x, c, scr, lane, t0);         // |x| < P + 2^11 in, < 8.3P out
+            if constexpr (TM == 2) SUB::template forward_rest<true>(x, c, scr, lane, t0);     // < 3.5P + 2^11 in, < 9.7P out
+            else SUB::template forward<true>(x, c, scr, lane, t0);    // |x| < P + 2^11 in, < 8.3P out
 #pragma unroll
             for (int g = 0; g < G4; ++g) {
                 const int32_t bb0[4] = {(int32_t)b0[g].x, (int32_t)b0[g].y, (int32_t)b0[g].z, (int32_t)b0[g].w};
@@ -901,7 +953,7 @@ __global__ __launch_bounds__(512, (LOGN == 10 ? 4 : 2)) void blind_rotate_split_
             int32_t send[RS];
 #pragma unroll
             for (int r = 0; r < RS; ++r) {
-                t[r] = mont_redc(acc0[r], c.P, c.pinv);              // l <= 4 rows of |x| < 8.3P: |.| < 1.6P
+                t[r] = mont_redc(acc0[r], c.P, c.pinv);              // l <= 4 rows of |x| < 9.7P: |.| < 1.8P
                 send[r] = mont_redc(acc1[r], c.P, c.pinv);
             }
             SUB::write_row(send, sh.x1[wv], lane);
@@ -911,7 +963,7 @@ __global__ __launch_bounds__(512, (LOGN == 10 ? 4 : 2)) void blind_rotate_split_
             int32_t other[RS];
             SUB::read_row(other, sh.x1[wv ^ 2], lane);
 #pragma unroll
-            for (int r = 0; r < RS; ++r) t[r] += other[r];          // |.| < 3.2P (the inverse takes < 4P)
+            for (int r = 0; r < RS; ++r) t[r] += other[r];          // |.| < 3.6P (the inverse takes < 4P)
         }
         SUB::template inverse<true>(t, c, scr, lane);
 #pragma unroll
@@ -1450,10 +1502,17 @@ void launch_blind_rotate8(hipStream_t s, const DevParams &p, const DevKey &key, 
 void launch_blind_rotate_split(hipStream_t s, const DevParams &p, const DevKey &key, const int32_t *pool,
                                const RotDesc *rots, int count, int32_t *u_buf, int32_t *acc_dbg) {
     if (count <= 0) return;
-#define BRS(LN, TB) hipLaunchKernelGGL((blind_rotate_split_kernel<LN, TB>), dim3(count), dim3(512), 0, s, p, key, pool, rots, u_buf, acc_dbg)
+#define BRS(LN, TM) hipLaunchKernelGGL((blind_rotate_split_kernel<LN, TM>), dim3(count), dim3(512), 0, s, p, key, pool, rots, u_buf, acc_dbg)
+    // table mode: digit_table 1 = the widest the digits and the LDS budget allow (N = 2048: stage 0 and the first
+    // radix-4 step for digits of at most 6 bits), 2 = stage 0 only, 0 = none
     const bool tab = digit_table_usable(p);
-    if (p.N == 2048) { if (tab) BRS(11, true); else BRS(11, false); }
-    else { if (tab) BRS(10, true); else BRS(10, false); }
+    if (p.N == 2048) {
+        if (tab && p.digit_table == 1 && p.Bgbit <= SPLIT_TAB2_BITS) BRS(11, 2);
+        else if (tab) BRS(11, 1);
+        else BRS(11, 0);
+    } else {
+        if (tab) BRS(10, 1); else BRS(10, 0);
+    }
 #undef BRS
 }
 

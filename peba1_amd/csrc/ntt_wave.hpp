@@ -382,26 +382,34 @@ struct WaveNtt {
                     const int32_t u = x0 + A, v = x0 - A;
                     x[r] = u + S; x[r | l] = u - S; x[r | h] = v + T; x[r | h | l] = v - T;
                 }
-            if constexpr (RB > 2) fwd_pass(x, c, t0.rest);               // the other steps of the first pass
-            FwdTw1 t1;
-            if constexpr (EARLY) t1.load(c, lane);
-#pragma unroll
-            for (int r = 0; r < REGS; ++r) scr[t1_l0_addr(lane, r)] = (uint32_t)x[r];
-            wave_lds_fence();
-            read_row(x, scr, lane);
-            wave_lds_fence();
-            if constexpr (!EARLY) t1.load(c, lane);
-            fwd_pass(x, c, t1);
-            FwdTw2 t2;
-            if constexpr (EARLY) t2.load(c, lane);
-#pragma unroll
-            for (int r = 0; r < REGS; ++r) scr[t2_l1_addr(lane, r)] = (uint32_t)x[r];
-            wave_lds_fence();
-            read_row(x, scr, lane);
-            wave_lds_fence();
-            if constexpr (!EARLY) t2.load(c, lane);
-            fwd_pass(x, c, t2);
+            forward_rest<EARLY>(x, c, scr, lane, t0);
         }
+    }
+    // everything after the first radix-4 step of a forward transform (for callers that produce that
+    // step's outputs themselves, from tables)
+    template <bool EARLY>
+    static __device__ __forceinline__ void forward_rest(int32_t (&x)[REGS], const PrimeCtx &c, uint32_t *scr, int lane,
+                                                        const FwdTw0 &t0) {
+        static_assert(FwdTw0::PAIR, "the first step is a radix-4 step");
+        if constexpr (RB > 2) fwd_pass(x, c, t0.rest);               // the other steps of the first pass
+        FwdTw1 t1;
+        if constexpr (EARLY) t1.load(c, lane);
+#pragma unroll
+        for (int r = 0; r < REGS; ++r) scr[t1_l0_addr(lane, r)] = (uint32_t)x[r];
+        wave_lds_fence();
+        read_row(x, scr, lane);
+        wave_lds_fence();
+        if constexpr (!EARLY) t1.load(c, lane);
+        fwd_pass(x, c, t1);
+        FwdTw2 t2;
+        if constexpr (EARLY) t2.load(c, lane);
+#pragma unroll
+        for (int r = 0; r < REGS; ++r) scr[t2_l1_addr(lane, r)] = (uint32_t)x[r];
+        wave_lds_fence();
+        read_row(x, scr, lane);
+        wave_lds_fence();
+        if constexpr (!EARLY) t2.load(c, lane);
+        fwd_pass(x, c, t2);
     }
     // fills this prime's digit table for digits of `width` bits (threads tid, tid + nthreads, ... of
     // the workgroup); entry f of a row is for the digit whose two's-complement bit field is f

@@ -378,7 +378,9 @@ def test_every_selectable_kernel_form_is_bit_exact(oracle, pname):
         ref_many = None
         # (form, digit table, 4-wave limit, 8-wave limit): the small batch runs the 8-wave form where enabled
         forms = [(v, t, 1 << 30, b8) for v in (0, 1) for t in (1, 0) for b8 in (1 << 30, 0)]
-        forms += [(2, t, 1 << 30, 0) for t in (1, 0)]               # the split form (8 waves, half transforms)
+        # the split form (8 waves, half transforms); table 1 = the most the set allows (stage 0 and the first
+        # radix-4 step at Bgbit <= 6), 2 = stage 0 only, 0 = none
+        forms += [(2, t, 1 << 30, 0) for t in (1, 2, 0)]
         forms += [(0, 1, 0, 0)] if pp.N == 1024 else []
         try:
             for variant, table, br4_max, br8_max in forms:
