@@ -164,9 +164,11 @@ int tfhe_hip_test_assign_lanes(const int32_t *ops5, int32_t count, int32_t unit,
 /* Diagnostic (tools/lane_probe.py): `levels` rounds of (blind rotate + key switch) over `width`
  * random gates, issued as `lanes` independent chains on `lanes` HIP streams; returns the wall
  * time in ms (negative on error).  Measures what overlapping level-synchronous chains could gain. */
-/* Diagnostic: one blind-rotate launch of `width` random gates; times2[2i], times2[2i+1] = the
- * shader clock (s_memtime, 100 MHz) at the start and end of workgroup i. */
-int tfhe_hip_test_wg_times(const TFheGateBootstrappingCloudKeySet *bk, int32_t width, uint64_t *times2);
+/* Diagnostic: a blind-rotate launch of `width` random gates (the second of two back to back);
+ * times4[4i .. 4i+3] = s_memtime (shader cycles; the start stamp carries the XCC / CU id in its top 16
+ * bits) at the start and end of workgroup i, then s_memrealtime (constant 100 MHz) at its start and
+ * end; *launch_ms = the launch's duration between two stream events. */
+int tfhe_hip_test_wg_times(const TFheGateBootstrappingCloudKeySet *bk, int32_t width, uint64_t *times4, double *launch_ms);
 double tfhe_hip_test_lane_probe(const TFheGateBootstrappingCloudKeySet *bk, int32_t lanes, int32_t levels, int32_t width);
 
 /* ---- kernel-level entry points (K2/K3 parity tests against the oracle) ---- */

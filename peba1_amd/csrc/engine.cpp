@@ -457,7 +457,7 @@ void Engine::execute(const DeviceKeyImage *key, SlotPool *pool, const LevelPlan 
         }
         return timing_events_[nt++];
     };
-    struct Timed { hipEvent_t e0, e1, e2; bool wide8; };
+    struct Timed { hipEvent_t e0, e1, e2; bool wide8; int nrot; };
     std::vector<Timed> timed;
     hipEvent_t base = nullptr;
     if (kernel_timing) {
@@ -484,7 +484,7 @@ void Engine::execute(const DeviceKeyImage *key, SlotPool *pool, const LevelPlan 
                     waited[s][o] = w;
                 }
             }
-            Timed t{nullptr, nullptr, nullptr, false};
+            Timed t{nullptr, nullptr, nullptr, false, nrot};
             if (kernel_timing) { t.e0 = timing_event(); hip_check(hipEventRecord(t.e0, st), "event"); }
             if (nrot) {
                 t.wide8 = launch_br(key, pool->data(), drots + plan.rot_off[gg], nrot, u_buf[s], nullptr, st, K > 1 && s == 0 ? lane_prio : 0);
@@ -520,11 +520,16 @@ void Engine::execute(const DeviceKeyImage *key, SlotPool *pool, const LevelPlan 
         // durations per launch, and the union of the blind-rotate intervals (two lanes overlap)
         std::vector<std::pair<float, float>> br;
         br.reserve(timed.size());
+        // diagnostic: start, blind-rotate and key-switch time of every level (TFHE_HIP_TRACE_TIMES = file)
+        FILE *tf = nullptr;
+        if (const char *trace = std::getenv("TFHE_HIP_TRACE_TIMES")) tf = std::fopen(trace, "a");
+        if (tf) std::fprintf(tf, "flush levels=%d\n", levels);
         for (const Timed &t : timed) {
             float a = 0, b = 0, c = 0;
             hip_check(hipEventElapsedTime(&a, base, t.e0), "elapsed");
             hip_check(hipEventElapsedTime(&b, base, t.e1), "elapsed");
             hip_check(hipEventElapsedTime(&c, base, t.e2), "elapsed");
+            if (tf) std::fprintf(tf, "%d %.4f %.4f %.4f %d\n", t.nrot, a, b - a, c - b, t.wide8 ? 1 : 0);
             stats.ms_blind_rotate += b - a;
             if (t.wide8) stats.ms_blind_rotate8 += b - a;
             stats.ms_keyswitch += c - b;
@@ -541,6 +546,7 @@ void Engine::execute(const DeviceKeyImage *key, SlotPool *pool, const LevelPlan 
             }
         }
         if (cur_b >= cur_a) stats.ms_blind_rotate_busy += cur_b - cur_a;
+        if (tf) std::fclose(tf);
     }
     stats.levels += (uint64_t)levels;
     ++stats.flushes;
@@ -677,15 +683,32 @@ double Engine::run_lane_probe(const DeviceKeyImage *key, int lanes, int levels, 
     }
     unsigned long long *dtimes = nullptr;
     if (wg_times) {                                      // one launch, per-workgroup start/end stamps
-        dtimes = static_cast<unsigned long long *>(scratch(43, (size_t)2 * width * 8));
+        dtimes = static_cast<unsigned long long *>(scratch(43, (size_t)4 * width * 8));
+        hipEvent_t e0, e1;
+        hip_check(hipEventCreate(&e0), "probe event");
+        hip_check(hipEventCreate(&e1), "probe event");
+        // launches back to back, the last one stamped and timed: what a level of a circuit sees
+        // (TFHE_HIP_PROBE_WARM = "count:width[:ks]" changes the unstamped launches before it, default one of
+        // the same width; ks = 1 puts a key-switch launch of that width after each of them, as a circuit does)
+        int warm_count = 1, warm_width = width, warm_ks = 0;
+        if (const char *env = std::getenv("TFHE_HIP_PROBE_WARM")) std::sscanf(env, "%d:%d:%d", &warm_count, &warm_width, &warm_ks);
+        warm_width = std::max(1, std::min(warm_width, width));
+        for (int w = 0; w < warm_count; ++w) {
+            launch_br(key, pool, drots, warm_width, ubuf[0], nullptr, st[0]);
+            if (warm_ks) launch_ks(key, ubuf[0], dks, warm_width, pool, st[0], 0);
+        }
         wg_times_dbg_ = dtimes;
-        hip_check(hipDeviceSynchronize(), "probe sync");
+        hip_check(hipEventRecord(e0, st[0]), "probe event record");
         launch_br(key, pool, drots, width, ubuf[0], nullptr, st[0]);
+        hip_check(hipEventRecord(e1, st[0]), "probe event record");
         hip_check(hipStreamSynchronize(st[0]), "probe stamps");
         wg_times_dbg_ = nullptr;
-        hip_check(hipMemcpy(wg_times, dtimes, (size_t)2 * width * 8, hipMemcpyDeviceToHost), "probe stamps copy");
+        float ems = 0.f;
+        hip_check(hipEventElapsedTime(&ems, e0, e1), "probe event time");
+        (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
+        hip_check(hipMemcpy(wg_times, dtimes, (size_t)4 * width * 8, hipMemcpyDeviceToHost), "probe stamps copy");
         for (int s = 0; s < lanes; ++s) hip_check(hipStreamDestroy(st[s]), "probe stream destroy");
-        return 0.0;
+        return (double)ems;
     }
     hip_check(hipDeviceSynchronize(), "probe sync");
     const auto t0 = std::chrono::steady_clock::now();

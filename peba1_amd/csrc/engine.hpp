@@ -149,7 +149,7 @@ public:
     // diagnostic (tools/lane_probe.py): `levels` rounds of (blind rotate + key switch) of `width`
     // random gates in total, issued as `lanes` independent chains on `lanes` streams; returns ms
     // wg_times != nullptr: instead, ONE blind-rotate launch of `width` gates whose workgroups stamp
-    // s_memtime at start and end into wg_times[2 * width]
+    // s_memtime and s_memrealtime at start and end into wg_times[4 * width]; returns that launch's event time
     double run_lane_probe(const DeviceKeyImage *key, int lanes, int levels, int width, unsigned long long *wg_times = nullptr);
 
 private:

@@ -606,13 +606,17 @@ __global__ __launch_bounds__(256, (BrTraits<LOGN, V>::WAVES_PER_SIMD)) void blin
         // low 48 bits: shader clock; high 16 bits: XCC id and the CU / SH / SE fields of HW_ID
         const uint64_t hw = __builtin_amdgcn_s_getreg((31 << 11) | (0 << 6) | 4);
         const uint64_t xcc = __builtin_amdgcn_s_getreg((3 << 11) | (0 << 6) | 20);
-        p.wg_times[2 * blockIdx.x] = (__builtin_amdgcn_s_memtime() & 0xFFFFFFFFFFFFull) |
+        p.wg_times[4 * blockIdx.x] = (__builtin_amdgcn_s_memtime() & 0xFFFFFFFFFFFFull) |
                                      ((((xcc & 0xF) << 8) | ((hw >> 8) & 0xFF)) << 48);
+        p.wg_times[4 * blockIdx.x + 2] = __builtin_amdgcn_s_memrealtime();       // constant 100 MHz
     }
     const RotDesc rd = rots[blockIdx.x];
     blind_rotate4_body<LOGN, V, TAB>(p, key, pool, rd, sh, threadIdx.x, parity);
     extract_sample<LOGN, 256>(p, rd, sh.acc, u_buf, acc_dbg, threadIdx.x);
-    if (p.wg_times && threadIdx.x == 0) p.wg_times[2 * blockIdx.x + 1] = __builtin_amdgcn_s_memtime();
+    if (p.wg_times && threadIdx.x == 0) {
+        p.wg_times[4 * blockIdx.x + 1] = __builtin_amdgcn_s_memtime();
+        p.wg_times[4 * blockIdx.x + 3] = __builtin_amdgcn_s_memrealtime();
+    }
 }
 
 // ---------------------------------------------------------------------------

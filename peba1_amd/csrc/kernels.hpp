@@ -20,7 +20,8 @@ struct DevParams {
     int32_t br_variant;     // N = 1024: 0 = wide form (2 workgroups per CU), 1 = lean form (3 per CU); kernels.hip BrTraits
                             // (2 = split transforms: only read by the negacyclic test launcher)
     uint32_t *cu_arrivals;  // [4096] arrival counters per CU (never reset: only the parity of the arrival order is used)
-    unsigned long long *wg_times;   // diagnostic: [2 * grid] s_memtime at workgroup start and end, or null
+    unsigned long long *wg_times;   // diagnostic: [4 * grid] s_memtime (shader cycles) at workgroup start and end, then
+                                    // s_memrealtime (100 MHz) at start and end; or null
 };
 
 // Device-resident evaluation key.

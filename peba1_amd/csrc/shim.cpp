@@ -952,11 +952,12 @@ double tfhe_hip_test_lane_probe(const TFheGateBootstrappingCloudKeySet *bk, int3
     return Engine::get().run_lane_probe(bk->bk->dev, lanes, levels, width);
 }
 
-int tfhe_hip_test_wg_times(const TFheGateBootstrappingCloudKeySet *bk, int32_t width, uint64_t *times2) {
-    if (!bk || !bk->bk || !times2 || width <= 0) { set_error("wg_times: bad arguments"); return -1; }
+int tfhe_hip_test_wg_times(const TFheGateBootstrappingCloudKeySet *bk, int32_t width, uint64_t *times4, double *launch_ms) {
+    if (!bk || !bk->bk || !times4 || width <= 0) { set_error("wg_times: bad arguments"); return -1; }
     std::lock_guard<std::recursive_mutex> g(rec().mtx);
     pool_of_key(bk);
-    Engine::get().run_lane_probe(bk->bk->dev, 1, 1, width, reinterpret_cast<unsigned long long *>(times2));
+    const double ms = Engine::get().run_lane_probe(bk->bk->dev, 1, 1, width, reinterpret_cast<unsigned long long *>(times4));
+    if (launch_ms) *launch_ms = ms;
     return 0;
 }
 

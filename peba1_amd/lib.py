@@ -89,7 +89,7 @@ SIGNATURES = {
     "export_gate_bootstrapping_ciphertext_toFile": (None, [C.c_void_p, LS, PS]),
     "import_gate_bootstrapping_ciphertext_fromFile": (None, [C.c_void_p, LS, PS]),
     "tfhe_hip_test_assign_lanes": (C.c_int, [I32P, C.c_int32, C.c_int32, C.c_int32, I32P]),
-    "tfhe_hip_test_wg_times": (C.c_int, [CK, C.c_int32, C.POINTER(C.c_uint64)]),
+    "tfhe_hip_test_wg_times": (C.c_int, [CK, C.c_int32, C.POINTER(C.c_uint64), C.POINTER(C.c_double)]),
     "tfhe_hip_test_lane_probe": (C.c_double, [CK, C.c_int32, C.c_int32, C.c_int32]),
     "tfhe_hip_last_error": (C.c_char_p, []),
     "tfhe_hip_clear_error": (None, []),

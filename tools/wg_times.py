@@ -15,9 +15,9 @@ ks = api.SecretKeySet(pp, 0x5EBA2)
 CLK = 2320.0      # s_memtime ticks per microsecond on this part (shader clock); counters are per XCD
 for width in (256, 512, 1024, 2048):
     for rep in range(2):
-        t = np.zeros(2 * width, dtype=np.uint64)
-        assert L.tfhe_hip_test_wg_times(ks.cloud, width, t.ctypes.data_as(C.POINTER(C.c_uint64))) == 0
-    t = t.reshape(width, 2)
+        t = np.zeros(4 * width, dtype=np.uint64)
+        assert L.tfhe_hip_test_wg_times(ks.cloud, width, t.ctypes.data_as(C.POINTER(C.c_uint64)), None) == 0
+    t = t.reshape(width, 4)
     cu = (t[:, 0] >> np.uint64(48)).astype(np.int64)
     xcc = cu >> 8
     start = (t[:, 0] & np.uint64(0xFFFFFFFFFFFF)).astype(np.int64)
