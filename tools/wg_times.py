@@ -1,5 +1,7 @@
 """Where does a blind-rotate launch spend its time?  Per-workgroup start and end stamps
-(s_memtime, 100 MHz) of one launch: dispatch ramp, spread of the run times, tail."""
+(s_memrealtime, constant 100 MHz) of one launch: dispatch ramp, spread of the run times, tail.
+The launch is the second of two back to back, so it runs at a half-warm shader clock
+(tools/diag/launch_clock.py); the cycle stamps next to the time stamps give that clock."""
 import ctypes as C
 import os
 import sys
@@ -12,7 +14,7 @@ from peba1_amd import api, lib  # noqa: E402
 L = lib.load()
 pp = api.ParameterSet(128)
 ks = api.SecretKeySet(pp, 0x5EBA2)
-CLK = 2320.0      # s_memtime ticks per microsecond on this part (shader clock); counters are per XCD
+CLK = 100.0       # s_memrealtime ticks per microsecond
 for width in (256, 512, 1024, 2048):
     for rep in range(2):
         t = np.zeros(4 * width, dtype=np.uint64)
@@ -20,8 +22,9 @@ for width in (256, 512, 1024, 2048):
     t = t.reshape(width, 4)
     cu = (t[:, 0] >> np.uint64(48)).astype(np.int64)
     xcc = cu >> 8
-    start = (t[:, 0] & np.uint64(0xFFFFFFFFFFFF)).astype(np.int64)
-    end = (t[:, 1] & np.uint64(0xFFFFFFFFFFFF)).astype(np.int64)
+    start = t[:, 2].astype(np.int64)
+    end = t[:, 3].astype(np.int64)
+    cycles = (t[:, 1] & np.uint64(0xFFFFFFFFFFFF)).astype(np.int64) - (t[:, 0] & np.uint64(0xFFFFFFFFFFFF)).astype(np.int64)
     dur = (end - start) / CLK / 1e3                              # ms
     rel = np.zeros(width)
     for x in np.unique(xcc):                                      # start relative to the XCD's first workgroup
@@ -30,7 +33,7 @@ for width in (256, 512, 1024, 2048):
     fin = rel + dur
     q = lambda a, p: float(np.percentile(a, p))
     per_cu = np.bincount(np.unique(cu, return_inverse=True)[1])
-    print(f"width {width:5d}: CUs used {len(per_cu)}, workgroups per CU min {per_cu.min()} max {per_cu.max()} | "
+    print(f"width {width:5d}: clock {float(np.median(cycles / ((end - start) / CLK))) / 1e3:5.3f} GHz | CUs used {len(per_cu)}, workgroups per CU min {per_cu.min()} max {per_cu.max()} | "
           f"start p50 {q(rel, 50):6.3f} p90 {q(rel, 90):6.3f} max {rel.max():6.3f} ms | run min {dur.min():5.2f} p10 {q(dur, 10):5.2f} "
           f"p50 {q(dur, 50):5.2f} p90 {q(dur, 90):5.2f} max {dur.max():5.2f} ms | finish max {fin.max():6.3f} ms", flush=True)
     if width == 512:
