@@ -53,10 +53,13 @@ int schedule_levels(const std::vector<PendingOp> &ops, int asap_depth, bool bala
     if (alap_out) *alap_out = lvl;
     if (!balance || asap_depth <= 2 || n < 4 * unit) return asap_depth;
 
-    // producer of each pending slot (destinations are unique: SSA)
-    std::unordered_map<int32_t, int32_t> producer;
-    producer.reserve((size_t)n * 2);
-    for (int i = 0; i < n; ++i) producer.emplace(ops[i].dst, i);
+    // producer of each pending slot (destinations are unique: SSA; slot ids are pool indices, so a flat
+    // table replaces the hash map that used to cost a third of a match's scheduling time)
+    int32_t max_slot = -1;
+    for (int i = 0; i < n; ++i) max_slot = std::max(max_slot, ops[i].dst);
+    std::vector<int32_t> producer((size_t)max_slot + 1, -1);
+    for (int i = 0; i < n; ++i)
+        if (producer[ops[i].dst] < 0) producer[ops[i].dst] = i;       // (first writer, as emplace kept it)
 
     // predecessor lists (<= 3 each) and successor lists in CSR form
     std::vector<int32_t> pred(3 * (size_t)n, -1), npred(n, 0), succ_off(n + 1, 0);
@@ -64,13 +67,13 @@ int schedule_levels(const std::vector<PendingOp> &ops, int asap_depth, bool bala
         const int32_t src[3] = {ops[i].a, ops[i].b, ops[i].c};
         for (int s = 0; s < 3; ++s) {
             if (src[s] < 0) continue;
-            auto it = producer.find(src[s]);
-            if (it == producer.end() || it->second >= i) continue;   // materialised before this flush
+            const int32_t pr = src[s] <= max_slot ? producer[src[s]] : -1;
+            if (pr < 0 || pr >= i) continue;                         // materialised before this flush
             bool dup = false;
-            for (int t = 0; t < npred[i]; ++t) dup |= pred[3 * (size_t)i + t] == it->second;
+            for (int t = 0; t < npred[i]; ++t) dup |= pred[3 * (size_t)i + t] == pr;
             if (dup) continue;
-            pred[3 * (size_t)i + npred[i]++] = it->second;
-            ++succ_off[it->second + 1];
+            pred[3 * (size_t)i + npred[i]++] = pr;
+            ++succ_off[pr + 1];
         }
     }
     for (int i = 0; i < n; ++i) succ_off[i + 1] += succ_off[i];
