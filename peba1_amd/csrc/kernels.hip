@@ -2,8 +2,12 @@
 //
 //   K6    bk_transform_kernel     Torus32 bootstrapping key -> NTT image (once per key)
 //   K1+K2 blind_rotate4_kernel    gate prelude, modulus switch, blind rotate (n external
-//                                 products), sample extract; four wave64 per rotation (default)
-//         blind_rotate_kernel     the same with two wave64 per rotation (selectable, tested)
+//                                 products), sample extract; four wave64 per rotation (default at N = 1024)
+//         blind_rotate8_kernel    eight wave64 per rotation (two per prime and input polynomial) for launches of
+//                                 at most one workgroup per CU: narrow levels, single gates (N = 1024)
+//         blind_rotate_split_kernel  eight wave64 per rotation, every transform as two half-size ones
+//                                 (default at N = 2048; selectable at N = 1024)
+//         blind_rotate_kernel     two wave64 per rotation (selectable, tested)
 //   K3/K4 keyswitch_tile_kernel   (u0 [+ u1] + const) -> LWE sample under the gate key, one pass
 //                                 over the KSK rows of a coefficient range serves 16 gates
 //         keyswitch_kernel        per-gate form for narrow launches; ks_reduce_kernel adds the
@@ -17,7 +21,7 @@
 // reference call sites: /root/reference/src/Math.cpp:34-43 (every bootsXOR/bootsAND).
 //
 // All ring kernels are templates on LOGN (N = 1024: TFHE's parameter sets, N = 2048: BASELINE
-// configs[4]); 16 or 32 coefficients per lane.  The accumulator (2 x N Torus32) lives in LDS
+// configs[4]); 16 or 32 coefficients per lane (8 or 16 in the split form).  The accumulator (2 x N Torus32) lives in LDS
 // for the whole n-step loop.
 // 4-wave form: wave (q, u) works modulo prime q on input polynomial u -- per step the rotated
 // accumulator, gadget digits, l forward NTTs (ntt_wave.hpp), 64-bit multiply-accumulate
