@@ -119,6 +119,8 @@ int tfhe_hip_gate_batch(int gate, LweSample *result, const LweSample *a, const L
  * (same function of the same ciphertexts, so the same words); 0 = evaluate every call.
  * "balance_levels": 1 (default) = slack-aware level filling at flush, 0 = plain ASAP
  * levels.
+ * Only in a library built with -DTFHE_HIP_EXPERIMENTAL (tfhe_hip_has_experimental() == 1; build.sh leaves it
+ * off: both executors measured slower than per-level launches):
  * "dataflow": 0 (default) = one blind-rotate + one key-switch launch per level; 1 (env
  * TFHE_HIP_DATAFLOW) = experimental: a flush runs as ONE launch in which workgroups take
  * gates in priority order, wait on done flags of their producers and do the key switch
@@ -129,6 +131,8 @@ int tfhe_hip_gate_batch(int gate, LweSample *result, const LweSample *a, const L
  * by events only where the DAG requires it (measured slower on the match).
  * Returns 0, or -1 for an unknown name. */
 int tfhe_hip_set_tuning(const char *name, int64_t value);
+/* 1 when the library carries the experimental executors ("dataflow", "lanes") */
+int tfhe_hip_has_experimental(void);
 
 /* ---- statistics ---- */
 typedef struct TfheHipStats {
@@ -159,8 +163,10 @@ void tfhe_hip_set_kernel_timing(int on);
  * records (kind: gate code 0..9, 16 = MUX, 17 = NOT; absent operands -1) without
  * touching the device; writes the level of each op, returns the depth ---- */
 int tfhe_hip_test_schedule(const int32_t *ops5, int32_t count, int32_t unit, int32_t balance, int32_t *levels_out);
+#ifdef TFHE_HIP_EXPERIMENTAL
 /* same input; writes the execution lane (0 urgent, 1 background) of each op for two-lane execution */
 int tfhe_hip_test_assign_lanes(const int32_t *ops5, int32_t count, int32_t unit, int32_t tight_slack, int32_t *lanes_out);
+#endif
 /* Diagnostic (tools/lane_probe.py): `levels` rounds of (blind rotate + key switch) over `width`
  * random gates, issued as `lanes` independent chains on `lanes` HIP streams; returns the wall
  * time in ms (negative on error).  Measures what overlapping level-synchronous chains could gain. */

@@ -640,7 +640,8 @@ void orc_cmux_rotate(const OrcKeySet *ks, int32_t i, int32_t barai, Torus32 *acc
             const uint32_t P = FP[pr], pinv = ft->pinv[pr];
             for (int32_t q = 0; q < kpl; ++q) {               /* kpl forward transforms */
                 uint32_t *x = dn + (size_t)q * N;
-                for (int32_t j = 0; j < N; ++j) x[j] = fast_from_i32(dig[(size_t)q * N + j], P);
+                /* gadget digits: |d| <= Bg/2 < P, so the canonical residue is d or d + P (no division) */
+                for (int32_t j = 0; j < N; ++j) { const int32_t dj = dig[(size_t)q * N + j]; x[j] = (uint32_t)(dj + ((dj >> 31) & (int32_t)P)); }
                 fast_fwd(x, ft, pr);
             }
             for (int32_t w = 0; w <= k; ++w) {                /* MAC against the key image, inverse */
@@ -653,7 +654,9 @@ void orc_cmux_rotate(const OrcKeySet *ks, int32_t i, int32_t barai, Torus32 *acc
                 uint32_t *r = res + ((size_t)pr * (k + 1) + w) * N;
                 for (int32_t j = 0; j < N; ++j) {
                     const uint32_t m = (uint32_t)sum[j] * pinv;
-                    r[j] = (uint32_t)((sum[j] + (uint64_t)m * P) >> 32) % P;
+                    /* sum < kpl P^2 < 2^32 * 0.2 P, so the reduced value is below 1.2 P: one conditional subtraction */
+                    const uint32_t rr = (uint32_t)((sum[j] + (uint64_t)m * P) >> 32);
+                    r[j] = rr >= P ? rr - P : rr;
                 }
                 fast_inv(r, ft, pr);
             }

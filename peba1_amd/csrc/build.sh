@@ -6,7 +6,9 @@ OUT=../libtfhe-hip.so
 ROCM=${ROCM_PATH:-/opt/rocm}
 HIPCC=${HIPCC:-$ROCM/bin/hipcc}
 CXX=${HOSTCXX:-$ROCM/lib/llvm/bin/clang++}
-FLAGS="-O3 -std=c++17 -fPIC -ffp-contract=off -Wall -Wno-unused-result"
+# TFHE_HIP_DEFS="-DTFHE_HIP_EXPERIMENTAL" adds the executors that measured slower than per-level launches
+# (the persistent dataflow launch, two-lane execution) and their tests; off by default
+FLAGS="-O3 -std=c++17 -fPIC -ffp-contract=off -Wall -Wno-unused-result ${TFHE_HIP_DEFS-}"
 HOSTFLAGS="$FLAGS -D__HIP_PLATFORM_AMD__ -I$ROCM/include"
 # max-ilp scheduling: the blind-rotate kernel is bound by multiplier-class issue and dependency stalls;
 # measured 1 % faster than the default strategy, max-memory-clause and no clustering 3-4 % slower

@@ -432,6 +432,9 @@ void Engine::execute(const DeviceKeyImage *key, SlotPool *pool, const LevelPlan 
 
     lane_stream_[0] = stream_;
     const size_t ngroups = ((size_t)levels + 1) * K;
+#ifndef TFHE_HIP_EXPERIMENTAL
+    if (K != 1) fatal("two-lane execution is an experimental executor: build with -DTFHE_HIP_EXPERIMENTAL");
+#else
     if (K > 1) {
         if (!lane_stream_[1]) {
             // the background lane: lowest queue priority, so freed workgroup slots go to the urgent lane first
@@ -448,6 +451,7 @@ void Engine::execute(const DeviceKeyImage *key, SlotPool *pool, const LevelPlan 
         hip_check(hipEventRecord(order_events_[ngroups], stream_), "upload event");
         hip_check(hipStreamWaitEvent(lane_stream_[1], order_events_[ngroups], 0), "wait upload");
     }
+#endif
     size_t nt = 0;                                       // timing events used: base, then 3 per group
     auto timing_event = [&]() {
         if (nt == timing_events_.size()) {
@@ -465,7 +469,9 @@ void Engine::execute(const DeviceKeyImage *key, SlotPool *pool, const LevelPlan 
         hip_check(hipEventRecord(base, stream_), "event");
         timed.reserve(ngroups);
     }
+#ifdef TFHE_HIP_EXPERIMENTAL
     int waited[2][2] = {{0, 0}, {0, 0}};                 // waited[s][o]: lane s already waits for lane o up to this level+1
+#endif
     int last_group[2] = {-1, -1};
     for (int L = 0; L <= levels; ++L) {
         for (int s = 0; s < K; ++s) {
@@ -476,6 +482,7 @@ void Engine::execute(const DeviceKeyImage *key, SlotPool *pool, const LevelPlan 
             const int nnot = plan.not_off[gn + 1] - plan.not_off[gn];
             if (nrot == 0 && nks == 0 && nnot == 0) continue;
             hipStream_t st = lane_stream_[s];
+#ifdef TFHE_HIP_EXPERIMENTAL
             if (K > 1) {
                 const int o = 1 - s;
                 const int w = plan.need[gn * K + o];
@@ -484,6 +491,7 @@ void Engine::execute(const DeviceKeyImage *key, SlotPool *pool, const LevelPlan 
                     waited[s][o] = w;
                 }
             }
+#endif
             Timed t{nullptr, nullptr, nullptr, false, nrot};
             if (kernel_timing) { t.e0 = timing_event(); hip_check(hipEventRecord(t.e0, st), "event"); }
             if (nrot) {
@@ -494,7 +502,9 @@ void Engine::execute(const DeviceKeyImage *key, SlotPool *pool, const LevelPlan 
             if (nks) launch_ks(key, u_buf[s], dks + plan.ks_off[gg], nks, pool->data(), st, s);
             if (kernel_timing) { t.e2 = timing_event(); hip_check(hipEventRecord(t.e2, st), "event"); timed.push_back(t); }
             launch_not(st, key->dp, dnots + plan.not_off[gn], nnot, pool->data());
+#ifdef TFHE_HIP_EXPERIMENTAL
             if (K > 1) hip_check(hipEventRecord(order_events_[gn], st), "lane event");
+#endif
             last_group[s] = (int)gn;
             stats.blind_rotates += (uint64_t)nrot;
             stats.keyswitches += (uint64_t)nks;
@@ -514,7 +524,9 @@ void Engine::execute(const DeviceKeyImage *key, SlotPool *pool, const LevelPlan 
         }
     }
     hip_check(hipGetLastError(), "kernel launch");
+#ifdef TFHE_HIP_EXPERIMENTAL
     if (K > 1 && last_group[1] >= 0) hip_check(hipStreamWaitEvent(stream_, order_events_[last_group[1]], 0), "join lanes");
+#endif
     hip_check(hipStreamSynchronize(stream_), "level execution");
     if (kernel_timing) {
         // durations per launch, and the union of the blind-rotate intervals (two lanes overlap)
@@ -553,6 +565,7 @@ void Engine::execute(const DeviceKeyImage *key, SlotPool *pool, const LevelPlan 
     stats.ms_flush_wall += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
 }
 
+#ifdef TFHE_HIP_EXPERIMENTAL
 void Engine::execute_dataflow(const DeviceKeyImage *key, SlotPool *pool, const std::vector<GateTask> &tasks, int depth) {
     const auto t0 = std::chrono::steady_clock::now();
     const int ntasks = (int)tasks.size();
@@ -605,6 +618,7 @@ void Engine::execute_dataflow(const DeviceKeyImage *key, SlotPool *pool, const s
     ++stats.flushes;
     stats.ms_flush_wall += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
 }
+#endif  // TFHE_HIP_EXPERIMENTAL
 
 void Engine::run_bootstrap_woks(const DeviceKeyImage *key, const Torus32 *lin, int count, Torus32 *u_out, Torus32 *acc_out) {
     const DevParams &dp = key->dp;

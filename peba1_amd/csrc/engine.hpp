@@ -100,8 +100,10 @@ public:
 
     // run a levelised plan; synchronises the stream before returning
     void execute(const DeviceKeyImage *key, SlotPool *pool, const LevelPlan &plan);
+#ifdef TFHE_HIP_EXPERIMENTAL
     // run a whole DAG (tasks in topological priority order) as one dataflow launch
     void execute_dataflow(const DeviceKeyImage *key, SlotPool *pool, const std::vector<GateTask> &tasks, int depth);
+#endif
     // raw test paths
     void run_bootstrap_woks(const DeviceKeyImage *key, const Torus32 *lin, int count, Torus32 *u_out, Torus32 *acc_out);
     void run_keyswitch(const DeviceKeyImage *key, const Torus32 *u, int count, Torus32 *out);

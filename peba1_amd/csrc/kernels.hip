@@ -13,7 +13,8 @@
 //         keyswitch_kernel        per-gate form for narrow launches; ks_reduce_kernel adds the
 //                                 partial sums of the ranges
 //   K5    not_kernel              negation
-//         gate_dataflow_kernel    experimental: a whole gate DAG in one persistent launch
+//         gate_dataflow_kernel    experimental (built with -DTFHE_HIP_EXPERIMENTAL only): a whole gate DAG in one
+//                                 persistent launch
 //         gather/scatter_slots    packed words <-> ciphertext pool (import, export, collectives)
 //
 // Restates (does not translate) tfhe's tfhe_bootstrap_woKS_FFT / tfhe_blindRotate_FFT
@@ -1044,6 +1045,7 @@ __global__ __launch_bounds__(256) void negacyclic_split_kernel(const int32_t *__
     }
 }
 
+#ifdef TFHE_HIP_EXPERIMENTAL   // measured slower than per-level launches: off in build.sh
 // ---------------------------------------------------------------------------
 // Dataflow executor: ONE launch runs a whole recorded gate DAG.  `tasks` is sorted in a
 // topological priority order (scheduler.cpp); every workgroup repeatedly takes the next
@@ -1237,6 +1239,8 @@ __global__ __launch_bounds__(256, 1) void gate_dataflow_kernel(
         ti = __builtin_amdgcn_readfirstlane(s_task);
     }
 }
+
+#endif  // TFHE_HIP_EXPERIMENTAL
 
 // ---------------------------------------------------------------------------
 // K3/K4: key switch (tfhe lweKeySwitchTranslate_fromArray).  grid = gates.
@@ -1542,6 +1546,7 @@ void launch_blind_rotate4(hipStream_t s, const DevParams &p, const DevKey &key, 
 #undef BR4
 }
 
+#ifdef TFHE_HIP_EXPERIMENTAL
 void launch_gate_dataflow(hipStream_t s, const DevParams &p, const DevKey &key, int32_t *pool, const GateTask *tasks,
                           int ntasks, int32_t *done, int32_t *ctrl, int max_blocks) {
     if (ntasks <= 0) return;
@@ -1551,6 +1556,7 @@ void launch_gate_dataflow(hipStream_t s, const DevParams &p, const DevKey &key, 
     else
         hipLaunchKernelGGL(gate_dataflow_kernel<10>, dim3(grid), dim3(256), 0, s, p, key, pool, tasks, ntasks, done, ctrl);
 }
+#endif
 
 void launch_keyswitch(hipStream_t s, const DevParams &p, const DevKey &key, const int32_t *u_buf,
                       const KsDesc *descs, int count, int32_t *pool, int splits, int32_t *partial, int tile) {

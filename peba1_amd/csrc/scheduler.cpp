@@ -14,6 +14,7 @@ struct HeapItem {
 };
 }  // namespace
 
+#ifdef TFHE_HIP_EXPERIMENTAL   // orders for the experimental executors (dataflow launch, two lanes)
 void priority_order(const std::vector<PendingOp> &ops, const std::vector<int32_t> &lvl,
                     const std::vector<int32_t> &alap, std::vector<int32_t> &order) {
     const int n = (int)ops.size();
@@ -44,6 +45,7 @@ void assign_lanes(const std::vector<PendingOp> &ops, const std::vector<int32_t> 
         producer.emplace(ops[i].dst, i);
     }
 }
+#endif  // TFHE_HIP_EXPERIMENTAL
 
 int schedule_levels(const std::vector<PendingOp> &ops, int asap_depth, bool balance, int unit,
                     std::vector<int32_t> &lvl, std::vector<int32_t> *alap_out) {

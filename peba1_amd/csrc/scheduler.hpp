@@ -33,6 +33,7 @@ inline int op_rotations(const PendingOp &op) { return op.kind == OP_NOT ? 0 : (o
 int schedule_levels(const std::vector<PendingOp> &ops, int asap_depth, bool balance, int unit,
                     std::vector<int32_t> &lvl, std::vector<int32_t> *alap_out = nullptr);
 
+#ifdef TFHE_HIP_EXPERIMENTAL
 // Execution order for the dataflow executor: a topological order of the DAG in which
 // more urgent gates come first (balanced level, then ALAP level, then recording order;
 // a NOT directly after the gates of its level).  order[k] = index into ops.
@@ -49,5 +50,6 @@ void priority_order(const std::vector<PendingOp> &ops, const std::vector<int32_t
 // operand (lane 0 when that is already materialised).  lanes_out[i] in {0, 1}.
 void assign_lanes(const std::vector<PendingOp> &ops, const std::vector<int32_t> &alap, int tight_slack,
                   std::vector<uint8_t> &lanes_out);
+#endif  // TFHE_HIP_EXPERIMENTAL
 
 }  // namespace tfhe_hip

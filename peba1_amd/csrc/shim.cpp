@@ -102,9 +102,11 @@ struct Recorder {
     // API must; fixed seeds exist only behind tfhe_hip_set_encrypt_seed / tfhe_hip_new_secret_keyset_seeded.
     Rng enc_rng{os_entropy()};
     bool balance_levels = true;   // slack-aware level filling (scheduler.hpp)
+#ifdef TFHE_HIP_EXPERIMENTAL      // executors that measured slower than per-level launches
     bool dataflow = false;        // opt-in: one dataflow launch per flush instead of per-level launches
     int lanes = 1;                // 2: urgent gates and the rest on two streams (scheduler.hpp assign_lanes)
     int tight_slack = 64;         // lane 0 takes the gates with at most this much slack
+#endif
     std::unordered_map<int32_t, int32_t> not_origin;   // pending NOT output slot -> its operand slot
     // Pending gates by (kind, operand slots): a gate recorded again with the same operands before
     // the flush is the same function of the same ciphertexts, so its result slot is shared
@@ -124,9 +126,11 @@ Recorder &rec() {
     static Recorder r;
     static bool init = [] {
         if (const char *e = std::getenv("TFHE_HIP_DEFERRED")) r.deferred = std::atoi(e) != 0;
+#ifdef TFHE_HIP_EXPERIMENTAL
         if (const char *e = std::getenv("TFHE_HIP_DATAFLOW")) r.dataflow = std::atoi(e) != 0;
         if (const char *e = std::getenv("TFHE_HIP_LANES")) r.lanes = std::atoi(e) > 1 ? 2 : 1;
         if (const char *e = std::getenv("TFHE_HIP_TIGHT_SLACK")) r.tight_slack = std::atoi(e);
+#endif
         return true;
     }();
     (void)init;
@@ -282,6 +286,7 @@ int flush_locked() {
             std::fclose(f);
         }
     }
+#ifdef TFHE_HIP_EXPERIMENTAL
     if (r.dataflow) {
         // one launch for the whole DAG: tasks in topological priority order, each naming the
         // tasks that produce its operands
@@ -324,14 +329,17 @@ int flush_locked() {
         r.max_level = 0;
         return levels;
     }
+#endif  // TFHE_HIP_EXPERIMENTAL
     // execution lanes: urgent gates (little slack) and the rest run as two level sequences on
     // two streams, ordered against each other only where the DAG says so (scheduler.hpp)
     int K = 1;
     std::vector<uint8_t> lane;
+#ifdef TFHE_HIP_EXPERIMENTAL
     if (r.lanes > 1 && levels > 2) {
         assign_lanes(r.ops, alap, r.tight_slack, lane);
         for (uint8_t l : lane) if (l) { K = 2; break; }
     }
+#endif
     if (K == 1) lane.assign(r.ops.size(), 0);
     LevelPlan plan;
     plan.lanes = K;
@@ -874,6 +882,14 @@ int tfhe_hip_gate_batch(int gate, LweSample *result, const LweSample *a, const L
     return rc;
 }
 
+int tfhe_hip_has_experimental(void) {
+#ifdef TFHE_HIP_EXPERIMENTAL
+    return 1;
+#else
+    return 0;
+#endif
+}
+
 int tfhe_hip_set_tuning(const char *name, int64_t value) {
     if (name && std::strcmp(name, "br4_max_rotations") == 0) { Engine::get().br4_max_rotations = (int)value; return 0; }
     if (name && std::strcmp(name, "ks_target_blocks") == 0) { Engine::get().ks_target_blocks = (int)value; return 0; }
@@ -888,9 +904,11 @@ int tfhe_hip_set_tuning(const char *name, int64_t value) {
     if (name && std::strcmp(name, "br_variant") == 0) { Engine::get().br_variant = (int)value; return 0; }
     if (name && std::strcmp(name, "reuse_gates") == 0) { rec().reuse_gates = value != 0; return 0; }
     if (name && std::strcmp(name, "balance_levels") == 0) { rec().balance_levels = value != 0; return 0; }
+#ifdef TFHE_HIP_EXPERIMENTAL
     if (name && std::strcmp(name, "lanes") == 0) { rec().lanes = value > 1 ? 2 : 1; return 0; }
     if (name && std::strcmp(name, "tight_slack") == 0) { rec().tight_slack = (int)value; return 0; }
     if (name && std::strcmp(name, "dataflow") == 0) { rec().dataflow = value != 0; return 0; }
+#endif
     set_error(std::string("tfhe_hip_set_tuning: unknown name ") + (name ? name : "(null)"));
     return -1;
 }
@@ -934,6 +952,7 @@ int tfhe_hip_test_schedule(const int32_t *ops5, int32_t count, int32_t unit, int
     return d;
 }
 
+#ifdef TFHE_HIP_EXPERIMENTAL
 int tfhe_hip_test_assign_lanes(const int32_t *ops5, int32_t count, int32_t unit, int32_t tight_slack, int32_t *lanes_out) {
     std::vector<PendingOp> ops;
     const int depth = test_build_ops(ops5, count, ops);
@@ -944,6 +963,7 @@ int tfhe_hip_test_assign_lanes(const int32_t *ops5, int32_t count, int32_t unit,
     for (int32_t i = 0; i < count; ++i) lanes_out[i] = lane[i];
     return d;
 }
+#endif
 
 double tfhe_hip_test_lane_probe(const TFheGateBootstrappingCloudKeySet *bk, int32_t lanes, int32_t levels, int32_t width) {
     if (!bk || !bk->bk) { set_error("lane_probe: null keyset"); return -1.0; }

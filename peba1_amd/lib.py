@@ -88,7 +88,6 @@ SIGNATURES = {
     "new_tfheGateBootstrappingSecretKeySet_fromFile": (SK, [C.c_void_p]),
     "export_gate_bootstrapping_ciphertext_toFile": (None, [C.c_void_p, LS, PS]),
     "import_gate_bootstrapping_ciphertext_fromFile": (None, [C.c_void_p, LS, PS]),
-    "tfhe_hip_test_assign_lanes": (C.c_int, [I32P, C.c_int32, C.c_int32, C.c_int32, I32P]),
     "tfhe_hip_test_wg_times": (C.c_int, [CK, C.c_int32, C.POINTER(C.c_uint64), C.POINTER(C.c_double)]),
     "tfhe_hip_test_lane_probe": (C.c_double, [CK, C.c_int32, C.c_int32, C.c_int32]),
     "tfhe_hip_last_error": (C.c_char_p, []),
@@ -115,6 +114,7 @@ SIGNATURES = {
     "tfhe_hip_flush": (C.c_int, []),
     "tfhe_hip_gate_batch": (C.c_int, [C.c_int, LS, LS, LS, C.c_int32, CK]),
     "tfhe_hip_set_tuning": (C.c_int, [C.c_char_p, C.c_int64]),
+    "tfhe_hip_has_experimental": (C.c_int, []),
     "tfhe_hip_get_stats": (None, [C.POINTER(Stats)]),
     "tfhe_hip_reset_stats": (None, []),
     "tfhe_hip_set_kernel_timing": (None, [C.c_int]),
@@ -125,6 +125,10 @@ SIGNATURES = {
 }
 for _g in _GATE2:
     SIGNATURES[_g] = (None, [LS, LS, LS, CK])
+# declared only under -DTFHE_HIP_EXPERIMENTAL (off in build.sh): bound when the library carries them
+EXPERIMENTAL_SIGNATURES = {
+    "tfhe_hip_test_assign_lanes": (C.c_int, [I32P, C.c_int32, C.c_int32, C.c_int32, I32P]),
+}
 
 _lib = None
 
@@ -142,5 +146,15 @@ def load():
             f = getattr(L, name)   # AttributeError if the library does not export a declared symbol
             f.restype = res
             f.argtypes = args
+        if L.tfhe_hip_has_experimental():
+            for name, (res, args) in EXPERIMENTAL_SIGNATURES.items():
+                f = getattr(L, name)
+                f.restype = res
+                f.argtypes = args
         _lib = L
     return _lib
+
+
+def experimental():
+    """True when libtfhe-hip.so was built with -DTFHE_HIP_EXPERIMENTAL (dataflow launch, two-lane execution)."""
+    return bool(load().tfhe_hip_has_experimental())

@@ -9,7 +9,14 @@ Takes ~10 CPU-minutes (0.17 s per gate, single thread).
 With --fast it writes function_f_fast_digest.json instead: the same inputs through the optimised
 DAG (peba1_function_f_fast, circuits_fast.cpp; a few hundred gates, ~1 minute).
 With --p2048 it writes function_f_p2048_digest.json: the same circuit and inputs under the N = 2048
-parameter set of BASELINE configs[4] (~0.6 s per gate: about 35 CPU-minutes)."""
+parameter set of BASELINE configs[4] (~0.6 s per gate: about 35 CPU-minutes).
+With --threads T the oracle provider records the gate DAG and evaluates it level by level on T host
+threads (oracle/boots_oracle.c, recording mode): same ciphertexts, T times sooner.
+With --slots128 it writes function_f_128_digest.json: BASELINE configs[1] at its own size -- the 128-slot
+x 8-bit match of /root/reference/src/Math.cpp:379-387 on the inputs of SURVEY 8(c) (template
+(37 i + 11) mod 255, genuine probe = template + 1), evaluated twice, against the encrypted bounds 256 and
+0 (the reference's D3 behaviour); 215,544 blind rotations + 72 for the second comparator.  Needs
+--threads (about 55 minutes on 7 threads)."""
 import ctypes as C
 import hashlib
 import json
@@ -29,6 +36,8 @@ TEMPLATE, PROBE, BOUND, BITS = [37, 200], [40, 190], 100, 8
 
 
 def main():
+    if "--slots128" in sys.argv[1:]:
+        return slots128()
     fast = "--fast" in sys.argv[1:]
     pname = "P2048" if "--p2048" in sys.argv[1:] else "P128"
     subprocess.check_call(["make", "-s", "-C", os.path.join(ROOT, "oracle")])
@@ -50,6 +59,8 @@ def main():
     p = O.params(pname)
     ks = B.orc_keygen(C.byref(p), KEY_SEED)
     B.orc_boots_bind(ks, ENC_SEED)
+    if "--threads" in sys.argv[1:]:
+        B.orc_boots_set_recording(int(sys.argv[sys.argv.index("--threads") + 1]))
     params = B.orc_boots_params()
     cloud = B.orc_boots_cloud()
     SZ = 24
@@ -85,6 +96,71 @@ def main():
     if pname != "P128":
         name = name.replace("function_f", "function_f_" + pname.lower())
     with open(os.path.join(ROOT, "tests", "golden", name), "w") as f:
+        json.dump(out, f, indent=1)
+    print(json.dumps(out, indent=1))
+
+
+def slots128():
+    """configs[1] at its own size; see the module docstring."""
+    nslots, bits = 128, 8
+    threads = int(sys.argv[sys.argv.index("--threads") + 1]) if "--threads" in sys.argv else 7
+    template = [(37 * i + 11) % 255 for i in range(nslots)]
+    probe = [t + 1 for t in template]
+    bounds = [256, 0]
+    subprocess.check_call(["make", "-s", "-C", os.path.join(ROOT, "oracle")])
+    B = C.CDLL(os.path.join(ROOT, "oracle", "liboracle_boots.so"))
+    V = C.c_void_p
+    B.orc_keygen.restype = V
+    B.orc_keygen.argtypes = [C.POINTER(O.OrcParams), C.c_uint64]
+    B.orc_boots_bind.argtypes = [V, C.c_uint64]
+    B.orc_boots_params.restype = V
+    B.orc_boots_cloud.restype = V
+    B.orc_boots_gate_count.restype = C.c_longlong
+    B.orc_boots_unique_rotations.restype = C.c_longlong
+    B.new_gate_bootstrapping_ciphertext_array.restype = V
+    B.new_gate_bootstrapping_ciphertext_array.argtypes = [C.c_int32, V]
+    B.bootsSymEncrypt.argtypes = [V, C.c_int32, V]
+    B.bootsSymDecrypt.argtypes = [V, V]
+    B.orc_boots_export.argtypes = [V, C.c_int32, V]
+    B.peba1_function_f.argtypes = [V, V, V, C.c_int, V, C.c_int, V]
+    p = O.params("P128")
+    ks = B.orc_keygen(C.byref(p), KEY_SEED)
+    B.orc_boots_bind(ks, ENC_SEED)
+    B.orc_boots_set_recording(threads)
+    params, cloud, SZ = B.orc_boots_params(), B.orc_boots_cloud(), 24
+
+    def enc(v, nb):
+        a = B.new_gate_bootstrapping_ciphertext_array(nb, params)
+        for i in range(nb):
+            B.bootsSymEncrypt(a + i * SZ, (v >> i) & 1, None)
+        return a
+
+    # encryption order is part of the fixture: per slot template then probe, then the bounds in order
+    T, S = [], []
+    for t, s in zip(template, probe):
+        T.append(enc(t, bits))
+        S.append(enc(s, bits))
+    enc_bounds = [enc(b, 3 * bits) for b in bounds]
+    t0 = time.time()
+    d = sum((a - b) ** 2 for a, b in zip(probe, template))
+    out = {"params": "P128", "circuit": "peba1_function_f", "key_seed": KEY_SEED, "encrypt_seed": ENC_SEED, "nslots": nslots, "bits": bits,
+           "template": "(37*i+11)%255", "probe": "template+1", "distance": d, "bounds": bounds, "runs": []}
+    for bound, eb in zip(bounds, enc_bounds):
+        rb = B.new_gate_bootstrapping_ciphertext_array(3 * bits, params)
+        before = B.orc_boots_gate_count()
+        B.peba1_function_f(rb, (V * nslots)(*S), (V * nslots)(*T), nslots, eb, bits, cloud)
+        words = np.zeros((3 * bits, p.n + 1), dtype=np.int32)
+        B.orc_boots_export(rb, 3 * bits, words.ctypes.data_as(V))
+        bit = B.bootsSymDecrypt(rb, None)
+        assert bit == (1 if d > bound else 0), (bit, d, bound)
+        out["runs"].append({"bound": bound, "match_bit": int(bit), "blind_rotates_recorded": int(B.orc_boots_gate_count() - before),
+                            "result_b_sha256": hashlib.sha256(words.tobytes()).hexdigest(),
+                            "result_b0_sha256": hashlib.sha256(words[0].tobytes()).hexdigest()})
+        print(json.dumps(out["runs"][-1]), flush=True)
+    out["blind_rotates_evaluated"] = int(B.orc_boots_unique_rotations())
+    out["oracle_seconds"] = round(time.time() - t0, 1)
+    out["oracle_threads"] = threads
+    with open(os.path.join(ROOT, "tests", "golden", "function_f_128_digest.json"), "w") as f:
         json.dump(out, f, indent=1)
     print(json.dumps(out, indent=1))
 
