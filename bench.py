@@ -118,7 +118,17 @@ def cpu_baseline(seed):
     t3 = time.perf_counter()
     oks.gate_batch("AND", a[:4], b[:4], nthreads=1, use_ntt=3)
     single_f = 4.0 / (time.perf_counter() - t3)
+    model = "unknown"
+    try:
+        with open("/proc/cpuinfo") as f:
+            for line in f:
+                if line.startswith("model name"):
+                    model = line.split(":", 1)[1].strip()
+                    break
+    except OSError:
+        pass
     return {"value": count / dt, "unit": "bootstrapped gates/s", "cores": cores, "kind": "port",
+            "cpu_model": model, "host_cpus_visible": os.cpu_count(),
             "sample": f"{count} independent bootsAND (P128) on {cores} threads, oracle exact-integer two-prime NTT "
                       f"(scalar C); 1 thread: {single:.2f} gates/s",
             "fft_standin": {"value": nf / dtf, "unit": "bootstrapped gates/s", "cores": cores,
@@ -217,22 +227,35 @@ def main():
         tmpl = circuits.EncryptedVector(pp, tmpl_vals, bitsize, ks).to_device()
         gather_buf = None
         if use_dist:
-            mine = torch.empty(pp.words, dtype=torch.int32, device=xdev)
             gather_buf = [torch.empty(pp.words, dtype=torch.int32, device=xdev) for _ in range(world)] if rank == 0 else None
+        pending = []        # (send buffer, work handle) of the previous step's gather
 
         def step():
             rb = api.CiphertextArray(pp, 3 * bitsize)
             circuits.function_f(rb, probe, tmpl, bound, bitsize, ks)   # records ~350k API calls
             api.flush()                                                # levelised batched execution
             if use_dist:    # the only exchange: match-bit ciphertexts to rank 0 over RCCL
+                # Ordering (both directions): the library exports on its own non-blocking stream and
+                # returns after that stream has been synchronised, so the send buffer is complete before the gather is
+                # enqueued.  The other way round the collective reads the buffer asynchronously on RCCL's stream: the
+                # previous step's gather is waited for before its buffers are dropped or written again, and every
+                # step sends from a buffer of its own.
+                for _, work in pending:
+                    work.wait()
+                if pending and xdev == "cuda":
+                    torch.cuda.current_stream().synchronize()
+                pending.clear()
+                mine = torch.empty(pp.words, dtype=torch.int32, device=xdev)
                 (L.tfhe_hip_export_samples_device if xdev == "cuda" else L.tfhe_hip_export_samples)(
                     rb.ptr, 1, pp.ptr, ctypes.cast(mine.data_ptr(), ctypes.c_void_p if xdev == "cuda" else lib.I32P))
-                dist.gather(mine, gather_buf, dst=0)
+                pending.append((mine, dist.gather(mine, gather_buf, dst=0, async_op=True)))
             return rb
 
         def check(last):
             bit = int(last.decrypt(ks)[0])
             assert bit == plain_bit(tmpl_vals), f"rank {rank}: match bit {bit}"
+            for _, work in pending:
+                work.wait()
             if use_dist and rank == 0:
                 torch.cuda.synchronize()
                 tmp = api.CiphertextArray(pp, 1)
@@ -376,6 +399,10 @@ def main():
                          "valu": valu, "counters_measured_on_kernels_sha16": khash if (traffic or valu) else None,
                          "kernels_sha16": khash,
                          "launches": int(dn), "avg_launch_ms": dms / max(1, dn), "rotations_per_launch": drot / max(1, dn),
+                         # shader clock of the timed blind-rotate launches: cycles / 100 MHz reference ticks of workgroup 0
+                         # of every launch (the same launch is ~15 % slower at the ~2.0 GHz of a cold or power-limited
+                         # chip than at ~2.37 GHz) -- explains run-to-run and box-to-box differences
+                         "shader_clock_ghz": 0.1 * st["clk_shader_cycles"] / st["clk_ref_ticks"] if st["clk_ref_ticks"] else None,
                          "other_blind_rotate_kernel": {"kernel": "blind_rotate4_kernel" if dom8 else "blind_rotate8_kernel",
                                                        "launches": int(on), "avg_launch_ms": oms / max(1, on),
                                                        "rotations_per_launch": orot / max(1, on)},
@@ -488,6 +515,7 @@ def extras(api, circuits, identify, lib, pd, pp, ks, probe, tmpl, bound, base, p
     assert int(rbh.decrypt(ks)[0]) == (1 if bin(ta ^ tb).count("1") > 40 else 0)
     out["hamming128_match"] = {"match_ms": t * 1e3, "blind_rotates": int(s["blind_rotates"]),
                                "levels": int(s["levels"]), "gates_per_s": s["blind_rotates"] / t}
+    out["independent_gates_4096"] = independent_gates(api, lib, 4096)
     # the same 128-slot match through the optimised DAG (peba1_function_f_fast; not the reference's
     # gate sequence) -- same match bit, fewer and shallower gates
     api.reset_stats()
@@ -501,6 +529,56 @@ def extras(api, circuits, identify, lib, pd, pp, ks, probe, tmpl, bound, base, p
     out["optimised_dag_match"] = {"match_ms": t * 1e3, "blind_rotates": int(s["blind_rotates"]),
                                   "levels": int(s["levels"]), "gates_per_s": s["blind_rotates"] / t}
     return out
+
+
+def independent_gates(api, lib, G):
+    """SURVEY 8(d)'s microbenchmark inside the driver-run line: G independent bootsAND on fresh encryptions of
+    random bits, one launch, for the three parameter sets (P128 = the headline's; P80 = tfhe's legacy set;
+    P2048 = BASELINE configs[4]).  Blind-rotate launch time from HIP events; the fraction is algorithmic bytes
+    per second over the 8 TB/s HBM peak (SURVEY 8d's table)."""
+    import numpy as np
+    L = lib.load()
+    res = {}
+    was = api.get_deferred()
+    api.set_deferred(False)
+    try:
+        for name, make in (("P128", lambda: api.ParameterSet(128)), ("P80", lambda: api.ParameterSet(80)),
+                           ("P2048", lambda: api.ParameterSet(p2048=True))):
+            pq = make()
+            kq = api.SecretKeySet(pq, 0x5EBA2)
+            rng = np.random.default_rng(11)
+            xa, xb = rng.integers(0, 2, G), rng.integers(0, 2, G)
+            A = api.CiphertextArray(pq, G).encrypt(xa, kq)
+            B = api.CiphertextArray(pq, G).encrypt(xb, kq)
+            A.set_words(A.words()); B.set_words(B.words())            # resident in HBM
+            R = api.CiphertextArray(pq, G)
+            api.gate_batch("AND", R, A, B, kq)                         # warm-up launch
+            best = None
+            for _ in range(3):
+                api.reset_stats()
+                t = time.perf_counter()
+                api.gate_batch("AND", R, A, B, kq)
+                t = time.perf_counter() - t
+                s = api.stats()
+                if best is None or s["ms_blind_rotate"] < best[0]["ms_blind_rotate"]:
+                    best = (s, t)
+            s, t = best
+            sample = R.decrypt(kq)[:64]
+            assert list(sample) == [int(x & y) for x, y in zip(xa[:64], xb[:64])], name
+            a_br, a_ks, _ = algorithmic_bytes(pq)
+            rps = G / (s["ms_blind_rotate"] * 1e-3)
+            res[name] = {"n": pq.n, "N": pq.N, "l": pq.l, "Bgbit": pq.Bgbit, "gates": G,
+                         "ms_blind_rotate": s["ms_blind_rotate"], "ms_keyswitch": s["ms_keyswitch"],
+                         "rotations_per_s_blind_rotate_only": rps,
+                         "gates_per_s_with_keyswitch": G / ((s["ms_blind_rotate"] + s["ms_keyswitch"]) * 1e-3),
+                         "roofline_frac_algorithmic": rps * a_br / (HBM_PEAK_GBPS * 1e9),
+                         "shader_clock_ghz": 0.1 * s["clk_shader_cycles"] / s["clk_ref_ticks"] if s["clk_ref_ticks"] else None,
+                         "checked": "64 decrypted outputs == a AND b"}
+            del A, B, R
+            kq.close()
+    finally:
+        api.set_deferred(was)
+    return res
 
 
 if __name__ == "__main__":

@@ -43,16 +43,25 @@ TFheGateBootstrappingParameterSet *tfhe_hip_new_parameters(
 /* BASELINE.json configs[4]: N=2048, Bg=2^6, l=3 (n=1024, ks 8x2 bit fixed by this repo) */
 TFheGateBootstrappingParameterSet *tfhe_hip_new_p2048_parameters(void);
 
-/* ---- deterministic key generation and encryption randomness ----
- * By default new_random_gate_bootstrapping_secret_keyset and bootsSymEncrypt draw from a
- * generator seeded with OS entropy (getrandom); the entry points below fix the seeds, for
- * tests and golden fixtures only. ---- */
+/* ---- randomness ----
+ * Default (new_random_gate_bootstrapping_secret_keyset, bootsSymEncrypt): ChaCha20 key streams (RFC 8439 block
+ * function), each under its own 256-bit key + 64-bit nonce from getrandom(); the secrets (key bits, every noise
+ * sample) and the public masks (bk / ksk masks, the `a` words of ciphertexts) come from two independently keyed
+ * streams.  No OS entropy = abort with a message.
+ * The entry points below replace that with the SEEDED generator of the key-derivation specification this library
+ * shares with the test oracle (xoshiro256** through splitmix64, one stream for secrets and masks):
+ * reproducible and NOT cryptographic -- for tests and golden fixtures only, never for keys that protect data. ---- */
 TFheGateBootstrappingSecretKeySet *tfhe_hip_new_secret_keyset_seeded(
     const TFheGateBootstrappingParameterSet *params, uint64_t seed);
 /* host-only keyset (no device upload): lets CPU-only tests check key derivation */
 TFheGateBootstrappingSecretKeySet *tfhe_hip_new_secret_keyset_seeded_host(
     const TFheGateBootstrappingParameterSet *params, uint64_t seed);
 void tfhe_hip_set_encrypt_seed(uint64_t seed);
+/* 1 after tfhe_hip_set_encrypt_seed (bootsSymEncrypt is reproducible, not secure), else 0 */
+int tfhe_hip_randomness_is_seeded(void);
+/* known-answer hook for the default generator: ChaCha20 key-stream block of (key[8], 64-bit counter, nonce[2]);
+ * RFC 8439 2.3.2 = counter 1 | 0x09000000 << 32, nonce {0x4a000000, 0} */
+void tfhe_hip_test_chacha20_block(const uint32_t *key8, uint64_t counter, const uint32_t *nonce2, uint32_t *out16);
 
 /* read-only views of the key material (parity tests hash these) */
 const int32_t *tfhe_hip_key_lwe(const TFheGateBootstrappingSecretKeySet *key, int64_t *count);
@@ -111,6 +120,9 @@ int tfhe_hip_gate_batch(int gate, LweSample *result, const LweSample *a, const L
  * "ks_tile": 16 (default) or 32 = launches of at least 2*tile key switches use the tiled
  * kernel (a workgroup streams the KSK rows of one range once for `tile` gates); 0 = always
  * one workgroup per (gate, range); env TFHE_HIP_KS_TILE.
+ * "ks_atomic": 1 = the ranges of a split key switch add their partial sums into the zeroed destination
+ * slot with 32-bit atomic adds (no partial-sum buffer, no reduce launch); 0 (default) = partial sums + reduce;
+ * env TFHE_HIP_KS_ATOMIC.  Integer adds commute: the same words either way.
  * "br_fair": k > 0 (default 18, env TFHE_HIP_BR_FAIR) = in launches that put two blind-rotate
  * workgroups on a CU, the two swap wave issue priority every 2^k shader cycles so that both
  * finish together; 0 = leave it to the hardware's oldest-first arbitration.
@@ -153,11 +165,22 @@ typedef struct TfheHipStats {
     uint64_t br8_launches;
     uint64_t br8_rotations;
     double   ms_blind_rotate8;
+    /* with kernel timing on: shader cycles (s_memtime) and 100 MHz reference ticks (s_memrealtime) that workgroup 0
+     * of every blind-rotate launch of the flushes lived for; 0.1 * cycles / ticks = the shader clock in GHz the
+     * timed launches ran at (a cold chip runs them at ~2.0 GHz, a warm one at ~2.37) */
+    uint64_t clk_shader_cycles;
+    uint64_t clk_ref_ticks;
 } TfheHipStats;
 void tfhe_hip_get_stats(TfheHipStats *out);
 void tfhe_hip_reset_stats(void);
 /* when on, every kernel launch is bracketed by HIP events, read back after the flush */
 void tfhe_hip_set_kernel_timing(int on);
+
+/* ---- host-logic test entry: does blind-rotate kernel form `form` (0 = 4 waves wide, 1 = 4 waves lean, 2 = split,
+ * 3 = 8 waves, 4 = 2 waves) keep its magnitude bounds for gadget (l, Bgbit) at ring size N with digit-table mode
+ * `tables` (0, 1, 2 as "br_digit_table")?  A key is refused at upload when no form does; a launch falls back to an
+ * admissible form (peba1_amd/csrc/br_forms.hpp).  Returns 1 or 0. ---- */
+int tfhe_hip_test_form_admissible(int form, int32_t N, int32_t l, int32_t Bgbit, int tables);
 
 /* ---- host-logic test entry: levelise a DAG given as count x {kind, dst, a, b, c} slot
  * records (kind: gate code 0..9, 16 = MUX, 17 = NOT; absent operands -1) without

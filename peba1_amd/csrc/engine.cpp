@@ -12,6 +12,7 @@
 #include <cstring>
 #include <mutex>
 
+#include "br_forms.hpp"
 #include "ntt_field.hpp"
 
 namespace tfhe_hip {
@@ -87,6 +88,7 @@ void Engine::ensure_init() {
     if (const char *env = std::getenv("TFHE_HIP_KS_BLOCKS")) ks_target_blocks = std::atoi(env);
     if (const char *env = std::getenv("TFHE_HIP_KS_MAX_SPLITS")) ks_max_splits = std::atoi(env);
     if (const char *env = std::getenv("TFHE_HIP_KS_TILE")) ks_tile = std::atoi(env);
+    if (const char *env = std::getenv("TFHE_HIP_KS_ATOMIC")) ks_atomic = std::atoi(env);
     hip_check(hipSetDevice(device_), "hipSetDevice");
     {
         hipDeviceProp_t prop;
@@ -205,24 +207,37 @@ static DevParams make_dev_params(const Params &p) {
     d.br_variant = 0;
     d.digit_table = 1;
     d.cu_arrivals = nullptr;
+    d.clock_acc = nullptr;
     d.wg_times = nullptr;
     return d;
+}
+
+// why the kernels cannot evaluate gates under `p` exactly, or null.  Also applied by the file loaders (io.cpp).
+const char *unsupported_reason(const Params &p) {
+    if ((p.N != 1024 && p.N != 2048) || p.k != 1) return "the blind-rotate kernels are built for N = 1024 or 2048 and k = 1";
+    if (p.n < 1 || p.n > 1024 || p.ct_stride() / 4 > 320) return "LWE dimension n must be in [1, 1024]";
+    if (p.l < 1 || p.Bgbit < 1 || p.l * p.Bgbit > 32 || p.Bgbit > 12) return "gadget digits must fit 12 bits and l * Bgbit <= 32";
+    if (p.ks_t < 1 || p.ks_basebit < 1 || p.ks_t * p.ks_basebit > 31 || p.ks_basebit > 8) return "key-switch digits out of range";
+    // exactness of the CRT range: (k+1) l N (Bg/2) 2^31 must stay below P0*P1/2
+    const double bound = (double)(p.k + 1) * p.l * p.N * (double)(1u << (p.Bgbit - 1)) * 2147483648.0;
+    if (bound >= (double)CRT_HALF) return "gadget parameters exceed the exact range of the two-prime NTT";
+    // at least one kernel form must keep its lazy-arithmetic bounds for this (l, Bgbit) (br_forms.hpp)
+    for (int f = 0; f < BR_FORM_COUNT; ++f)
+        for (int t = 0; t < 3; ++t)
+            if (br_form_admissible(f, p.N, p.l, p.Bgbit, t)) return nullptr;
+    return "gadget (l, Bgbit) outside the exact range of every blind-rotate kernel form (br_forms.hpp)";
 }
 
 DeviceKeyImage *Engine::upload_key(const TfheHipCloudKey &ck) {
     ensure_init();
     const Params &p = ck.p;
-    if ((p.N != 1024 && p.N != 2048) || p.k != 1)
-        fatal("the blind-rotate kernels are built for N = 1024 or 2048 and k = 1 (got N=" + std::to_string(p.N) +
-              ", k=" + std::to_string(p.k) + ")");
-    if (p.n > 1024 || p.ct_stride() / 4 > 320) fatal("n > 1024 unsupported");
-    if (p.l * p.Bgbit > 32 || p.Bgbit > 12) fatal("gadget digits must fit 12 bits");
-    // exactness of the CRT range: (k+1) l N (Bg/2) 2^31 must stay below P0*P1/2
-    const double bound = (double)(p.k + 1) * p.l * p.N * (double)(1u << (p.Bgbit - 1)) * 2147483648.0;
-    if (bound >= (double)CRT_HALF) fatal("gadget parameters exceed the exact range of the two-prime NTT");
-    // forward NTT input digits must be < P in magnitude; pointwise sum must fit 64 bits
+    // a parameter set the kernels cannot run exactly is refused (the call that needed the key has no effect and
+    // tfhe_hip_last_error() says why): a custom tuple or a loaded file may carry anything
+    if (const char *why = unsupported_reason(p)) api_fail(why);
     auto *img = new DeviceKeyImage();
     img->dp = make_dev_params(p);
+    for (int f = 0; f < BR_FORM_COUNT; ++f)
+        for (int t = 0; t < 3; ++t) img->form_ok[f][t] = br_form_admissible(f, p.N, p.l, p.Bgbit, t);
     uint32_t scale[2];
     const std::vector<uint32_t> tw = make_twiddles(p.N, scale);
     hip_check(hipMalloc(reinterpret_cast<void **>(&img->tw), tw.size() * 4), "hipMalloc(tw)");
@@ -338,35 +353,66 @@ void Engine::read_slots_packed(SlotPool *pool, const int32_t *slots, int count, 
 bool Engine::launch_br(const DeviceKeyImage *key, const int32_t *pool, const RotDesc *rots, int count, int32_t *u_buf,
                        int32_t *acc_dbg, hipStream_t stream, int wave_prio) {
     if (!stream) stream = stream_;
-    if (count <= br4_max_rotations) {
-        DevParams dp = key->dp;
-        dp.wave_prio = wave_prio;
-        dp.br_variant = dp.N == 1024 && br_variant == 1 ? 1 : 0;
-        dp.digit_table = br_digit_table;
-        if (br_variant == 2 || (br_variant < 0 && dp.N == 2048 && br_split_auto_2048)) {
-            launch_blind_rotate_split(stream, dp, key->key, pool, rots, count, u_buf, acc_dbg);
-            return false;
+    DevParams dp = key->dp;
+    // the form the tunings ask for ...
+    int form;
+    if (count > br4_max_rotations) form = dp.N == 1024 ? BR_FORM_WAVE2 : BR_FORM_LEAN4;
+    else if (br_variant == 2 || (br_variant < 0 && dp.N == 2048 && br_split_auto_2048)) form = BR_FORM_SPLIT;
+    // launches that leave CUs with at most one workgroup: the 8-wave form (a second wave per SIMD)
+    else if (br8_max_rotations > 0 && count <= std::min(br8_max_rotations, cu_count_) && dp.N == 1024 && dp.l >= 2 && !wg_times_dbg_)
+        form = BR_FORM_WAVE8;
+    else form = dp.N == 1024 && br_variant != 1 ? BR_FORM_WIDE4 : BR_FORM_LEAN4;
+    // the workgroup-time probe reads stamps only the 4-wave kernel writes
+    if (wg_times_dbg_ && form != BR_FORM_WIDE4 && form != BR_FORM_LEAN4) form = dp.N == 1024 ? BR_FORM_WIDE4 : BR_FORM_LEAN4;
+    // ... if its magnitude bounds hold for this key's gadget (br_forms.hpp; every built-in set passes everywhere
+    // except l = 3 in the 4-wave form at N = 2048); else the same form with smaller or no digit tables, else another form
+    int tables = br_digit_table < 0 || br_digit_table > 2 ? 0 : br_digit_table;
+    if (!key->form_ok[form][tables]) {
+        static const int order[BR_FORM_COUNT] = {BR_FORM_WIDE4, BR_FORM_SPLIT, BR_FORM_LEAN4, BR_FORM_WAVE2, BR_FORM_WAVE8};
+        int pick_f = -1, pick_t = 0;
+        for (int k = -1; k < BR_FORM_COUNT && pick_f < 0; ++k) {
+            const int f = k < 0 ? form : order[k];
+            if (f == BR_FORM_WAVE8 && count > cu_count_) continue;          // its LDS allows one workgroup per CU only
+            for (int t : {tables, 2, 0})
+                if (key->form_ok[f][t]) { pick_f = f; pick_t = t; break; }
         }
-        if (br_fair > 0 && count > cu_count_) {                   // only launches that put several workgroups on a CU
-            if (!cu_arrivals_) {
-                hip_check(hipMalloc(&cu_arrivals_, 4096 * sizeof(uint32_t)), "hipMalloc(cu arrivals)");
-                hip_check(hipMemset(cu_arrivals_, 0, 4096 * sizeof(uint32_t)), "hipMemset(cu arrivals)");
-            }
-            dp.fair_shift = br_fair;
-            dp.cu_arrivals = cu_arrivals_;
+        if (pick_f < 0) fatal("no admissible blind-rotate form (upload_key should have refused this key)");
+        form = pick_f; tables = pick_t;
+    }
+    dp.wave_prio = wave_prio;
+    dp.digit_table = tables;
+    dp.br_variant = dp.N == 1024 && form == BR_FORM_LEAN4 ? 1 : 0;
+    if (kernel_timing) {
+        if (!clock_acc_) {
+            hip_check(hipMalloc(&clock_acc_, 2 * sizeof(unsigned long long)), "hipMalloc(clock sums)");
+            hip_check(hipMemset(clock_acc_, 0, 2 * sizeof(unsigned long long)), "hipMemset(clock sums)");
         }
-        dp.wg_times = wg_times_dbg_;
-        // launches that leave CUs with at most one workgroup: the 8-wave form (a second wave per SIMD)
-        if (br8_max_rotations > 0 && count <= std::min(br8_max_rotations, cu_count_) && dp.N == 1024 && dp.l >= 2 && !wg_times_dbg_) {
-            launch_blind_rotate8(stream, dp, key->key, pool, rots, count, u_buf, acc_dbg);
-            return true;
-        }
-        launch_blind_rotate4(stream, dp, key->key, pool, rots, count, u_buf, acc_dbg);
+        dp.clock_acc = clock_acc_;
+    }
+    if (form == BR_FORM_WAVE2) {
+        // (splitting a short last round off to the latency kernel was measured: the kernel
+        // boundary costs more overlap than the faster tail gains -- match 3.99 s -> 4.15 s)
+        launch_blind_rotate(stream, dp, key->key, pool, rots, count, u_buf, acc_dbg);
         return false;
     }
-    // (splitting a short last round off to the latency kernel was measured: the kernel
-    // boundary costs more overlap than the faster tail gains -- match 3.99 s -> 4.15 s)
-    launch_blind_rotate(stream, key->dp, key->key, pool, rots, count, u_buf, acc_dbg);
+    if (form == BR_FORM_SPLIT) {
+        launch_blind_rotate_split(stream, dp, key->key, pool, rots, count, u_buf, acc_dbg);
+        return false;
+    }
+    if (br_fair > 0 && count > cu_count_) {                   // only launches that put several workgroups on a CU
+        if (!cu_arrivals_) {
+            hip_check(hipMalloc(&cu_arrivals_, 4096 * sizeof(uint32_t)), "hipMalloc(cu arrivals)");
+            hip_check(hipMemset(cu_arrivals_, 0, 4096 * sizeof(uint32_t)), "hipMemset(cu arrivals)");
+        }
+        dp.fair_shift = br_fair;
+        dp.cu_arrivals = cu_arrivals_;
+    }
+    dp.wg_times = wg_times_dbg_;
+    if (form == BR_FORM_WAVE8) {
+        launch_blind_rotate8(stream, dp, key->key, pool, rots, count, u_buf, acc_dbg);
+        return true;
+    }
+    launch_blind_rotate4(stream, dp, key->key, pool, rots, count, u_buf, acc_dbg);
     return false;
 }
 
@@ -405,8 +451,9 @@ void Engine::launch_ks(const DeviceKeyImage *key, const int32_t *u_buf, const Ks
             while (splits < ks_max_splits && cnt * splits * 2 <= ks_target_blocks) splits *= 2;
         }
         int32_t *partial = nullptr;
-        if (splits > 1) partial = static_cast<int32_t *>(scratch(10 + (size_t)lane, (size_t)cnt * splits * dp.ct_stride * 4));
-        launch_keyswitch(stream, dp, key->key, u_buf, descs + done, cnt, pool, splits, partial, tiled ? ks_tile : 0);
+        if (splits > 1 && !ks_atomic) partial = static_cast<int32_t *>(scratch(10 + (size_t)lane, (size_t)cnt * splits * dp.ct_stride * 4));
+        launch_keyswitch(stream, dp, key->key, u_buf, descs + done, cnt, pool, splits, partial, tiled ? ks_tile : 0,
+                         ks_atomic != 0);
     }
 }
 
@@ -560,6 +607,13 @@ void Engine::execute(const DeviceKeyImage *key, SlotPool *pool, const LevelPlan 
         if (cur_b >= cur_a) stats.ms_blind_rotate_busy += cur_b - cur_a;
         if (tf) std::fclose(tf);
     }
+    if (kernel_timing && clock_acc_) {
+        unsigned long long sums[2] = {0, 0};
+        hip_check(hipMemcpy(sums, clock_acc_, sizeof sums, hipMemcpyDeviceToHost), "read clock sums");
+        hip_check(hipMemset(clock_acc_, 0, sizeof sums), "clear clock sums");
+        stats.clk_shader_cycles += sums[0];
+        stats.clk_ref_ticks += sums[1];
+    }
     stats.levels += (uint64_t)levels;
     ++stats.flushes;
     stats.ms_flush_wall += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
@@ -711,6 +765,9 @@ double Engine::run_lane_probe(const DeviceKeyImage *key, int lanes, int levels, 
             launch_br(key, pool, drots, warm_width, ubuf[0], nullptr, st[0]);
             if (warm_ks) launch_ks(key, ubuf[0], dks, warm_width, pool, st[0], 0);
         }
+        // stamps come from the 4-wave kernel only (launch_br forces it while the probe is armed); cleared first so
+        // that a launch which wrote none is noticed instead of read as timings
+        hip_check(hipMemsetAsync(dtimes, 0, (size_t)4 * width * 8, st[0]), "clear stamps");
         wg_times_dbg_ = dtimes;
         hip_check(hipEventRecord(e0, st[0]), "probe event record");
         launch_br(key, pool, drots, width, ubuf[0], nullptr, st[0]);
@@ -722,6 +779,8 @@ double Engine::run_lane_probe(const DeviceKeyImage *key, int lanes, int levels, 
         (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
         hip_check(hipMemcpy(wg_times, dtimes, (size_t)4 * width * 8, hipMemcpyDeviceToHost), "probe stamps copy");
         for (int s = 0; s < lanes; ++s) hip_check(hipStreamDestroy(st[s]), "probe stream destroy");
+        for (int i = 0; i < width; ++i)
+            if (wg_times[4 * i] == 0 || wg_times[4 * i + 1] == 0) return -1.0;      // a workgroup left no stamp
         return (double)ems;
     }
     hip_check(hipDeviceSynchronize(), "probe sync");

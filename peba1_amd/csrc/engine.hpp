@@ -15,6 +15,8 @@
 struct DeviceKeyImage {
     tfhe_hip::DevParams dp;
     tfhe_hip::DevKey key;
+    // form_ok[form][tables]: the kernel form's magnitude bounds hold for this key's (l, Bgbit) (br_forms.hpp)
+    bool form_ok[5][3] = {};
     uint32_t *bk_img = nullptr;
     int32_t *ksk = nullptr;
     uint32_t *tw = nullptr;
@@ -26,6 +28,7 @@ void set_error(const std::string &msg);
 const std::string &last_error_ref();
 [[noreturn]] void fatal(const std::string &msg);
 void hip_check(hipError_t e, const char *what);
+const char *unsupported_reason(const Params &p);   // why the kernels cannot run this parameter set exactly, or null
 
 // A condition the caller can recover from (slot pool exhausted, a sample this library did not
 // allocate, a sample used with a key of another LWE dimension, a malformed file): thrown inside
@@ -122,6 +125,9 @@ public:
     int ks_max_splits = 32;
     // gates per workgroup of the tiled key switch (16 or 32; 0 = per-gate kernel only)
     int ks_tile = 16;
+    // 1 = the coefficient ranges of a key switch add their partial sums into the (zeroed) destination slot with
+    // 32-bit atomic adds instead of writing them out for a reduce launch (env TFHE_HIP_KS_ATOMIC, tuning "ks_atomic")
+    int ks_atomic = 0;
     // two-lane execution: 1 = the urgent lane's blind-rotate waves raise their issue priority
     // (measured slower: the co-resident workgroups of the other lane become its stragglers)
     int lane_prio = 0;
@@ -162,6 +168,7 @@ private:
     bool inited_ = false;
     hipStream_t stream_ = nullptr;
     uint32_t *cu_arrivals_ = nullptr;
+    unsigned long long *clock_acc_ = nullptr;           // kernel timing: shader-cycle / reference-tick sums (kernels.hpp)
     unsigned long long *wg_times_dbg_ = nullptr;        // set by the workgroup-time probe only
     hipStream_t lane_stream_[2] = {nullptr, nullptr};   // lane 0 = stream_, lane 1 created on first use
     std::vector<hipEvent_t> order_events_;              // cross-lane ordering, no timing

@@ -11,6 +11,7 @@
 
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <ctime>
 #include <sys/random.h>
@@ -18,19 +19,20 @@
 
 namespace tfhe_hip {
 
-uint64_t os_entropy() {
-    uint64_t v = 0;
-    if (getrandom(&v, sizeof v, 0) == (ssize_t)sizeof v) return v;
-    if (FILE *f = std::fopen("/dev/urandom", "rb")) {
-        const size_t got = std::fread(&v, 1, sizeof v, f);
-        std::fclose(f);
-        if (got == sizeof v) return v;
+bool os_random(void *out, size_t bytes) {
+    unsigned char *p = static_cast<unsigned char *>(out);
+    size_t got = 0;
+    while (got < bytes) {
+        const ssize_t r = getrandom(p + got, bytes - got, 0);
+        if (r <= 0) break;
+        got += (size_t)r;
     }
-    // no entropy source at all: better than a constant, and said so
-    std::fprintf(stderr, "libtfhe-hip: warning: no OS entropy source, seeding from clock and pid\n");
-    struct timespec ts;
-    clock_gettime(CLOCK_REALTIME, &ts);
-    return ((uint64_t)ts.tv_sec << 32) ^ (uint64_t)ts.tv_nsec ^ ((uint64_t)getpid() << 20);
+    if (got == bytes) return true;
+    if (FILE *f = std::fopen("/dev/urandom", "rb")) {
+        got = std::fread(p, 1, bytes, f);
+        std::fclose(f);
+    }
+    return got == bytes;
 }
 
 uint32_t Params::decomp_offset() const {
@@ -87,6 +89,7 @@ const Params &params_of(const TFheGateBootstrappingParameterSet *set) {
 static inline uint64_t rotl(uint64_t x, int k) { return (x << k) | (x >> (64 - k)); }
 
 void Rng::reseed(uint64_t seed) {
+    chacha_ = false;
     uint64_t z = seed;
     for (auto &word : s_) {
         z += 0x9E3779B97F4A7C15ULL;
@@ -97,7 +100,63 @@ void Rng::reseed(uint64_t seed) {
     }
 }
 
+Rng Rng::secure() {
+    Rng r(0);
+    uint32_t seed[10];
+    if (!os_random(seed, sizeof seed)) {
+        // a keyset or an encryption without entropy would be worthless: stop, like upstream's fatal paths
+        std::fprintf(stderr, "libtfhe-hip: fatal: the operating system offers no entropy (getrandom, /dev/urandom)\n");
+        std::abort();
+    }
+    std::memcpy(r.key_, seed, sizeof r.key_);
+    r.nonce_[0] = seed[8]; r.nonce_[1] = seed[9];
+    r.counter_ = 0;
+    r.pos_ = 16;
+    r.chacha_ = true;
+    return r;
+}
+
+static inline uint32_t rotl32(uint32_t x, int k) { return (x << k) | (x >> (32 - k)); }
+
+// one ChaCha20 block (RFC 8439 section 2.3, with the original 64-bit counter / 64-bit nonce split)
+void Rng::refill() {
+    uint32_t in[16] = {0x61707865u, 0x3320646eu, 0x79622d32u, 0x6b206574u,
+                       key_[0], key_[1], key_[2], key_[3], key_[4], key_[5], key_[6], key_[7],
+                       (uint32_t)counter_, (uint32_t)(counter_ >> 32), nonce_[0], nonce_[1]};
+    uint32_t x[16];
+    std::memcpy(x, in, sizeof x);
+#define CHACHA_QR(a, b, c, d)                      \
+    x[a] += x[b]; x[d] = rotl32(x[d] ^ x[a], 16);  \
+    x[c] += x[d]; x[b] = rotl32(x[b] ^ x[c], 12);  \
+    x[a] += x[b]; x[d] = rotl32(x[d] ^ x[a], 8);   \
+    x[c] += x[d]; x[b] = rotl32(x[b] ^ x[c], 7)
+    for (int round = 0; round < 10; ++round) {
+        CHACHA_QR(0, 4, 8, 12); CHACHA_QR(1, 5, 9, 13); CHACHA_QR(2, 6, 10, 14); CHACHA_QR(3, 7, 11, 15);
+        CHACHA_QR(0, 5, 10, 15); CHACHA_QR(1, 6, 11, 12); CHACHA_QR(2, 7, 8, 13); CHACHA_QR(3, 4, 9, 14);
+    }
+#undef CHACHA_QR
+    for (int i = 0; i < 16; ++i) block_[i] = x[i] + in[i];
+    ++counter_;
+    pos_ = 0;
+}
+
+void Rng::chacha_block(const uint32_t key[8], uint64_t counter, const uint32_t nonce[2], uint32_t out[16]) {
+    Rng r(0);
+    std::memcpy(r.key_, key, sizeof r.key_);
+    r.nonce_[0] = nonce[0]; r.nonce_[1] = nonce[1];
+    r.counter_ = counter;
+    r.chacha_ = true;
+    r.refill();
+    std::memcpy(out, r.block_, sizeof r.block_);
+}
+
 uint64_t Rng::next() {
+    if (chacha_) {
+        if (pos_ >= 16) refill();
+        const uint64_t v = (uint64_t)block_[pos_] | ((uint64_t)block_[pos_ + 1] << 32);
+        pos_ += 2;
+        return v;
+    }
     const uint64_t result = rotl(s_[1] * 5, 7) * 9;
     const uint64_t t = s_[1] << 17;
     s_[2] ^= s_[0]; s_[3] ^= s_[1]; s_[1] ^= s_[2]; s_[0] ^= s_[3];
@@ -123,14 +182,13 @@ static void add_mul_by_bits(uint32_t *body, const uint32_t *mask, const int32_t 
     }
 }
 
-void generate_keys(const Params &p, uint64_t seed, TfheHipSecretKey &sk, TfheHipCloudKey &ck) {
-    Rng rng(seed);
+void generate_keys(const Params &p, Rng &secret, Rng &mask, TfheHipSecretKey &sk, TfheHipCloudKey &ck) {
     const int n = p.n, N = p.N, k = p.k, l = p.l, kpl = p.kpl(), t = p.ks_t, base = 1 << p.ks_basebit;
     sk.p = p; ck.p = p;
     sk.lwe_key.resize(n);
-    for (auto &b : sk.lwe_key) b = rng.bit();
+    for (auto &b : sk.lwe_key) b = secret.bit();
     sk.tlwe_key.resize((size_t)k * N);
-    for (auto &b : sk.tlwe_key) b = rng.bit();
+    for (auto &b : sk.tlwe_key) b = secret.bit();
 
     // bootstrapping key: BK_i = TGSW_{tlwe_key}(lwe_key[i])
     ck.bk.assign(p.bk_words(), 0);
@@ -139,8 +197,8 @@ void generate_keys(const Params &p, uint64_t seed, TfheHipSecretKey &sk, TfheHip
             uint32_t *smp = reinterpret_cast<uint32_t *>(ck.bk.data()) + ((size_t)i * kpl + row) * (size_t)(k + 1) * N;
             uint32_t *body = smp + (size_t)k * N;
             for (int u = 0; u < k; ++u)
-                for (int j = 0; j < N; ++j) smp[(size_t)u * N + j] = (uint32_t)rng.torus();
-            for (int j = 0; j < N; ++j) body[j] = (uint32_t)dtot32(rng.gauss(p.bk_stdev));
+                for (int j = 0; j < N; ++j) smp[(size_t)u * N + j] = (uint32_t)mask.torus();
+            for (int j = 0; j < N; ++j) body[j] = (uint32_t)dtot32(secret.gauss(p.bk_stdev));
             for (int u = 0; u < k; ++u) add_mul_by_bits(body, smp + (size_t)u * N, sk.tlwe_key.data() + (size_t)u * N, N);
             const int bloc = row / l, jj = row % l;
             smp[(size_t)bloc * N] += (uint32_t)sk.lwe_key[i] << (32 - (jj + 1) * p.Bgbit);
@@ -154,20 +212,20 @@ void generate_keys(const Params &p, uint64_t seed, TfheHipSecretKey &sk, TfheHip
                 uint32_t *row = reinterpret_cast<uint32_t *>(ck.ksk.data()) + (((size_t)i * t + j) * base + v) * (size_t)(n + 1);
                 uint32_t b = 0;
                 for (int q = 0; q < n; ++q) {
-                    row[q] = (uint32_t)rng.torus();
+                    row[q] = (uint32_t)mask.torus();
                     b += row[q] * (uint32_t)sk.lwe_key[q];
                 }
                 b += (uint32_t)(sk.tlwe_key[i] * v) << (32 - (j + 1) * p.ks_basebit);
-                b += (uint32_t)dtot32(rng.gauss(p.ks_stdev));
+                b += (uint32_t)dtot32(secret.gauss(p.ks_stdev));
                 row[n] = b;
             }
 }
 
-void encrypt_bit(const TfheHipSecretKey &sk, Rng &rng, int32_t message, Torus32 *a, Torus32 *b) {
+void encrypt_bit(const TfheHipSecretKey &sk, Rng &secret, Rng &mask, int32_t message, Torus32 *a, Torus32 *b) {
     const uint32_t mu = message ? (1u << 29) : 0u - (1u << 29);
-    uint32_t body = mu + (uint32_t)dtot32(rng.gauss(sk.p.ks_stdev));
+    uint32_t body = mu + (uint32_t)dtot32(secret.gauss(sk.p.ks_stdev));
     for (int i = 0; i < sk.p.n; ++i) {
-        a[i] = rng.torus();
+        a[i] = mask.torus();
         body += (uint32_t)a[i] * (uint32_t)sk.lwe_key[i];
     }
     *b = (Torus32)body;

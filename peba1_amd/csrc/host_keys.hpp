@@ -37,22 +37,38 @@ const Params &params_of(const TFheGateBootstrappingParameterSet *set);
 bool default_params(int32_t minimum_lambda, Params &out);
 Params p2048_params();
 
-// xoshiro256** seeded through splitmix64 (DESIGN.md "key derivation")
+// Two generators behind one interface.
+//  * Seeded: xoshiro256** seeded through splitmix64 -- the generator of the key-derivation specification that the
+//    product and the test oracle share (DESIGN.md "key derivation"); reproducible, NOT cryptographic; reached only
+//    through tfhe_hip_new_secret_keyset_seeded / tfhe_hip_set_encrypt_seed (tests, golden fixtures).
+//  * Secure (Rng::secure()): the ChaCha20 key stream (RFC 8439 block function, 64-bit block counter) under a 256-bit
+//    key and a 64-bit nonce read from the operating system (getrandom): what new_random_gate_bootstrapping_secret_keyset
+//    and bootsSymEncrypt draw from by default.  Secrets (key bits, noise) and the public masks come from two
+//    independently keyed streams, so the published masks say nothing about the stream the secrets came from.
 class Rng {
 public:
     explicit Rng(uint64_t seed = 0) { reseed(seed); }
-    void reseed(uint64_t seed);
+    static Rng secure();             // aborts with a message if the OS offers no entropy
+    void reseed(uint64_t seed);      // (re)start the seeded generator
     uint64_t next();
     Torus32 torus() { return (Torus32)(uint32_t)(next() >> 32); }
     int32_t bit() { return (int32_t)(next() >> 63); }
     double gauss(double sigma);
+    bool is_secure() const { return chacha_; }
+    // known-answer hook (tests): the key-stream block of (key, counter, nonce)
+    static void chacha_block(const uint32_t key[8], uint64_t counter, const uint32_t nonce[2], uint32_t out[16]);
 private:
-    uint64_t s_[4];
+    void refill();
+    bool chacha_ = false;
+    uint64_t s_[4];                  // xoshiro state
+    uint32_t key_[8], nonce_[2];     // ChaCha20 key and nonce
+    uint64_t counter_ = 0;
+    uint32_t block_[16];
+    int pos_ = 16;                   // next unread word of block_
 };
 Torus32 dtot32(double d);
-// 64 bits from the operating system (getrandom, /dev/urandom as a fallback): the seed of every
-// keyset and of the encryption generator unless the caller fixes one
-uint64_t os_entropy();
+// fills `bytes` bytes from the operating system (getrandom, /dev/urandom as a fallback); false if neither works
+bool os_random(void *out, size_t bytes);
 
 }  // namespace tfhe_hip
 
@@ -72,7 +88,9 @@ struct TfheHipCloudKey {
 };
 
 namespace tfhe_hip {
-void generate_keys(const Params &p, uint64_t seed, TfheHipSecretKey &sk, TfheHipCloudKey &ck);
-void encrypt_bit(const TfheHipSecretKey &sk, Rng &rng, int32_t message, Torus32 *a, Torus32 *b);
+// `secret` yields the key bits and every noise sample, `mask` the public uniform masks.  The seeded path passes ONE
+// generator for both (the draw order of DESIGN.md, which the oracle regenerates); the default path two secure ones.
+void generate_keys(const Params &p, Rng &secret, Rng &mask, TfheHipSecretKey &sk, TfheHipCloudKey &ck);
+void encrypt_bit(const TfheHipSecretKey &sk, Rng &secret, Rng &mask, int32_t message, Torus32 *a, Torus32 *b);
 Torus32 phase_of(const TfheHipSecretKey &sk, const Torus32 *a, Torus32 b);
 }  // namespace tfhe_hip

@@ -3,6 +3,7 @@
 // little endian.
 #include <cstdio>
 #include <cstring>
+#include <exception>
 #include <memory>
 #include <mutex>
 #include <set>
@@ -54,27 +55,46 @@ Params get_params(FILE *F) {
     if (p.n <= 0 || p.n > 4096 || p.N <= 0 || p.N > 65536 || (p.N & (p.N - 1)) || p.k < 1 || p.k > 4 || p.l < 1 || p.Bgbit < 1 ||
         p.l * p.Bgbit > 32 || p.ks_t < 1 || p.ks_basebit < 1 || p.ks_t * p.ks_basebit > 31)
         api_fail("tfhe_io: corrupt parameter record");
+    // the shapes the engine can evaluate (the predicate of Engine::upload_key): a file describing anything else
+    // is refused here, with the reason, instead of loading and failing at the first gate
+    if (const char *why = unsupported_reason(p)) api_fail(std::string("tfhe_io: unsupported parameter set in file: ") + why);
     return p;
 }
 
 template <typename T>
 void put_vec(FILE *F, const std::vector<T> &v) { put(F, v.data(), v.size() * sizeof(T)); }
+// Reads in bounded chunks, growing the vector as the bytes arrive: a short or hostile file whose header promises
+// gigabytes fails at its real end with at most one chunk allocated beyond its content.
 template <typename T>
-void get_vec(FILE *F, std::vector<T> &v, size_t count) { v.resize(count); get(F, v.data(), count * sizeof(T)); }
+void get_vec(FILE *F, std::vector<T> &v, size_t count) {
+    constexpr size_t CHUNK = ((size_t)16 << 20) / sizeof(T);
+    v.clear();
+    for (size_t done = 0; done < count;) {
+        const size_t step = count - done < CHUNK ? count - done : CHUNK;
+        v.resize(done + step);
+        get(F, v.data() + done, step * sizeof(T));
+        done += step;
+    }
+}
 
 // keysets created by the loaders own their parameter bundle (and, for cloud keysets, themselves)
 std::mutex g_mtx;
 std::set<const void *> g_owned_cloud, g_owned_secret;
 
 void put_cloud_payload(FILE *F, const TfheHipCloudKey &ck) { put_params(F, ck.p); put_vec(F, ck.bk); put_vec(F, ck.ksk); }
-TfheHipCloudKey *get_cloud_payload(FILE *F) {
+uint64_t cloud_bytes(const Params &p) { return sizeof(ParamsRecord) + (p.bk_words() + p.ksk_words()) * sizeof(Torus32); }
+// `declared` = the header's payload size (a secret-keyset file carries the two secret keys after the cloud payload); the sizes the
+// file's own parameter record implies must agree with it before anything is allocated
+TfheHipCloudKey *get_cloud_payload(FILE *F, uint64_t declared, bool with_secret_keys) {
     std::unique_ptr<TfheHipCloudKey> ck(new TfheHipCloudKey());
     ck->p = get_params(F);
+    const uint64_t secret_bytes = with_secret_keys ? (uint64_t)(ck->p.n + ck->p.k * ck->p.N) * sizeof(int32_t) : 0;
+    if (declared != cloud_bytes(ck->p) + secret_bytes)
+        api_fail("tfhe_io: payload size does not match the file's parameter record (corrupt file)");
     get_vec(F, ck->bk, ck->p.bk_words());
     get_vec(F, ck->ksk, ck->p.ksk_words());
     return ck.release();
 }
-uint64_t cloud_bytes(const Params &p) { return sizeof(ParamsRecord) + (p.bk_words() + p.ksk_words()) * sizeof(Torus32); }
 
 }  // namespace
 
@@ -91,6 +111,7 @@ auto io_guard(F &&body) -> decltype(body()) {
     try { return body(); }
     catch (const ApiError &e) { set_error(e.msg); return decltype(body())(); }
     catch (const std::bad_alloc &) { set_error("tfhe_io: out of host memory"); return decltype(body())(); }
+    catch (const std::exception &e) { set_error(std::string("tfhe_io: ") + e.what()); return decltype(body())(); }
 }
 struct Done {};   // "void" for io_guard
 
@@ -105,7 +126,7 @@ void export_tfheGateBootstrappingParameterSet_toFile(FILE *F, const TFheGateBoot
 }
 TFheGateBootstrappingParameterSet *new_tfheGateBootstrappingParameterSet_fromFile(FILE *F) {
     return io_guard([&]() -> TFheGateBootstrappingParameterSet * {
-        get_header(F, KIND_PARAMS);
+        if (get_header(F, KIND_PARAMS) != sizeof(ParamsRecord)) api_fail("tfhe_io: corrupt parameter file");
         return &make_param_bundle(get_params(F))->set;
     });
 }
@@ -118,8 +139,8 @@ void export_tfheGateBootstrappingCloudKeySet_toFile(FILE *F, const TFheGateBoots
     });
 }
 static TFheGateBootstrappingCloudKeySet *load_cloud(FILE *F) {
-    get_header(F, KIND_CLOUD);
-    TfheHipCloudKey *ck = get_cloud_payload(F);
+    const uint64_t declared = get_header(F, KIND_CLOUD);
+    TfheHipCloudKey *ck = get_cloud_payload(F, declared, false);
     auto *ks = new TFheGateBootstrappingCloudKeySet();
     ks->params = &make_param_bundle(ck->p)->set;
     ks->bk = ck;
@@ -143,8 +164,8 @@ void export_tfheGateBootstrappingSecretKeySet_toFile(FILE *F, const TFheGateBoot
     });
 }
 static TFheGateBootstrappingSecretKeySet *load_secret(FILE *F) {
-    get_header(F, KIND_SECRET);
-    std::unique_ptr<TfheHipCloudKey> ck(get_cloud_payload(F));
+    const uint64_t declared = get_header(F, KIND_SECRET);
+    std::unique_ptr<TfheHipCloudKey> ck(get_cloud_payload(F, declared, true));
     std::unique_ptr<TfheHipSecretKey> sk(new TfheHipSecretKey());
     sk->p = ck->p;
     get_vec(F, sk->lwe_key, (size_t)ck->p.n);

@@ -173,6 +173,24 @@ __device__ __forceinline__ void prelude_modswitch(const DevParams &p, const RotD
     }
 }
 
+// Shader clock of a launch (bench.py reports it beside the times: the same launch takes 15 % longer at the 2.0 GHz
+// a cold chip runs than at the 2.37 GHz of a warm one): lane 0 of workgroup 0 adds the shader
+// cycles and the 100 MHz reference ticks it lived for to two running sums.
+struct ClockProbe {
+    unsigned long long c0 = 0, r0 = 0;
+    bool on = false;
+    __device__ __forceinline__ void begin(const DevParams &p) {
+        on = p.clock_acc != nullptr && blockIdx.x == 0 && threadIdx.x == 0;
+        if (on) { c0 = __builtin_amdgcn_s_memtime(); r0 = __builtin_amdgcn_s_memrealtime(); }
+    }
+    __device__ __forceinline__ void end(const DevParams &p) {
+        if (on) {
+            atomicAdd(&p.clock_acc[0], __builtin_amdgcn_s_memtime() - c0);
+            atomicAdd(&p.clock_acc[1], __builtin_amdgcn_s_memrealtime() - r0);
+        }
+    }
+};
+
 // body polynomial of ACC = (0, X^{-barb} * (mu + mu X + ... + mu X^{N-1})), coefficient j
 template <int LOGN>
 __device__ __forceinline__ uint32_t testvector_coef(int j, int barb, int32_t mu) {
@@ -615,9 +633,12 @@ __global__ __launch_bounds__(256, (BrTraits<LOGN, V>::WAVES_PER_SIMD)) void blin
                                      ((((xcc & 0xF) << 8) | ((hw >> 8) & 0xFF)) << 48);
         p.wg_times[4 * blockIdx.x + 2] = __builtin_amdgcn_s_memrealtime();       // constant 100 MHz
     }
+    ClockProbe clk;
+    clk.begin(p);
     const RotDesc rd = rots[blockIdx.x];
     blind_rotate4_body<LOGN, V, TAB>(p, key, pool, rd, sh, threadIdx.x, parity);
     extract_sample<LOGN, 256>(p, rd, sh.acc, u_buf, acc_dbg, threadIdx.x);
+    clk.end(p);
     if (p.wg_times && threadIdx.x == 0) {
         p.wg_times[4 * blockIdx.x + 1] = __builtin_amdgcn_s_memtime();
         p.wg_times[4 * blockIdx.x + 3] = __builtin_amdgcn_s_memrealtime();
@@ -667,6 +688,8 @@ __global__ __launch_bounds__(512, 2) void blind_rotate8_kernel(
     uint32_t *scr = sh.scr[wv];
     const int n = p.n;
     const RotDesc rd = rots[blockIdx.x];
+    ClockProbe clk;
+    clk.begin(p);
 
     prelude_modswitch<LOGN, 512>(p, rd, pool, sh.bar, tid);
     if constexpr (TAB) {
@@ -750,6 +773,7 @@ __global__ __launch_bounds__(512, 2) void blind_rotate8_kernel(
         __syncthreads();
     }
     extract_sample<LOGN, 512>(p, rd, sh.acc, u_buf, acc_dbg, tid);
+    clk.end(p);
 }
 
 // ---------------------------------------------------------------------------
@@ -831,6 +855,8 @@ __global__ __launch_bounds__(512, (LOGN == 10 ? 4 : 2)) void blind_rotate_split_
     // stage-0 twiddles (entry 1 of the full-size tables): forward of this wave's prime, inverse of both
     const uint32_t w1 = key.tw[(size_t)(q * 2 + 0) * N + 1];
     const uint32_t iw1_0 = key.tw[(size_t)1 * N + 1], iw1_1 = key.tw[(size_t)3 * N + 1];
+    ClockProbe clk;
+    clk.begin(p);
 
     prelude_modswitch<LOGN, 512>(p, rd, pool, sh.bar, tid);
     if constexpr (TAB) {
@@ -995,6 +1021,7 @@ __global__ __launch_bounds__(512, (LOGN == 10 ? 4 : 2)) void blind_rotate_split_
         __syncthreads();
     }
     extract_sample<LOGN, 512>(p, rd, sh.acc, u_buf, acc_dbg, tid);
+    clk.end(p);
 }
 
 // test kernel: the negacyclic product of negacyclic_kernel through split transforms (4 waves: prime, half)
@@ -1293,9 +1320,25 @@ __global__ __launch_bounds__(KS_MAX_THREADS) void keyswitch_kernel(DevParams p, 
         if (wi == p.n && split == 0) o[e] += su[i1 - i0];
         if (wi > p.n) o[e] = 0;
     }
+    if (splits > 1 && !partial) {                     // accumulate in place (the slot was zeroed by ks_zero_kernel)
+        uint32_t *dst = reinterpret_cast<uint32_t *>(pool + (size_t)d.dst_slot * p.ct_stride) + 4 * tid;
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+            if (4 * tid + e <= p.n) __hip_atomic_fetch_add(dst + e, o[e], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        return;
+    }
     int32_t *dst = splits == 1 ? pool + (size_t)d.dst_slot * p.ct_stride
                                : partial + ((size_t)blockIdx.x * splits + split) * p.ct_stride;
     reinterpret_cast<uint4 *>(dst)[tid] = make_uint4(o[0], o[1], o[2], o[3]);
+}
+
+// in-place accumulation (tuning "ks_atomic"): the destination slots start at zero and every coefficient range
+// adds its partial sum with 32-bit atomic adds -- integer adds commute, so the words are the same whatever the order
+__global__ __launch_bounds__(KS_MAX_THREADS) void ks_zero_kernel(DevParams p, const KsDesc *__restrict__ descs,
+                                                             int32_t *__restrict__ pool) {
+    const int tid = threadIdx.x;
+    if (tid >= (p.ct_stride >> 2)) return;
+    reinterpret_cast<uint4 *>(pool + (size_t)descs[blockIdx.x].dst_slot * p.ct_stride)[tid] = make_uint4(0, 0, 0, 0);
 }
 
 __global__ __launch_bounds__(KS_MAX_THREADS) void ks_reduce_kernel(DevParams p, const KsDesc *__restrict__ descs, int splits,
@@ -1328,10 +1371,10 @@ __global__ __launch_bounds__(KS_MAX_THREADS) void ks_reduce_kernel(DevParams p, 
 // partial sums go through ks_reduce_kernel as above.
 typedef uint32_t v4u32 __attribute__((ext_vector_type(4)));
 
-template <int THREADS, int G>
+template <int THREADS, int G, bool ATOMIC = false>
 __global__ __launch_bounds__(THREADS) void keyswitch_tile_kernel(DevParams p, DevKey key, const int32_t *__restrict__ u_buf,
                                                               const KsDesc *__restrict__ descs, int count,
-                                                              int32_t *__restrict__ partial) {
+                                                              int32_t *__restrict__ partial /* ATOMIC: the slot pool */) {
     constexpr int JB = 4, ROWS = JB * 3, MAXR = 64;
     __shared__ uint4 rows[JB * 4 * THREADS];
     __shared__ __align__(16) uint32_t su[MAXR][G];       // [coefficient][gate]: four gates' digit words per 16-byte read
@@ -1435,8 +1478,15 @@ __global__ __launch_bounds__(THREADS) void keyswitch_tile_kernel(DevParams p, De
             if (wi == p.n && split == 0) o[e] += sbody[g];
             if (wi > p.n) o[e] = 0;
         }
-        reinterpret_cast<uint4 *>(partial + ((size_t)(g0 + g) * splits + split) * p.ct_stride)[tid] =
-            make_uint4(o[0], o[1], o[2], o[3]);
+        if constexpr (ATOMIC) {
+            uint32_t *dst = reinterpret_cast<uint32_t *>(partial + (size_t)descs[g0 + g].dst_slot * p.ct_stride) + 4 * tid;
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+                if (4 * tid + e <= p.n) __hip_atomic_fetch_add(dst + e, o[e], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        } else {
+            reinterpret_cast<uint4 *>(partial + ((size_t)(g0 + g) * splits + split) * p.ct_stride)[tid] =
+                make_uint4(o[0], o[1], o[2], o[3]);
+        }
     }
 }
 
@@ -1559,17 +1609,22 @@ void launch_gate_dataflow(hipStream_t s, const DevParams &p, const DevKey &key, 
 #endif
 
 void launch_keyswitch(hipStream_t s, const DevParams &p, const DevKey &key, const int32_t *u_buf,
-                      const KsDesc *descs, int count, int32_t *pool, int splits, int32_t *partial, int tile) {
+                      const KsDesc *descs, int count, int32_t *pool, int splits, int32_t *partial, int tile, bool atomic) {
     if (count <= 0) return;
     const int threads = ((p.ct_stride / 4 + 63) / 64) * 64;      // one 16-byte lane per 4 output words
-    if (splits <= 1 || !partial) {
+    if (splits <= 1 || (!partial && !atomic)) {
         hipLaunchKernelGGL(keyswitch_kernel, dim3(count, 1), dim3(threads), 0, s, p, key, u_buf, descs, pool, nullptr);
         return;
     }
+    if (atomic) hipLaunchKernelGGL(ks_zero_kernel, dim3(count), dim3(threads), 0, s, p, descs, pool);
     const int range = (p.k * p.N + splits - 1) / splits;
     if (tile > 0 && count >= 2 * tile && p.ks_t == 8 && p.ks_basebit == 2 && range <= 64 && (tile == 16 || tile == 32)) {
         const dim3 grid((count + tile - 1) / tile, splits);
-#define KS_TILE(T, GT) hipLaunchKernelGGL((keyswitch_tile_kernel<T, GT>), grid, dim3(T), 0, s, p, key, u_buf, descs, count, partial)
+#define KS_TILE(T, GT)                                                                                                      \
+    do {                                                                                                                    \
+        if (atomic) hipLaunchKernelGGL((keyswitch_tile_kernel<T, GT, true>), grid, dim3(T), 0, s, p, key, u_buf, descs, count, pool); \
+        else hipLaunchKernelGGL((keyswitch_tile_kernel<T, GT, false>), grid, dim3(T), 0, s, p, key, u_buf, descs, count, partial);    \
+    } while (0)
         if (tile == 16) {
             if (threads == 128) KS_TILE(128, 16); else if (threads == 192) KS_TILE(192, 16); else if (threads == 320) KS_TILE(320, 16); else tile = 0;
         } else {
@@ -1580,8 +1635,9 @@ void launch_keyswitch(hipStream_t s, const DevParams &p, const DevKey &key, cons
         tile = 0;
     }
     if (tile == 0)
-        hipLaunchKernelGGL(keyswitch_kernel, dim3(count, splits), dim3(threads), 0, s, p, key, u_buf, descs, pool, partial);
-    hipLaunchKernelGGL(ks_reduce_kernel, dim3(count), dim3(threads), 0, s, p, descs, splits, partial, pool);
+        hipLaunchKernelGGL(keyswitch_kernel, dim3(count, splits), dim3(threads), 0, s, p, key, u_buf, descs, pool,
+                           atomic ? nullptr : partial);
+    if (!atomic) hipLaunchKernelGGL(ks_reduce_kernel, dim3(count), dim3(threads), 0, s, p, descs, splits, partial, pool);
 }
 
 void launch_not(hipStream_t s, const DevParams &p, const NotDesc *descs, int count, int32_t *pool) {

@@ -20,6 +20,9 @@ struct DevParams {
     int32_t br_variant;     // N = 1024: 0 = wide form (2 workgroups per CU), 1 = lean form (3 per CU); kernels.hip BrTraits
                             // (2 = split transforms: only read by the negacyclic test launcher)
     uint32_t *cu_arrivals;  // [4096] arrival counters per CU (never reset: only the parity of the arrival order is used)
+    unsigned long long *clock_acc;  // kernel timing: [2] running sums of shader cycles (s_memtime) and of 100 MHz ticks
+                                    // (s_memrealtime) over workgroup 0 of every blind-rotate launch -> the shader
+                                    // clock the launches ran at; or null
     unsigned long long *wg_times;   // diagnostic: [4 * grid] s_memtime (shader cycles) at workgroup start and end, then
                                     // s_memrealtime (100 MHz) at start and end; or null
 };
@@ -84,8 +87,11 @@ void launch_blind_rotate_split(hipStream_t s, const DevParams &p, const DevKey &
 // (partial sums in `partial[count][splits][ct_stride]`, then a reduce launch).  tile = 16 or
 // 32: launches of at least 2*tile gates use the tiled kernel (one pass over the KSK rows of
 // a range serves `tile` gates); 0 = always one workgroup per (gate, range)
+// atomic: no partial-sum buffer and no reduce launch -- the destination slots are zeroed by a small launch and
+// every range adds its sum with 32-bit atomic adds (tuning "ks_atomic"; same words: integer adds commute)
 void launch_keyswitch(hipStream_t s, const DevParams &p, const DevKey &key, const int32_t *u_buf,
-                      const KsDesc *descs, int count, int32_t *pool, int splits, int32_t *partial, int tile);
+                      const KsDesc *descs, int count, int32_t *pool, int splits, int32_t *partial, int tile,
+                      bool atomic = false);
 void launch_not(hipStream_t s, const DevParams &p, const NotDesc *descs, int count, int32_t *pool);
 // res[c] = ip[c] * (poly whose image is img[c]) through the device NTT
 void launch_negacyclic(hipStream_t s, const DevParams &p, const uint32_t *tw, const int32_t *ip,

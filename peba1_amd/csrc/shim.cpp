@@ -23,6 +23,7 @@
 #include <unordered_map>
 #include <vector>
 
+#include "br_forms.hpp"
 #include "engine.hpp"
 #include "scheduler.hpp"
 #include "../../include/tfhe/tfhe.h"
@@ -98,9 +99,11 @@ struct Recorder {
     SlotPool *pool = nullptr;
     std::vector<PendingOp> ops;
     int32_t max_level = 0;
-    // Encryption masks and the default keygen draw from OS entropy, as a drop-in for upstream's
-    // API must; fixed seeds exist only behind tfhe_hip_set_encrypt_seed / tfhe_hip_new_secret_keyset_seeded.
-    Rng enc_rng{os_entropy()};
+    // bootsSymEncrypt and the default keygen draw from two ChaCha20 streams keyed by the OS (host_keys.hpp: one for
+    // the noise / the secrets, one for the public masks); after tfhe_hip_set_encrypt_seed both roles fall to ONE
+    // seeded xoshiro generator (enc_secret; the specified draw order of the fixtures).
+    Rng enc_secret = Rng::secure(), enc_mask = Rng::secure();
+    bool enc_seeded = false;
     bool balance_levels = true;   // slack-aware level filling (scheduler.hpp)
 #ifdef TFHE_HIP_EXPERIMENTAL      // executors that measured slower than per-level launches
     bool dataflow = false;        // opt-in: one dataflow launch per flush instead of per-level launches
@@ -456,14 +459,30 @@ void delete_gate_bootstrapping_parameters(TFheGateBootstrappingParameterSet *par
     delete reinterpret_cast<ParamBundle *>(params);
 }
 
-static TFheGateBootstrappingSecretKeySet *make_keyset(const TFheGateBootstrappingParameterSet *params, uint64_t seed,
+// seed == nullptr: secrets and masks from two ChaCha20 streams keyed by the OS; else the seeded generator (fixtures)
+static TFheGateBootstrappingSecretKeySet *make_keyset(const TFheGateBootstrappingParameterSet *params, const uint64_t *seed,
                                                       bool device) {
     if (!params) { set_error("null params"); return nullptr; }
     const Params &p = params_of(params);
     auto *sk = new TfheHipSecretKey();
     auto *ck = new TfheHipCloudKey();
-    generate_keys(p, seed, *sk, *ck);
-    if (device) ck->dev = Engine::get().upload_key(*ck);
+    if (seed) {
+        Rng both(*seed);
+        generate_keys(p, both, both, *sk, *ck);
+    } else {
+        Rng secret = Rng::secure(), mask = Rng::secure();
+        generate_keys(p, secret, mask, *sk, *ck);
+    }
+    if (device) {
+        try {
+            ck->dev = Engine::get().upload_key(*ck);
+        } catch (const ApiError &e) {       // a parameter set the kernels cannot run exactly: no keyset, and why
+            set_error(e.msg);
+            delete sk;
+            delete ck;
+            return nullptr;
+        }
+    }
     auto *ks = new TFheGateBootstrappingSecretKeySet();
     ks->params = params;
     ks->lwe_key = sk;
@@ -475,9 +494,9 @@ static TFheGateBootstrappingSecretKeySet *make_keyset(const TFheGateBootstrappin
 }
 
 TFheGateBootstrappingSecretKeySet *new_random_gate_bootstrapping_secret_keyset(const TFheGateBootstrappingParameterSet *params) {
-    // upstream draws from its global generator; here every keyset is seeded from OS entropy
-    // (reproducible keys: tfhe_hip_new_secret_keyset_seeded)
-    return make_keyset(params, os_entropy(), true);
+    // upstream draws from its global generator; here every keyset comes from ChaCha20 streams keyed with 256 bits
+    // of OS entropy each (reproducible keys: tfhe_hip_new_secret_keyset_seeded)
+    return make_keyset(params, nullptr, true);
 }
 
 void delete_gate_bootstrapping_secret_keyset(TFheGateBootstrappingSecretKeySet *keyset) {
@@ -557,7 +576,7 @@ void bootsSymEncrypt(LweSample *result, int32_t message, const TFheGateBootstrap
         Recorder &r = rec();
         std::lock_guard<std::recursive_mutex> g(r.mtx);
         drop_slot(result);
-        encrypt_bit(*key->lwe_key, r.enc_rng, message, result->a, &result->b);
+        encrypt_bit(*key->lwe_key, r.enc_secret, r.enc_seeded ? r.enc_secret : r.enc_mask, message, result->a, &result->b);
     });
 }
 
@@ -720,15 +739,24 @@ TFheGateBootstrappingParameterSet *tfhe_hip_new_parameters(int32_t n, int32_t N,
 TFheGateBootstrappingParameterSet *tfhe_hip_new_p2048_parameters(void) { return &make_param_bundle(p2048_params())->set; }
 
 TFheGateBootstrappingSecretKeySet *tfhe_hip_new_secret_keyset_seeded(const TFheGateBootstrappingParameterSet *params, uint64_t seed) {
-    return make_keyset(params, seed, true);
+    return make_keyset(params, &seed, true);
 }
 TFheGateBootstrappingSecretKeySet *tfhe_hip_new_secret_keyset_seeded_host(const TFheGateBootstrappingParameterSet *params, uint64_t seed) {
-    return make_keyset(params, seed, false);
+    return make_keyset(params, &seed, false);
+}
+void tfhe_hip_test_chacha20_block(const uint32_t *key8, uint64_t counter, const uint32_t *nonce2, uint32_t *out16) {
+    Rng::chacha_block(key8, counter, nonce2, out16);
+}
+int tfhe_hip_randomness_is_seeded(void) {
+    Recorder &r = rec();
+    std::lock_guard<std::recursive_mutex> g(r.mtx);
+    return r.enc_seeded ? 1 : 0;
 }
 void tfhe_hip_set_encrypt_seed(uint64_t seed) {
     Recorder &r = rec();
     std::lock_guard<std::recursive_mutex> g(r.mtx);
-    r.enc_rng.reseed(seed);
+    r.enc_secret.reseed(seed);
+    r.enc_seeded = true;
 }
 
 const int32_t *tfhe_hip_key_lwe(const TFheGateBootstrappingSecretKeySet *key, int64_t *count) {
@@ -882,6 +910,10 @@ int tfhe_hip_gate_batch(int gate, LweSample *result, const LweSample *a, const L
     return rc;
 }
 
+int tfhe_hip_test_form_admissible(int form, int32_t N, int32_t l, int32_t Bgbit, int tables) {
+    return br_form_admissible(form, N, l, Bgbit, tables) ? 1 : 0;
+}
+
 int tfhe_hip_has_experimental(void) {
 #ifdef TFHE_HIP_EXPERIMENTAL
     return 1;
@@ -898,6 +930,7 @@ int tfhe_hip_set_tuning(const char *name, int64_t value) {
         Engine::get().ks_tile = (int)value;
         return 0;
     }
+    if (name && std::strcmp(name, "ks_atomic") == 0) { Engine::get().ks_atomic = value != 0; return 0; }
     if (name && std::strcmp(name, "br_fair") == 0) { Engine::get().br_fair = (int)value; return 0; }
     if (name && std::strcmp(name, "br_digit_table") == 0) { Engine::get().br_digit_table = (int)value; return 0; }
     if (name && std::strcmp(name, "br8_max_rotations") == 0) { Engine::get().br8_max_rotations = (int)value; return 0; }
@@ -978,6 +1011,7 @@ int tfhe_hip_test_wg_times(const TFheGateBootstrappingCloudKeySet *bk, int32_t w
     pool_of_key(bk);
     const double ms = Engine::get().run_lane_probe(bk->bk->dev, 1, 1, width, reinterpret_cast<unsigned long long *>(times4));
     if (launch_ms) *launch_ms = ms;
+    if (ms < 0) { set_error("wg_times: the launched kernel form wrote no stamps"); return -1; }
     return 0;
 }
 

@@ -50,7 +50,8 @@ class Stats(C.Structure):
                 ("levels", C.c_uint64), ("flushes", C.c_uint64), ("br_launches", C.c_uint64),
                 ("ms_blind_rotate", C.c_double), ("ms_keyswitch", C.c_double), ("ms_flush_wall", C.c_double),
                 ("ms_blind_rotate_busy", C.c_double), ("reused_gates", C.c_uint64),
-                ("br8_launches", C.c_uint64), ("br8_rotations", C.c_uint64), ("ms_blind_rotate8", C.c_double)]
+                ("br8_launches", C.c_uint64), ("br8_rotations", C.c_uint64), ("ms_blind_rotate8", C.c_double),
+                ("clk_shader_cycles", C.c_uint64), ("clk_ref_ticks", C.c_uint64)]
 
 
 PS = C.POINTER(ParameterSet)
@@ -99,6 +100,8 @@ SIGNATURES = {
     "tfhe_hip_new_secret_keyset_seeded": (SK, [PS, C.c_uint64]),
     "tfhe_hip_new_secret_keyset_seeded_host": (SK, [PS, C.c_uint64]),
     "tfhe_hip_set_encrypt_seed": (None, [C.c_uint64]),
+    "tfhe_hip_randomness_is_seeded": (C.c_int, []),
+    "tfhe_hip_test_chacha20_block": (None, [C.POINTER(C.c_uint32), C.c_uint64, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]),
     "tfhe_hip_key_lwe": (I32P, [SK, C.POINTER(C.c_int64)]),
     "tfhe_hip_key_tlwe": (I32P, [SK, C.POINTER(C.c_int64)]),
     "tfhe_hip_key_bk": (I32P, [CK, C.POINTER(C.c_int64)]),
@@ -115,6 +118,7 @@ SIGNATURES = {
     "tfhe_hip_gate_batch": (C.c_int, [C.c_int, LS, LS, LS, C.c_int32, CK]),
     "tfhe_hip_set_tuning": (C.c_int, [C.c_char_p, C.c_int64]),
     "tfhe_hip_has_experimental": (C.c_int, []),
+    "tfhe_hip_test_form_admissible": (C.c_int, [C.c_int, C.c_int32, C.c_int32, C.c_int32, C.c_int]),
     "tfhe_hip_get_stats": (None, [C.POINTER(Stats)]),
     "tfhe_hip_reset_stats": (None, []),
     "tfhe_hip_set_kernel_timing": (None, [C.c_int]),

@@ -189,3 +189,14 @@ def test_pool_size_is_bounded_by_the_gate_key_fields():
     out = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=300)
     assert out.returncode == 0, out.stderr[-3000:]
     assert "TFHE_HIP_POOL_SLOTS out of range" in out.stdout and "BIT 1" in out.stdout
+
+
+def test_gadget_outside_every_kernel_form_is_refused_at_key_upload():
+    """N = 2048, l = 8, Bgbit = 4 passes the CRT range check but exceeds the lazy-arithmetic bounds of every
+    blind-rotate form (br_forms.hpp): the keyset is refused with a message instead of evaluating wrong ciphertexts."""
+    from peba1_amd import api, lib
+    L = lib.load()
+    pp = api.ParameterSet(custom=(8, 2048, 1, 8, 4, 8, 2, 2.0 ** -15, 2.0 ** -25, 0.012467))
+    L.tfhe_hip_clear_error()
+    with pytest.raises(RuntimeError, match="every blind-rotate kernel form"):
+        api.SecretKeySet(pp, 7, device=True)

@@ -152,11 +152,16 @@ def test_tiled_keyswitch_matches_oracle(p128_keys, oracle, tile, count):
     api.set_tuning("ks_tile", tile)
     try:
         got = api.kernel_keyswitch(ks, u)
+        api.set_tuning("ks_atomic", 1)           # ranges accumulate in place: no partial sums, no reduce launch
+        in_place = api.kernel_keyswitch(ks, u)
         api.set_tuning("ks_tile", 0)
+        per_gate_in_place = api.kernel_keyswitch(ks, u)
+        api.set_tuning("ks_atomic", 0)
         per_gate = api.kernel_keyswitch(ks, u)
     finally:
         api.set_tuning("ks_tile", 16)
-    assert (got == per_gate).all()
+        api.set_tuning("ks_atomic", 0)
+    assert (got == per_gate).all() and (in_place == per_gate).all() and (per_gate_in_place == per_gate).all()
     for c in list(range(4)) + [count // 2, count - 2, count - 1]:
         assert (got[c] == oks.keyswitch(u[c])).all(), f"sample {c}"
 
@@ -405,5 +410,51 @@ def test_every_selectable_kernel_form_is_bit_exact(oracle, pname):
             api.set_tuning("br_digit_table", 1)
             api.set_tuning("br4_max_rotations", 1 << 30)
             api.set_tuning("br8_max_rotations", 1 << 30)
+    finally:
+        ks.close()
+
+
+@pytest.mark.parametrize("shape", [(1024, 4, 8), (2048, 6, 4), (1024, 8, 4)])
+def test_custom_gadgets_at_the_limit_of_the_kernel_forms(oracle, shape):
+    """gadgets other than the built-in ones.  l = 4 / Bg = 2^8 (N = 1024) is inside the wide, split, 8-wave
+    and 2-wave forms but not the lean one; N = 2048 / l = 6 / Bg = 2^4 only inside the split form without its
+    eleven-table first step; N = 1024 / l = 8 / Bg = 2^4 only inside the split and 2-wave forms.  Whatever form the
+    tunings ask for, the engine runs an admissible one (br_forms.hpp) and the accumulators are the oracle's."""
+    from peba1_amd import api
+    N, l, Bgbit = shape
+    n = 24                                            # short blind rotation: the gadget is what is under test
+    pp = api.ParameterSet(custom=(n, N, 1, l, Bgbit, 8, 2, 2.0 ** -15, 2.0 ** -25, 0.012467))
+    seed = 0xC0 + l
+    ks = api.SecretKeySet(pp, seed, device=True)
+    oks = oracle.KeySet(oracle.custom_params(n=n, N=N, l=l, Bgbit=Bgbit), seed)
+    try:
+        rng = np.random.default_rng(l)
+        lins = rng.integers(-2**31, 2**31, (300, pp.words), dtype=np.int64).astype(np.int32)
+        want = [oks.bootstrap_woks(lins[c]) for c in (0, 1, 299)]
+        try:
+            for variant, table, br4_max in ((-1, 1, 1 << 30), (0, 1, 1 << 30), (1, 1, 1 << 30), (2, 1, 1 << 30), (2, 0, 1 << 30),
+                                            (-1, 1, 0)):
+                api.set_tuning("br_variant", variant)
+                api.set_tuning("br_digit_table", table)
+                api.set_tuning("br4_max_rotations", br4_max)
+                u = api.kernel_bootstrap_woks(ks, lins)
+                for k, c in enumerate((0, 1, 299)):
+                    assert (u[c] == want[k]).all(), (shape, variant, table, br4_max, c)
+                u8 = api.kernel_bootstrap_woks(ks, lins[:2])            # narrow launch: the 8-wave form where admissible
+                assert (u8[0] == want[0]).all() and (u8[1] == want[1]).all(), (shape, variant, table, "narrow")
+        finally:
+            api.set_tuning("br_variant", -1)
+            api.set_tuning("br_digit_table", 1)
+            api.set_tuning("br4_max_rotations", 1 << 30)
+        # and whole gates through the public API
+        r = oracle.Rng(5)
+        cts = oks.encrypt(r, [1, 0, 1, 1])
+        a = api.CiphertextArray(pp, 2).set_words(cts[0:2])
+        b = api.CiphertextArray(pp, 2).set_words(cts[2:4])
+        res = api.CiphertextArray(pp, 2)
+        api.gate_batch("AND", res, a, b, ks)
+        got = res.words()
+        for i in range(2):
+            assert (got[i] == oks.gate("AND", cts[i], cts[2 + i])).all()
     finally:
         ks.close()

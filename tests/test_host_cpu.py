@@ -200,3 +200,31 @@ def test_missing_library_fails_loudly(monkeypatch, tmp_path):
     monkeypatch.setattr(lib, "LIB_PATH", str(tmp_path / "nope.so"))
     with pytest.raises(RuntimeError, match="no CPU fallback"):
         lib.load()
+
+
+def test_default_randomness_is_chacha20_keyed_by_the_os():
+    """The default generator (keys, noise, masks): RFC 8439 section 2.3.2 known answer of the block function, and
+    two default keysets / encryptions never repeat (64-bit seeded xoshiro was the production default)."""
+    import ctypes as C
+    from peba1_amd import api, lib
+    L = lib.load()
+    key = (C.c_uint32 * 8)(*[int.from_bytes(bytes(range(4 * i, 4 * i + 4)), "little") for i in range(8)])
+    nonce = (C.c_uint32 * 2)(0x4A000000, 0)
+    out = (C.c_uint32 * 16)()
+    L.tfhe_hip_test_chacha20_block(key, 1 | (0x09000000 << 32), nonce, out)
+    assert [f"{w:08x}" for w in out] == ["e4e7f110", "15593bd1", "1fdd0f50", "c47120a3", "c7f4d1c7", "0368c033", "9aaa2204",
+                                          "4e6cd4c3", "466482d2", "09aa9f07", "05d7c214", "a2028bd9", "d19c12b5", "b94e16de",
+                                          "e883d0cb", "4e3c50a2"]
+    # encryption without a fixed seed: masks differ from call to call and from the seeded stream
+    code = ("import sys; sys.path.insert(0, %r)\n"
+            "from peba1_amd import api, lib\n"
+            "L = lib.load(); assert L.tfhe_hip_randomness_is_seeded() == 0\n"
+            "pp = api.ParameterSet(custom=(16, 64, 1, 3, 7, 8, 2, 1e-5, 1e-8, 0.01))\n"
+            "ks = api.SecretKeySet(pp, 5, device=False)\n"
+            "a = api.CiphertextArray(pp, 2).encrypt([1, 1], ks)\n"
+            "w = a.words(); assert (w[0] != w[1]).any(); assert list(a.decrypt(ks)) == [1, 1]\n"
+            "print(w[0, :4].tolist())\n" % ROOT)
+    import sys
+    runs = [subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=120) for _ in range(2)]
+    assert all(r.returncode == 0 for r in runs), runs[0].stderr + runs[1].stderr
+    assert runs[0].stdout != runs[1].stdout                  # two processes, two key streams

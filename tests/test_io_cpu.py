@@ -83,3 +83,42 @@ def test_foreign_or_truncated_file_is_refused(small_key, tmp_path):
     back = api.CloudKeySet.load(tmp_path / "cloud.key")
     assert back.params.n == params.n
     back.close()
+
+
+def test_hostile_headers_fail_fast_and_unsupported_shapes_are_refused(small_key, tmp_path):
+    """(1) a 100-byte file whose parameter record promises gigabytes of key is refused before anything is
+    allocated (payload size vs the record, then bounded chunked reads); (2) a keyset whose shape the engine cannot
+    evaluate (N = 4096, or a gadget outside every kernel form) is refused by the loader with the reason, instead of
+    loading and aborting at the first gate; (3) nothing terminates the process."""
+    import struct
+    import time
+    params, key = small_key
+    key.save_cloud(tmp_path / "cloud.key")
+    blob = (tmp_path / "cloud.key").read_bytes()
+    hdr, rec = blob[:24], blob[24:24 + 56]
+    n, N, k, l, Bgbit, ks_t, ks_basebit, pad = struct.unpack("<8i", rec[:32])
+    assert (n, N, l, Bgbit) == (params.n, params.N, params.l, params.Bgbit)
+
+    def record(**kw):
+        v = dict(n=n, N=N, k=k, l=l, Bgbit=Bgbit, ks_t=ks_t, ks_basebit=ks_basebit, pad=0)
+        v.update(kw)
+        return struct.pack("<8i", *[v[f] for f in ("n", "N", "k", "l", "Bgbit", "ks_t", "ks_basebit", "pad")]) + rec[32:]
+
+    cases = {
+        # the engine's largest shapes, header untouched: payload size disagrees with the record
+        "huge.key": (hdr + record(n=1024, N=2048, l=4, Bgbit=8) + b"\0" * 20, "payload size does not match"),
+        # header forged to agree: the short read is noticed after at most one 16 MB chunk
+        "forged.key": (hdr[:16] + struct.pack("<Q", 56 + 4 * (1024 * 8 * 2 * 2048 + 2048 * ks_t * 4 * 1025))
+                       + record(n=1024, N=2048, l=4, Bgbit=8) + b"\0" * 20, "short read"),
+        "ring4096.key": (hdr + record(N=4096) + blob[80:200], "unsupported parameter set in file"),
+        "gadget.key": (hdr + record(N=2048, l=8, Bgbit=4) + blob[80:200], "every blind-rotate kernel form"),
+    }
+    for name, (data, needle) in cases.items():
+        (tmp_path / name).write_bytes(data)
+        t = time.time()
+        with pytest.raises(ValueError, match=needle):
+            api.CloudKeySet.load(tmp_path / name)
+        assert time.time() - t < 5.0, name
+    back = api.CloudKeySet.load(tmp_path / "cloud.key")                  # still alive and working
+    assert back.params.n == params.n
+    back.close()
