@@ -225,43 +225,25 @@ def main():
     if mode == "match":
         tmpl_vals = base if rank == 0 else identify.synthetic_template(base, rank)
         tmpl = circuits.EncryptedVector(pp, tmpl_vals, bitsize, ks).to_device()
-        gather_buf = None
-        if use_dist:
-            gather_buf = [torch.empty(pp.words, dtype=torch.int32, device=xdev) for _ in range(world)] if rank == 0 else None
-        pending = []        # (send buffer, work handle) of the previous step's gather
+        comm = pd.Comm(dist, torch, xdev) if use_dist else None
+        all_bits = api.CiphertextArray(pp, world) if use_dist and rank == 0 else None
 
         def step():
             rb = api.CiphertextArray(pp, 3 * bitsize)
             circuits.function_f(rb, probe, tmpl, bound, bitsize, ks)   # records ~350k API calls
             api.flush()                                                # levelised batched execution
-            if use_dist:    # the only exchange: match-bit ciphertexts to rank 0 over RCCL
-                # Ordering (both directions): the library exports on its own non-blocking stream and
-                # returns after that stream has been synchronised, so the send buffer is complete before the gather is
-                # enqueued.  The other way round the collective reads the buffer asynchronously on RCCL's stream: the
-                # previous step's gather is waited for before its buffers are dropped or written again, and every
-                # step sends from a buffer of its own.
-                for _, work in pending:
-                    work.wait()
-                if pending and xdev == "cuda":
-                    torch.cuda.current_stream().synchronize()
-                pending.clear()
-                mine = torch.empty(pp.words, dtype=torch.int32, device=xdev)
-                (L.tfhe_hip_export_samples_device if xdev == "cuda" else L.tfhe_hip_export_samples)(
-                    rb.ptr, 1, pp.ptr, ctypes.cast(mine.data_ptr(), ctypes.c_void_p if xdev == "cuda" else lib.I32P))
-                pending.append((mine, dist.gather(mine, gather_buf, dst=0, async_op=True)))
+            if use_dist:
+                # the only exchange: every rank's match-bit ciphertext to rank 0 (libpeba1-dist: RCCL gather enqueued on
+                # the library's own stream between the stream-ordered export and import -- no host wait, and no
+                # buffer of one step is touched by the next before the stream has passed it)
+                pd.gather_samples(comm, all_bits.ptr if rank == 0 else None, rb.ptr, 1, pp.ptr)
             return rb
 
         def check(last):
             bit = int(last.decrypt(ks)[0])
             assert bit == plain_bit(tmpl_vals), f"rank {rank}: match bit {bit}"
-            for _, work in pending:
-                work.wait()
             if use_dist and rank == 0:
-                torch.cuda.synchronize()
-                tmp = api.CiphertextArray(pp, 1)
-                (L.tfhe_hip_import_samples_device if xdev == "cuda" else L.tfhe_hip_import_samples)(
-                    tmp.ptr, 1, pp.ptr, ctypes.cast(gather_buf[0].data_ptr(), ctypes.c_void_p if xdev == "cuda" else lib.I32P))
-                assert (tmp.words()[0] == last.words()[0]).all(), "gathered match-bit ciphertext differs"
+                assert (all_bits.words()[0] == last.words()[0]).all(), "gathered match-bit ciphertext differs"
             return "decrypted match bit of the last timed match == plaintext rule (distance > bound)"
         workload = (f"Function_f: {nslots} slots x {bitsize} bit template match per GPU, every recorded gate executed")
         parallelism, scaling = f"1 match per GPU x {world}", "weak"
@@ -272,32 +254,28 @@ def main():
         tmpl = circuits.EncryptedVector(pp, tmpl_vals, bitsize, ks).to_device()
         S = [a.ptr for a in probe.slots]
         T = [a.ptr for a in tmpl.slots]
-        prov = pd._Provider(L, circuits.load())
+        comm = pd.Comm(dist, torch, xdev) if use_dist else None
         phase_ms = {"ranks": [], "combine": []}
 
         def step():
             if use_dist:
-                mine = pd.local_partial(torch, prov, pp.ptr, ks.cloud, pp.words, S[lo:hi], T[lo:hi], bitsize, xdev)
-                gathered = [torch.empty_like(mine) for _ in range(world)] if rank == 0 else None
-                dist.gather(mine, gathered, dst=0)                     # 24 ciphertexts per rank, one collective
-                if rank != 0:
-                    return None
-                res = pd.combine(torch, prov, pp.ptr, ks.cloud, gathered, bound.ptr, xdev, fast=not args.ripple_combine)
-            else:
-                # logical ranks on the one device: the phases of dist.sharded_match_logical, timed one by one
-                gathered, rank_ms = [], []
-                for r in range(nranks):
-                    rlo, rhi = pd.shard_slots(nslots, nranks, r)
-                    tr = time.perf_counter()
-                    gathered.append(pd.local_partial(torch, prov, pp.ptr, ks.cloud, pp.words, S[rlo:rhi], T[rlo:rhi], bitsize, "cuda"))
-                    rank_ms.append((time.perf_counter() - tr) * 1e3)
-                tr = time.perf_counter()
-                res = pd.combine(torch, prov, pp.ptr, ks.cloud, gathered, bound.ptr, "cuda", fast=not args.ripple_combine)
+                # libpeba1-dist (C++): partial sum of this rank's slots, ONE gather of 24 ciphertexts per rank, rank 0 combines
+                res = pd.sharded_match(dist, torch, L, circuits.load(), pp.ptr, ks.cloud, pp.words, S[lo:hi], T[lo:hi],
+                                       bound.ptr, bitsize, device=xdev, fast_combine=not args.ripple_combine, comm=comm)
                 api.flush()
-                phase_ms["ranks"].append(rank_ms)
-                phase_ms["combine"].append((time.perf_counter() - tr) * 1e3)
                 return res
+            # logical ranks on the one device: the same C phases (peba1_sharded_partial_packed / _combine_packed), timed one by one
+            parts, rank_ms = [], []
+            for r in range(nranks):
+                rlo, rhi = pd.shard_slots(nslots, nranks, r)
+                tr = time.perf_counter()
+                parts.append(pd.local_partial_packed(ks.cloud, pp.words, S[rlo:rhi], T[rlo:rhi], bitsize))
+                rank_ms.append((time.perf_counter() - tr) * 1e3)
+            tr = time.perf_counter()
+            res = pd.combine_packed(L, pp.ptr, ks.cloud, parts, bound.ptr, fast=not args.ripple_combine)
             api.flush()
+            phase_ms["ranks"].append(rank_ms)
+            phase_ms["combine"].append((time.perf_counter() - tr) * 1e3)
             return res
 
         def check(last):

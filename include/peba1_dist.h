@@ -1,0 +1,87 @@
+/*
+ * peba1_dist.h -- C ABI of libpeba1-dist: the multi-GPU forms of the PEBA1 match for a C++ (or any C-ABI) host,
+ * one process per GPU.  north_star keeps the host in C++: a PEBA1 server that calls Function_f per enrolled
+ * client (/root/reference/src/main.cpp:533-542) shards exactly there, with no Python in the process.
+ *
+ *   slot-sharded match (BASELINE configs[2]): every rank evaluates the reference's slot loop
+ *     (Math.cpp:351-360) over ITS slots, ONE gather moves each rank's 24-ciphertext partial sum to rank 0,
+ *     rank 0 adds the partial sums and runs the comparator (Math.cpp:384).
+ *   1-to-N identification (configs[3]): matches are independent, no data-path collective; only the match-bit
+ *     ciphertexts are gathered to rank 0 (peba1_dist_gather_samples).
+ *
+ * Transport.  Either RCCL over xGMI -- device buffers, the gather enqueued on libtfhe-hip's own stream between
+ * the stream-ordered export and import (tfhe_hip.h), so nothing waits on the host -- or any host-memory
+ * exchange the caller supplies as a callback (MPI, sockets, torch.distributed/gloo): how several processes
+ * rehearse the N > 1 path on one GPU, and how a deployment without RCCL plugs in.
+ *
+ * The library calls only the public gate API (tfhe/tfhe.h, tfhe_hip.h) and libpeba1-circuits; its symbols
+ * resolve at load time against whichever provider is loaded (libtfhe-hip.so; the tests' plaintext provider for
+ * the host transport).  RCCL is opened on first use (dlopen librccl.so), not linked.
+ */
+#ifndef PEBA1_DIST_H
+#define PEBA1_DIST_H
+
+#include <stddef.h>
+
+#include "peba1_circuits.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct Peba1Comm Peba1Comm;
+
+/* contiguous slot range [*lo, *hi) of `rank`; earlier ranks take the remainder */
+void peba1_dist_shard_slots(int nslots, int world, int rank, int *lo, int *hi);
+
+/* ---- RCCL transport ---- */
+#define PEBA1_DIST_ID_BYTES 128
+/* rank 0: a fresh RCCL unique id (ncclGetUniqueId); ship the 128 bytes to the other ranks by any means */
+int peba1_dist_unique_id(void *id128);
+/* every rank (collective, ncclCommInitRank); selects nothing: call tfhe_hip_set_device first */
+Peba1Comm *peba1_dist_init_rccl(const void *id128, int world, int rank);
+/* or adopt a communicator the host already has (an ncclComm_t); not destroyed by peba1_dist_destroy */
+Peba1Comm *peba1_dist_adopt_rccl(void *nccl_comm, int world, int rank);
+
+/* ---- host-memory transport ----
+ * gather(ctx, send, recv, bytes, root): every rank contributes `bytes` bytes at `send`; on `root`, recv holds
+ * world * bytes, rank-major; recv is NULL elsewhere.  Returns 0 on success. */
+typedef int (*peba1_gather_fn)(void *ctx, const void *send, void *recv, size_t bytes, int root);
+Peba1Comm *peba1_dist_init_host(peba1_gather_fn gather, void *ctx, int world, int rank);
+
+void peba1_dist_destroy(Peba1Comm *comm);
+int peba1_dist_rank(const Peba1Comm *comm);
+int peba1_dist_world(const Peba1Comm *comm);
+/* message of the last failed call of this library on this thread's communicator ("" if none) */
+const char *peba1_dist_last_error(void);
+
+/* flags */
+#define PEBA1_DIST_FAST_COMBINE 1   /* rank 0: carry-save compressor + prefix adder + prefix comparator
+                                       (peba1_combine_and_compare_fast, ~20 levels) instead of the pairwise tree of the
+                                       reference's ripple adders + its comparator (~290 levels at 8 ranks) */
+
+/* Slot-sharded Function_f (Math.cpp:379-387 split as SURVEY.md 8e): a[i], b[i] (i < nslots_local) are THIS rank's
+ * slots of the sample and the template, `bitsize` samples each; bound_match and result_b (3 * bitsize = 24 samples,
+ * caller-allocated) are read / written on rank 0 only (may be NULL elsewhere).  result_b[0] = (distance > bound).
+ * Collective: every rank of the communicator calls it.  Returns 0, or -1 with peba1_dist_last_error(). */
+int peba1_sharded_function_f(Peba1Comm *comm, LweSample *result_b, LweSample *const *a, LweSample *const *b,
+                             int nslots_local, LweSample *bound_match, int bitsize,
+                             const TFheGateBootstrappingCloudKeySet *ck, int flags);
+
+/* The two phases on their own (tests, logical ranks on one device): phase 1 leaves this rank's packed partial sum
+ * (24 * sample_words int32) in `packed` (host memory); phase 3 combines `nparts` packed partial sums (rank-major)
+ * on the calling rank. */
+int peba1_sharded_partial_packed(LweSample *const *a, LweSample *const *b, int nslots_local, int bitsize,
+                                 const TFheGateBootstrappingCloudKeySet *ck, int32_t *packed);
+int peba1_sharded_combine_packed(LweSample *result_b, const int32_t *packed, int nparts, LweSample *bound_match,
+                                 const TFheGateBootstrappingCloudKeySet *ck, int flags);
+
+/* Gather `count` ciphertexts of every rank to rank 0 (identification: the match bits).  `all` (rank 0: world * count
+ * samples, rank-major; NULL elsewhere) and `mine` are sample arrays of parameter set `params`. */
+int peba1_dist_gather_samples(Peba1Comm *comm, LweSample *all, const LweSample *mine, int count,
+                              const TFheGateBootstrappingParameterSet *params);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -82,6 +82,17 @@ int tfhe_hip_export_samples_device(const LweSample *samples, int32_t count,
                                    const TFheGateBootstrappingParameterSet *params, void *device_words);
 int tfhe_hip_import_samples_device(LweSample *samples, int32_t count,
                                    const TFheGateBootstrappingParameterSet *params, const void *device_words);
+/* Stream-ordered forms for collectives driven from the host language (libpeba1-dist): the transfer is ENQUEUED on
+ * the library's own HIP stream, tfhe_hip_stream(), and the call returns without waiting.  Anything the caller then
+ * enqueues on that same stream -- an RCCL collective on the exported buffer, or the next flush after an import -- is
+ * ordered behind it by the stream itself, with no host synchronisation.  The buffer must stay allocated until the
+ * stream has passed the transfer (hipStreamSynchronize(tfhe_hip_stream()), or an event). */
+int tfhe_hip_export_samples_device_async(const LweSample *samples, int32_t count,
+                                         const TFheGateBootstrappingParameterSet *params, void *device_words);
+int tfhe_hip_import_samples_device_async(LweSample *samples, int32_t count,
+                                         const TFheGateBootstrappingParameterSet *params, const void *device_words);
+/* the hipStream_t every kernel and transfer of this library runs on (created non-blocking, highest priority) */
+void *tfhe_hip_stream(void);
 /* refresh the host mirror (a, b) of samples whose value lives on the device */
 int tfhe_hip_sync_samples(const LweSample *samples, int32_t count);
 

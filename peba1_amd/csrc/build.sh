@@ -29,3 +29,8 @@ echo "built $(realpath $OUT)"
 # whichever provider is loaded first (libtfhe-hip.so, or the tests' plain mock)
 $CXX $FLAGS -I../../include -shared -o ../libpeba1-circuits.so circuits.cpp circuits_fast.cpp
 echo "built $(realpath ../libpeba1-circuits.so)"
+# multi-GPU forms of the match for a C-ABI host (include/peba1_dist.h): host logic over the public gate API and the
+# circuits; RCCL is opened with dlopen on first use, the gate provider resolves at load time like the circuits'
+$CXX $HOSTFLAGS -I../../include -shared -o ../libpeba1-dist.so dist.cpp -L.. -lpeba1-circuits -Wl,-rpath,'$ORIGIN' \
+    -L$ROCM/lib -lamdhip64 -ldl
+echo "built $(realpath ../libpeba1-dist.so)"

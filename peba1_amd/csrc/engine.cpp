@@ -324,11 +324,31 @@ void Engine::read_slot(SlotPool *pool, int32_t slot, Torus32 *a, Torus32 *b) {
     *b = tmp[pool->ct_words() - 1];
 }
 
-void Engine::write_slots_packed(SlotPool *pool, const int32_t *slots, int count, const Torus32 *words, bool on_device) {
+// Slot lists travel through a pinned host ring, so that the stream-ordered (no host wait) forms below never read
+// host memory the caller has already released.
+int32_t *Engine::stage_slots(const int32_t *slots, int count) {
+    constexpr size_t RING = 1 << 16;                         // words; one transfer may use at most a quarter
+    if (!slot_ring_) hip_check(hipHostMalloc(reinterpret_cast<void **>(&slot_ring_), RING * 4, hipHostMallocDefault), "pinned slot ring");
+    if ((size_t)count > RING / 4) {                          // large lists: synchronous staging through the stream
+        hip_check(hipStreamSynchronize(stream_), "sync before large slot list");
+        slot_ring_pos_ = 0;
+        if ((size_t)count > RING) api_fail("too many samples in one packed transfer");
+    }
+    if (slot_ring_pos_ + (size_t)count > RING) {             // wrap: everything queued so far must have read its list
+        hip_check(hipStreamSynchronize(stream_), "sync at slot ring wrap");
+        slot_ring_pos_ = 0;
+    }
+    int32_t *h = slot_ring_ + slot_ring_pos_;
+    std::memcpy(h, slots, (size_t)count * 4);
+    slot_ring_pos_ += (size_t)count;
+    return h;
+}
+
+void Engine::write_slots_packed(SlotPool *pool, const int32_t *slots, int count, const Torus32 *words, bool on_device, bool wait) {
     if (count <= 0) return;
     const size_t wbytes = (size_t)count * pool->ct_words() * 4;
     int32_t *dslots = static_cast<int32_t *>(scratch(3, (size_t)count * 4));
-    hip_check(hipMemcpyAsync(dslots, slots, (size_t)count * 4, hipMemcpyHostToDevice, stream_), "upload slot list");
+    hip_check(hipMemcpyAsync(dslots, stage_slots(slots, count), (size_t)count * 4, hipMemcpyHostToDevice, stream_), "upload slot list");
     const int32_t *src = words;
     if (!on_device) {
         int32_t *dw = static_cast<int32_t *>(scratch(4, wbytes));
@@ -336,18 +356,19 @@ void Engine::write_slots_packed(SlotPool *pool, const int32_t *slots, int count,
         src = dw;
     }
     launch_scatter_slots(stream_, pool->data(), pool->ct_stride(), pool->ct_words(), dslots, count, src);
-    hip_check(hipStreamSynchronize(stream_), "scatter slots");
+    if (wait || !on_device) hip_check(hipStreamSynchronize(stream_), "scatter slots");
 }
 
-void Engine::read_slots_packed(SlotPool *pool, const int32_t *slots, int count, Torus32 *words, bool on_device) {
+void Engine::read_slots_packed(SlotPool *pool, const int32_t *slots, int count, Torus32 *words, bool on_device, bool wait) {
     if (count <= 0) return;
     const size_t wbytes = (size_t)count * pool->ct_words() * 4;
+    // (a list in flight from an earlier stream-ordered call is read by its kernel before this copy lands: one stream)
     int32_t *dslots = static_cast<int32_t *>(scratch(3, (size_t)count * 4));
-    hip_check(hipMemcpyAsync(dslots, slots, (size_t)count * 4, hipMemcpyHostToDevice, stream_), "upload slot list");
+    hip_check(hipMemcpyAsync(dslots, stage_slots(slots, count), (size_t)count * 4, hipMemcpyHostToDevice, stream_), "upload slot list");
     int32_t *dst = on_device ? words : static_cast<int32_t *>(scratch(4, wbytes));
     launch_gather_slots(stream_, pool->data(), pool->ct_stride(), pool->ct_words(), dslots, count, dst);
     if (!on_device) hip_check(hipMemcpyAsync(words, dst, wbytes, hipMemcpyDeviceToHost, stream_), "download packed words");
-    hip_check(hipStreamSynchronize(stream_), "gather slots");
+    if (wait || !on_device) hip_check(hipStreamSynchronize(stream_), "gather slots");
 }
 
 bool Engine::launch_br(const DeviceKeyImage *key, const int32_t *pool, const RotDesc *rots, int count, int32_t *u_buf,

@@ -98,8 +98,10 @@ public:
 
     void write_slot(SlotPool *pool, int32_t slot, const Torus32 *a, Torus32 b);       // host -> device
     void read_slot(SlotPool *pool, int32_t slot, Torus32 *a, Torus32 *b);             // device -> host
-    void write_slots_packed(SlotPool *pool, const int32_t *slots, int count, const Torus32 *words, bool words_on_device);
-    void read_slots_packed(SlotPool *pool, const int32_t *slots, int count, Torus32 *words, bool words_on_device);
+    // wait = false (device words only): the transfer is enqueued on the engine's stream and the call returns -- whatever
+    // is enqueued on that stream afterwards (a collective, the next flush) is ordered behind it without a host wait
+    void write_slots_packed(SlotPool *pool, const int32_t *slots, int count, const Torus32 *words, bool words_on_device, bool wait = true);
+    void read_slots_packed(SlotPool *pool, const int32_t *slots, int count, Torus32 *words, bool words_on_device, bool wait = true);
 
     // run a levelised plan; synchronises the stream before returning
     void execute(const DeviceKeyImage *key, SlotPool *pool, const LevelPlan &plan);
@@ -163,6 +165,9 @@ public:
 private:
     Engine() = default;
     void *scratch(size_t idx, size_t bytes);   // grow-only device scratch buffers
+    int32_t *stage_slots(const int32_t *slots, int count);
+    int32_t *slot_ring_ = nullptr;
+    size_t slot_ring_pos_ = 0;
     int device_ = 0;
     int cu_count_ = 256;
     bool inited_ = false;

@@ -797,7 +797,7 @@ static SlotPool *resolve_pool(const LweSample *samples, const TFheGateBootstrapp
 }
 
 static int export_impl(const LweSample *samples, int32_t count, const TFheGateBootstrappingParameterSet *params,
-                       Torus32 *out, bool device_dst) {
+                       Torus32 *out, bool device_dst, bool wait = true) {
     Recorder &r = rec();
     std::lock_guard<std::recursive_mutex> g(r.mtx);
     if (count <= 0) return 0;
@@ -820,12 +820,12 @@ static int export_impl(const LweSample *samples, int32_t count, const TFheGateBo
     if (!r.ops.empty()) flush_locked();
     std::vector<int32_t> slots(count);
     for (int32_t i = 0; i < count; ++i) slots[i] = ensure_slot(&samples[i], pool);
-    Engine::get().read_slots_packed(pool, slots.data(), count, out, device_dst);
+    Engine::get().read_slots_packed(pool, slots.data(), count, out, device_dst, wait);
     return 0;
 }
 
 static int import_impl(LweSample *samples, int32_t count, const TFheGateBootstrappingParameterSet *params,
-                       const Torus32 *in, bool device_src) {
+                       const Torus32 *in, bool device_src, bool wait = true) {
     Recorder &r = rec();
     std::lock_guard<std::recursive_mutex> g(r.mtx);
     if (count <= 0) return 0;
@@ -849,7 +849,7 @@ static int import_impl(LweSample *samples, int32_t count, const TFheGateBootstra
             samples[i].b = in[(size_t)i * (n + 1) + n];
         }
     }
-    Engine::get().write_slots_packed(pool, slots.data(), count, in, device_src);
+    Engine::get().write_slots_packed(pool, slots.data(), count, in, device_src, wait);
     return 0;
 }
 
@@ -868,6 +868,19 @@ int tfhe_hip_export_samples_device(const LweSample *samples, int32_t count,
 int tfhe_hip_import_samples_device(LweSample *samples, int32_t count, const TFheGateBootstrappingParameterSet *params,
                                    const void *device_words) {
     return guarded_rc([&] { return import_impl(samples, count, params, static_cast<const Torus32 *>(device_words), true); });
+}
+
+int tfhe_hip_export_samples_device_async(const LweSample *samples, int32_t count,
+                                         const TFheGateBootstrappingParameterSet *params, void *device_words) {
+    return guarded_rc([&] { return export_impl(samples, count, params, static_cast<Torus32 *>(device_words), true, false); });
+}
+int tfhe_hip_import_samples_device_async(LweSample *samples, int32_t count, const TFheGateBootstrappingParameterSet *params,
+                                         const void *device_words) {
+    return guarded_rc([&] { return import_impl(samples, count, params, static_cast<const Torus32 *>(device_words), true, false); });
+}
+void *tfhe_hip_stream(void) {
+    Engine::get().ensure_init();
+    return static_cast<void *>(Engine::get().stream());
 }
 
 int tfhe_hip_sync_samples(const LweSample *samples, int32_t count) {

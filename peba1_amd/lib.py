@@ -111,6 +111,9 @@ SIGNATURES = {
     "tfhe_hip_import_samples": (C.c_int, [LS, C.c_int32, PS, I32P]),
     "tfhe_hip_export_samples_device": (C.c_int, [LS, C.c_int32, PS, C.c_void_p]),
     "tfhe_hip_import_samples_device": (C.c_int, [LS, C.c_int32, PS, C.c_void_p]),
+    "tfhe_hip_export_samples_device_async": (C.c_int, [LS, C.c_int32, PS, C.c_void_p]),
+    "tfhe_hip_import_samples_device_async": (C.c_int, [LS, C.c_int32, PS, C.c_void_p]),
+    "tfhe_hip_stream": (C.c_void_p, []),
     "tfhe_hip_sync_samples": (C.c_int, [LS, C.c_int32]),
     "tfhe_hip_set_deferred": (None, [C.c_int]),
     "tfhe_hip_get_deferred": (C.c_int, []),

@@ -1,0 +1,81 @@
+// dist_host.cpp -- TEST: a C++ host (no Python anywhere in the process) runs the slot-sharded match through
+// libpeba1-dist's C ABI (include/peba1_dist.h) the way a PEBA1 server would around
+// /root/reference/src/main.cpp:533-542.  Here: the plaintext provider (tests/mock/plain_tfhe.cpp), the host
+// transport, and WORLD ranks simulated one after the other in this process (rank 0 last, so that its gather
+// finds every other rank's contribution); with libtfhe-hip and RCCL the calls are the same, one process per GPU
+// (INTEGRATION.md).
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <vector>
+
+#include "peba1_dist.h"
+#include "tfhe_hip.h"
+
+static std::vector<std::vector<char>> g_mail;     // what each rank has sent
+
+static int gather_cb(void *ctx, const void *send, void *recv, size_t bytes, int root) {
+    const int rank = *static_cast<int *>(ctx);
+    g_mail[(size_t)rank].assign(static_cast<const char *>(send), static_cast<const char *>(send) + bytes);
+    if (rank != root) return 0;
+    for (size_t r = 0; r < g_mail.size(); ++r) {
+        if (g_mail[r].size() != bytes) return -1;             // a rank has not called yet
+        std::memcpy(static_cast<char *>(recv) + r * bytes, g_mail[r].data(), bytes);
+    }
+    return 0;
+}
+
+static LweSample *encrypt_number(unsigned v, int bits, const TFheGateBootstrappingParameterSet *pp,
+                                 const TFheGateBootstrappingSecretKeySet *key) {
+    LweSample *a = new_gate_bootstrapping_ciphertext_array(bits, pp);
+    for (int i = 0; i < bits; ++i) bootsSymEncrypt(a + i, (v >> i) & 1, key);
+    return a;
+}
+
+int main(int argc, char **argv) {
+    const int world = argc > 1 ? std::atoi(argv[1]) : 3, nslots = 11, bitsize = 8;
+    TFheGateBootstrappingParameterSet *pp = new_default_gate_bootstrapping_parameters(128);
+    TFheGateBootstrappingSecretKeySet *key = new_random_gate_bootstrapping_secret_keyset(pp);
+    const TFheGateBootstrappingCloudKeySet *ck = &key->cloud;
+    std::vector<unsigned> tmpl(nslots), probe(nslots);
+    long d = 0;
+    for (int i = 0; i < nslots; ++i) {
+        tmpl[i] = (37u * i + 11) % 255;
+        probe[i] = (91u * i + 5) % 256;
+        d += ((long)probe[i] - (long)tmpl[i]) * ((long)probe[i] - (long)tmpl[i]);
+    }
+    for (int pass = 0; pass < 4; ++pass) {
+        const long bound = pass & 1 ? d : d - 1;               // both sides of the threshold
+        const int flags = pass & 2 ? PEBA1_DIST_FAST_COMBINE : 0;
+        g_mail.assign((size_t)world, {});
+        LweSample *result_b = new_gate_bootstrapping_ciphertext_array(24, pp);
+        LweSample *enc_bound = encrypt_number((unsigned)bound, 24, pp, key);
+        std::vector<int> ranks;
+        for (int r = 1; r < world; ++r) ranks.push_back(r);
+        ranks.push_back(0);
+        for (int rank : ranks) {
+            int lo, hi;
+            peba1_dist_shard_slots(nslots, world, rank, &lo, &hi);
+            std::vector<LweSample *> S, T;
+            for (int i = lo; i < hi; ++i) { S.push_back(encrypt_number(probe[i], bitsize, pp, key)); T.push_back(encrypt_number(tmpl[i], bitsize, pp, key)); }
+            Peba1Comm *comm = peba1_dist_init_host(gather_cb, &rank, world, rank);
+            if (!comm) { std::printf("init: %s\n", peba1_dist_last_error()); return 1; }
+            if (peba1_sharded_function_f(comm, rank == 0 ? result_b : nullptr, S.data(), T.data(), hi - lo,
+                                         rank == 0 ? enc_bound : nullptr, bitsize, ck, flags) != 0) {
+                std::printf("rank %d: %s\n", rank, peba1_dist_last_error());
+                return 1;
+            }
+            peba1_dist_destroy(comm);
+            for (LweSample *p : S) delete_gate_bootstrapping_ciphertext_array(bitsize, p);
+            for (LweSample *p : T) delete_gate_bootstrapping_ciphertext_array(bitsize, p);
+        }
+        const int bit = bootsSymDecrypt(result_b, key);
+        if (bit != (d > bound ? 1 : 0)) { std::printf("pass %d: bit %d, distance %ld, bound %ld\n", pass, bit, d, bound); return 1; }
+        delete_gate_bootstrapping_ciphertext_array(24, result_b);
+        delete_gate_bootstrapping_ciphertext_array(24, enc_bound);
+    }
+    // bad arguments are reported, not fatal
+    if (peba1_dist_init_host(nullptr, nullptr, 2, 0) != nullptr || !*peba1_dist_last_error()) return 1;
+    std::printf("DIST-HOST-OK world %d distance %ld\n", world, d);
+    return 0;
+}

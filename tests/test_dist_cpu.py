@@ -40,6 +40,7 @@ nslots = int(os.environ["PEBA1_SLOTS"])
 tmpl = [(37 * i + 11) % 255 for i in range(nslots)]
 probe = [(91 * i + 5) % 256 for i in range(nslots)] if os.environ["PEBA1_CASE"] == "impostor" else [v + 1 for v in tmpl]
 lo, hi = pd.shard_slots(nslots, world, rank)
+assert all(pd.shard_slots(n, w, r) == pd.shard_slots_c(n, w, r) for n in (1, 7, 12, 128) for w in (1, 2, 3, 8) for r in range(w))
 S = [enc(probe[i], 8) for i in range(lo, hi)]
 T = [enc(tmpl[i], 8) for i in range(lo, hi)]
 bound = enc(int(os.environ["PEBA1_BOUND"]), 24)
@@ -143,3 +144,30 @@ def test_sharded_match_logical_ranks_plain_provider(built):
     out = subprocess.run([sys.executable, built + "/logical.py"], env=dict(os.environ, PEBA1_ROOT=ROOT, PEBA1_TMP=built),
                          capture_output=True, text=True, timeout=300)
     assert out.returncode == 0 and "LOGICAL-OK" in out.stdout, out.stdout + out.stderr
+
+
+@pytest.mark.parametrize("world", [1, 3, 8])
+def test_cpp_host_runs_the_sharded_match_without_python(built, world):
+    """the multi-GPU path belongs to the C++ host.  A plain C++ program (tests/refcompat/dist_host.cpp)
+    links libpeba1-dist's sources, the circuits and the plaintext provider, and runs peba1_sharded_function_f for
+    `world` ranks through the host transport: match bit on both sides of the threshold, both combine forms."""
+    inc = os.path.join(ROOT, "include")
+    exe = os.path.join(built, "dist_host")
+    if not os.path.exists(exe):
+        subprocess.check_call(["g++", "-O1", "-std=gnu++17", "-D__HIP_PLATFORM_AMD__", "-I" + inc, "-I/opt/rocm/include",
+                               os.path.join(ROOT, "tests/refcompat/dist_host.cpp"), os.path.join(ROOT, "tests/mock/plain_tfhe.cpp"),
+                               os.path.join(ROOT, "peba1_amd/csrc/circuits.cpp"), os.path.join(ROOT, "peba1_amd/csrc/circuits_fast.cpp"),
+                               os.path.join(ROOT, "peba1_amd/csrc/dist.cpp"), "-o", exe, "-L/opt/rocm/lib", "-lamdhip64", "-ldl",
+                               "-Wl,-rpath,/opt/rocm/lib"])
+    out = subprocess.run([exe, str(world)], capture_output=True, text=True, timeout=120)
+    assert out.returncode == 0 and "DIST-HOST-OK" in out.stdout, out.stdout + out.stderr
+
+
+def test_libpeba1_dist_exports_every_declared_symbol():
+    import re
+    txt = open(os.path.join(ROOT, "include", "peba1_dist.h")).read()
+    txt = re.sub(r"/\*.*?\*/", "", txt, flags=re.S)
+    declared = set(re.findall(r"\b(peba1_\w+)\s*\(", txt)) - {"peba1_gather_fn"}
+    out = subprocess.check_output(["nm", "-D", "--defined-only", os.path.join(ROOT, "peba1_amd", "libpeba1-dist.so")]).decode()
+    exported = {line.split()[-1] for line in out.splitlines() if line.strip()}
+    assert len(declared) >= 12 and not (declared - exported), declared - exported
