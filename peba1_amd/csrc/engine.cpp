@@ -819,7 +819,10 @@ double Engine::run_lane_probe(const DeviceKeyImage *key, int lanes, int levels, 
 
 void Engine::run_negacyclic(const DeviceKeyImage *key, const int32_t *ip, const Torus32 *tp, Torus32 *res, int count) {
     DevParams dp = key->dp;
-    dp.br_variant = br_variant == 2 ? 2 : 0;             // 2: through the split transforms
+    // 2: through the split transforms; 3: first transpose through the cross-lane paths (N = 1024; same results);
+    // 4 / 5: timing forms of the LDS / cross-lane transform repeated 64 times (results meaningless)
+    dp.br_variant = br_variant >= 2 && br_variant <= 5 ? br_variant : 0;
+    if (dp.br_variant >= 3 && dp.N != 1024) dp.br_variant = 0;
     const size_t words = (size_t)count * dp.N;
     uint32_t scale[2];
     (void)make_twiddles(dp.N, scale);

@@ -118,7 +118,10 @@ __global__ __launch_bounds__(64) void bk_transform_kernel(const int32_t *__restr
 // ---------------------------------------------------------------------------
 // test kernel: res = ip * tp (negacyclic, mod 2^32), tp given as image
 // ---------------------------------------------------------------------------
-template <int LOGN>
+// XLANE: the forward transform's first transpose through v_permlane32_swap / v_permlane16_swap / DPP instead of LDS
+// (N = 1024; measurement only, tools/diag/crosslane.sh -> DESIGN.md section 5); REPS > 1 repeats the forward
+// transform on its own output so that the transform dominates the kernel's time (timing runs only: results differ)
+template <int LOGN, bool XLANE = false, int REPS = 1>
 __global__ __launch_bounds__(128) void negacyclic_kernel(const int32_t *__restrict__ ip, const uint32_t *__restrict__ img,
                                                          const uint32_t *__restrict__ tw, int32_t *__restrict__ res) {
     using NTT = WaveNtt<LOGN>;
@@ -133,7 +136,17 @@ __global__ __launch_bounds__(128) void negacyclic_kernel(const int32_t *__restri
     int32_t x[REGS];
 #pragma unroll
     for (int r = 0; r < REGS; ++r) x[r] = src[r * 64 + lane];
-    NTT::forward(x, c, scr, lane);
+#pragma unroll 1
+    for (int rep = 0; rep < REPS; ++rep) {
+        if constexpr (REPS > 1) {
+            if (rep > 0) {               // back to small inputs in natural order (any values do for timing)
+#pragma unroll
+                for (int r = 0; r < REGS; ++r) x[r] = (x[r] >> 20) + rep;
+            }
+        }
+        if constexpr (XLANE) NTT::forward_crosslane(x, c, scr, lane);
+        else NTT::forward(x, c, scr, lane);
+    }
     const uint4 *bp = reinterpret_cast<const uint4 *>(img + (size_t)(blockIdx.x * 2 + q) * N) + lane;
     int64_t acc[REGS];
 #pragma unroll
@@ -1654,6 +1667,9 @@ void launch_negacyclic(hipStream_t s, const DevParams &p, const uint32_t *tw, co
         return;
     }
     if (p.N == 2048) hipLaunchKernelGGL(negacyclic_kernel<11>, dim3(count), dim3(128), 0, s, ip, img, tw, res);
+    else if (p.br_variant == 3) hipLaunchKernelGGL((negacyclic_kernel<10, true>), dim3(count), dim3(128), 0, s, ip, img, tw, res);
+    else if (p.br_variant == 4) hipLaunchKernelGGL((negacyclic_kernel<10, false, 64>), dim3(count), dim3(128), 0, s, ip, img, tw, res);
+    else if (p.br_variant == 5) hipLaunchKernelGGL((negacyclic_kernel<10, true, 64>), dim3(count), dim3(128), 0, s, ip, img, tw, res);
     else hipLaunchKernelGGL(negacyclic_kernel<10>, dim3(count), dim3(128), 0, s, ip, img, tw, res);
 }
 

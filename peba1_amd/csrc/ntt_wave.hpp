@@ -316,6 +316,62 @@ struct WaveNtt {
     }
     static constexpr int steps_in(int stages) { return (stages + 1) / 2; }
 
+    // ---- the first transpose (L0 -> L1) through the cross-lane VALU paths instead of LDS ------------------
+    // MEASUREMENT ONLY (negacyclic test kernel, "br_variant" 3): north_star names wavefront
+    // shuffle primitives, so the alternative to the LDS transposes was built once and timed.  L0 -> L1 swaps lane
+    // bit 2 + b with register bit b (b = 0..3, N = 1024): for every register pair (A, B) = (x[r], x[r | 1 << b])
+    // the lanes with the lane bit set exchange their A with the B of the partner lane.  Lane bit 5: one
+    // v_permlane32_swap per pair; bit 4: one v_permlane16_swap; bits 3, 2: two v_mov_b32_dpp (row_shr / row_shl by
+    // 8 or 4 under a bank mask) per pair -- 8 + 8 + 16 + 16 = 48 VALU instructions (+ copies) where the LDS form
+    // issues 16 ds_write_b32 and 4 ds_read_b128 and no VALU at all.
+    static __device__ __forceinline__ void transpose1_crosslane(int32_t (&x)[REGS]) {
+        static_assert(LOGN == 10, "cross-lane transpose written for N = 1024 (4 register bits, lane bits 5..2)");
+#pragma unroll
+        for (int r = 0; r < REGS; ++r)
+            if (!(r & 8)) {              // lane bit 5 <-> register bit 3
+                const auto v = __builtin_amdgcn_permlane32_swap((unsigned)x[r], (unsigned)x[r | 8], false, false);
+                x[r] = (int32_t)v[0]; x[r | 8] = (int32_t)v[1];
+            }
+#pragma unroll
+        for (int r = 0; r < REGS; ++r)
+            if (!(r & 4)) {              // lane bit 4 <-> register bit 2
+                const auto v = __builtin_amdgcn_permlane16_swap((unsigned)x[r], (unsigned)x[r | 4], false, false);
+                x[r] = (int32_t)v[0]; x[r | 4] = (int32_t)v[1];
+            }
+#pragma unroll
+        for (int r = 0; r < REGS; ++r)
+            if (!(r & 2)) {              // lane bit 3 <-> register bit 1: rows of 16, distance 8, banks {2,3} / {0,1}
+                const int a = x[r], b = x[r | 2];
+                x[r] = __builtin_amdgcn_update_dpp(a, b, 0x118 /* row_shr:8 */, 0xF, 0xC, false);
+                x[r | 2] = __builtin_amdgcn_update_dpp(b, a, 0x108 /* row_shl:8 */, 0xF, 0x3, false);
+            }
+#pragma unroll
+        for (int r = 0; r < REGS; ++r)
+            if (!(r & 1)) {              // lane bit 2 <-> register bit 0: distance 4, banks {1,3} / {0,2}
+                const int a = x[r], b = x[r | 1];
+                x[r] = __builtin_amdgcn_update_dpp(a, b, 0x114 /* row_shr:4 */, 0xF, 0xA, false);
+                x[r | 1] = __builtin_amdgcn_update_dpp(b, a, 0x104 /* row_shl:4 */, 0xF, 0x5, false);
+            }
+    }
+    // forward transform whose first transpose goes through the cross-lane paths (measurement only)
+    static __device__ __forceinline__ void forward_crosslane(int32_t (&x)[REGS], const PrimeCtx &c, uint32_t *scr, int lane) {
+        FwdTw0 t0;
+        t0.load(c, lane);
+        fwd_pass(x, c, t0);
+        FwdTw1 t1;
+        t1.load(c, lane);
+        transpose1_crosslane(x);
+        fwd_pass(x, c, t1);
+        FwdTw2 t2;
+        t2.load(c, lane);
+#pragma unroll
+        for (int r = 0; r < REGS; ++r) scr[t2_l1_addr(lane, r)] = (uint32_t)x[r];
+        wave_lds_fence();
+        read_row(x, scr, lane);
+        wave_lds_fence();
+        fwd_pass(x, c, t2);
+    }
+
     // forward NTT: x in L0 (natural order) -> L2; |x| <= 2^11 ends below 6.7P, |x| < P below 8.2P.
     // t0: the first pass's twiddles, loaded by the caller (FwdTw0 t0; t0.load(c, lane);)
     // EARLY = false: a pass's twiddles are loaded after the transpose instead (fewer live registers).

@@ -133,7 +133,8 @@ class Comm:
                     out = [torch.empty_like(mine) for _ in range(self.world)] if self.rank == root else None
                     dist.gather(mine, out, dst=root)
                     if self.rank == root:
-                        C.memmove(recv, torch.cat(out).numpy().ctypes.data, nbytes * self.world)
+                        whole = torch.cat(out).contiguous().numpy()          # named: must outlive the copy below
+                        C.memmove(recv, whole.ctypes.data, nbytes * self.world)
                     return 0
                 except Exception:      # never unwind through the C frame
                     return -1

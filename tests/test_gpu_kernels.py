@@ -2,6 +2,9 @@
 all arithmetic is integer / Torus32).  Call path: Python -> C ABI (include/tfhe_hip.h)
 -> HIP kernels.  Reference semantics: SURVEY.md Appendix A.3; reference call sites
 /root/reference/src/Math.cpp:34-43."""
+import hashlib
+import os
+
 import numpy as np
 import pytest
 
@@ -458,3 +461,65 @@ def test_custom_gadgets_at_the_limit_of_the_kernel_forms(oracle, shape):
             assert (got[i] == oks.gate("AND", cts[i], cts[2 + i])).all()
     finally:
         ks.close()
+
+
+def test_parity_kit_words_are_what_the_gpu_computes():
+    """tests/golden/parity_kit: the kit's expected output words (what someone with upstream tfhe compares against
+    upstream's exact bootstrap, check_against_upstream.cpp) are reproduced by the HIP path from the kit's inputs under
+    the kit's keys -- every case, and the extracted sample of case 0 before its key switch."""
+    import json
+    from peba1_amd import api, lib
+    kit = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests", "golden", "parity_kit")
+    with open(os.path.join(kit, "kit.json")) as f:
+        meta = json.load(f)
+    p = meta["params"]
+    rd = lambda name, shape: np.fromfile(os.path.join(kit, name), dtype="<i4").reshape(shape)
+    inputs = rd("inputs.i32", (8, p["n"] + 1))
+    expected = rd("expected.i32", (len(meta["cases"]), p["n"] + 1))
+    extracted = rd("extracted.i32", (p["k"] * p["N"] + 1,))
+    pp = api.ParameterSet(custom=(p["n"], p["N"], p["k"], p["l"], p["Bgbit"], p["ks_t"], p["ks_basebit"],
+                                  p["ks_stdev"], p["bk_stdev"], p["max_stdev"]))
+    ks = api.SecretKeySet(pp, meta["key_seed"], device=True)
+    try:
+        assert hashlib.sha256(np.ascontiguousarray(ks.bk()).tobytes()).hexdigest() == meta["sha256"]["bk.i32"]
+        L = lib.load()
+        ct = api.CiphertextArray(pp, 8).set_words(inputs)
+        out = api.CiphertextArray(pp, len(meta["cases"]))
+        gates = {"AND": L.bootsAND, "XOR": L.bootsXOR, "OR": L.bootsOR, "XNOR": L.bootsXNOR, "NAND": L.bootsNAND}
+        for i, c in enumerate(meta["cases"]):
+            if c[0] == "MUX":
+                L.bootsMUX(out.at(i), ct.at(c[1]), ct.at(c[2]), ct.at(c[3]), ks.cloud)
+            else:
+                gates[c[0]](out.at(i), ct.at(c[1]), ct.at(c[2]), ks.cloud)
+        got = out.words()
+        for i, c in enumerate(meta["cases"]):
+            assert (got[i] == expected[i]).all(), c
+        assert list(out.decrypt(ks)) == meta["expected_bits"]
+        c0 = meta["cases"][0]
+        sa = {"AND": (1, 1, -meta["mu"])}[c0[0]]
+        lin = (sa[0] * inputs[c0[1]].astype(np.int64) + sa[1] * inputs[c0[2]].astype(np.int64))
+        lin[-1] += sa[2]
+        lin = (lin % (1 << 32)).astype(np.uint32).view(np.int32)
+        u = api.kernel_bootstrap_woks(ks, lin[None, :])
+        assert (u[0] == extracted).all()
+    finally:
+        ks.close()
+
+
+def test_crosslane_transpose_form_gives_the_same_products(p128_keys):
+    """The measurement form of the forward transform whose first transpose goes through v_permlane32_swap /
+    v_permlane16_swap / DPP instead of LDS (ntt_wave.hpp transpose1_crosslane) computes the same
+    negacyclic products as the LDS form."""
+    from peba1_amd import api
+    pp, ks, _ = p128_keys
+    rng = np.random.default_rng(8)
+    ip = rng.integers(-64, 64, (70, pp.N), dtype=np.int64).astype(np.int32)
+    tp = rng.integers(-2**31, 2**31, (70, pp.N), dtype=np.int64).astype(np.int32)
+    try:
+        api.set_tuning("br_variant", 0)
+        ref = api.kernel_negacyclic(ks, ip, tp)
+        api.set_tuning("br_variant", 3)
+        got = api.kernel_negacyclic(ks, ip, tp)
+    finally:
+        api.set_tuning("br_variant", -1)
+    assert (got == ref).all()

@@ -228,3 +228,33 @@ def test_default_randomness_is_chacha20_keyed_by_the_os():
     runs = [subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=120) for _ in range(2)]
     assert all(r.returncode == 0 for r in runs), runs[0].stderr + runs[1].stderr
     assert runs[0].stdout != runs[1].stdout                  # two processes, two key streams
+
+
+def test_parity_kit_files_are_what_the_oracle_produces():
+    """tests/golden/parity_kit: the committed raw-word fixtures are exactly what make_kit.py
+    regenerates from the oracle (schoolbook and two-prime evaluators agree inside it), and the product's seeded key
+    derivation yields the kit's keys -- so the GPU test can run the kit without loading files."""
+    import importlib.util
+    kit_dir = os.path.join(ROOT, "tests", "golden", "parity_kit")
+    spec = importlib.util.spec_from_file_location("make_kit", os.path.join(kit_dir, "make_kit.py"))
+    mk = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mk)
+    files, meta = mk.build()
+    with open(os.path.join(kit_dir, "kit.json")) as f:
+        committed = json.load(f)
+    assert committed == json.loads(json.dumps(meta))
+    for name, arr in files.items():
+        with open(os.path.join(kit_dir, name), "rb") as f:
+            blob = f.read()
+        assert hashlib.sha256(blob).hexdigest() == committed["sha256"][name], name
+        assert blob == np.array(arr, dtype="<i4").tobytes(), name
+    from peba1_amd import api
+    p = committed["params"]
+    pp = api.ParameterSet(custom=(p["n"], p["N"], p["k"], p["l"], p["Bgbit"], p["ks_t"], p["ks_basebit"],
+                                  p["ks_stdev"], p["bk_stdev"], p["max_stdev"]))
+    ks = api.SecretKeySet(pp, committed["key_seed"], device=False)
+    assert sha(ks.bk()) == committed["sha256"]["bk.i32"] and sha(ks.lwe_key()) == committed["sha256"]["lwe_key.i32"]
+    base = 1 << p["ks_basebit"]
+    ksk = ks.ksk().reshape(p["k"] * p["N"], p["ks_t"], base, p["n"] + 1)
+    assert sha(np.ascontiguousarray(ksk[:, :, 1:, :])) == committed["sha256"]["ksk.i32"]
+    ks.close()

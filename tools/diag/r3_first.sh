@@ -3,7 +3,8 @@
 set -o pipefail
 OUT=gpurun_out/r3a; mkdir -p $OUT
 export TMPDIR=/tmp
-timeout -k 10 900 python -m pytest tests -m gpu -q -x -p no:cacheprovider --durations=25 > $OUT/tests.log 2>&1; rc=$?
+SEL=${1:-tests}
+timeout -k 10 900 python -m pytest $SEL -m gpu -q -x -p no:cacheprovider --durations=25 > $OUT/tests.log 2>&1; rc=$?
 echo "pytest rc $rc"; tail -40 $OUT/tests.log
 if [ $rc -ne 0 ]; then exit $rc; fi
 timeout -k 10 500 python bench.py --steps 3 --warmup 1 > $OUT/bench.json 2> $OUT/bench.err || { tail -20 $OUT/bench.err; exit 1; }
@@ -22,4 +23,15 @@ for n in ("bench", "bench_ksatomic0", "bench_ksatomic1"):
     if j.get("cpu_baseline"):
         print("  cpu", j["cpu_baseline"]["value"], j["cpu_baseline"]["cpu_model"], j["cpu_baseline"]["cores"])
 PY
+# narrow-launch latency of the kernel forms (is the split form a better latency form than the 8-wave one at N = 1024?)
+for v in -1 2; do
+  echo "=== TFHE_HIP_BR_VARIANT=$v" >> $OUT/latency.txt
+  TFHE_HIP_BR_VARIANT=$v timeout -k 10 200 python tools/gate_throughput.py 1 64 256 512 4096 >> $OUT/latency.txt 2>&1 || exit 1
+done
+cat $OUT/latency.txt
+# cross-lane against LDS transposes
+timeout -k 10 300 rocprofv3 --kernel-trace --stats -d $OUT/xl -o xl -- python3 tools/diag/crosslane.py > $OUT/crosslane.log 2>&1 || { tail -20 $OUT/crosslane.log; exit 1; }
+python3 tools/rocpd_to_csv.py stats "$(ls $OUT/xl/*_results.db | head -1)" $OUT/crosslane_kernel_stats.csv && grep negacyclic $OUT/crosslane_kernel_stats.csv
+tail -8 $OUT/crosslane.log
+rm -rf $OUT/xl
 echo ALL-DONE
