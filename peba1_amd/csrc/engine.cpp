@@ -40,21 +40,40 @@ void hip_check(hipError_t e, const char *what) {
 }
 
 // ---- slot pool ---------------------------------------------------------------
-SlotPool::SlotPool(int ct_words, int ct_stride, size_t capacity) : words_(ct_words), stride_(ct_stride), cap_(capacity) {
-    hip_check(hipMalloc(reinterpret_cast<void **>(&data_), cap_ * (size_t)stride_ * sizeof(int32_t)), "hipMalloc(slot pool)");
-    ref_.assign(cap_, 0);
-    level.assign(cap_, 0);
-    pending.assign(cap_, 0);
-    free_.reserve(cap_);
-    for (size_t i = cap_; i-- > 0;) free_.push_back((int32_t)i);
+// The pool is one contiguous device array (kernels index it by slot id) that starts small and doubles on demand up to
+// `capacity` slots: a process that evaluates a few gates holds 0.2 GB, one that records whole matches grows to what its
+// widest flush pins (5.3 GB were allocated up front whatever the caller did).
+SlotPool::SlotPool(int ct_words, int ct_stride, size_t capacity) : words_(ct_words), stride_(ct_stride), max_cap_(capacity) {
+    free_.reserve(std::min<size_t>(max_cap_, (size_t)1 << 17));
+    grow(std::min<size_t>(max_cap_, (size_t)1 << 16));
 }
 SlotPool::~SlotPool() {
     if (data_) (void)hipFree(data_);
 }
+void SlotPool::grow(size_t new_cap) {
+    int32_t *fresh = nullptr;
+    hip_check(hipMalloc(reinterpret_cast<void **>(&fresh), new_cap * (size_t)stride_ * sizeof(int32_t)), "hipMalloc(slot pool)");
+    if (data_) {
+        // growth happens while recording (host side, nothing of this library in flight: a flush returns synchronised),
+        // but a caller's own stream may still read an exported buffer: wait for the device once, copy, release
+        hip_check(hipDeviceSynchronize(), "sync before pool growth");
+        hip_check(hipMemcpy(fresh, data_, cap_ * (size_t)stride_ * sizeof(int32_t), hipMemcpyDeviceToDevice), "copy slot pool");
+        (void)hipFree(data_);
+    }
+    data_ = fresh;
+    ref_.resize(new_cap, 0);
+    level.resize(new_cap, 0);
+    pending.resize(new_cap, 0);
+    for (size_t i = new_cap; i-- > cap_;) free_.push_back((int32_t)i);
+    cap_ = new_cap;
+}
 int32_t SlotPool::alloc() {
-    if (free_.empty())
-        api_fail("ciphertext slot pool exhausted (" + std::to_string(cap_) +
-                 " slots); raise TFHE_HIP_POOL_SLOTS or free ciphertext arrays");
+    if (free_.empty()) {
+        if (cap_ >= max_cap_)
+            api_fail("ciphertext slot pool exhausted (" + std::to_string(max_cap_) +
+                     " slots); raise TFHE_HIP_POOL_SLOTS or free ciphertext arrays");
+        grow(std::min(max_cap_, cap_ * 2));
+    }
     const int32_t s = free_.back();
     free_.pop_back();
     ref_[s] = 1;

@@ -54,14 +54,16 @@ public:
     int32_t *data() { return data_; }
     int ct_stride() const { return stride_; }
     int ct_words() const { return words_; }
-    size_t capacity() const { return cap_; }
+    size_t capacity() const { return max_cap_; }              // what the pool may grow to
+    size_t allocated() const { return cap_; }                 // slots backed by device memory now
     size_t in_use() const { return cap_ - free_.size(); }
     std::vector<int32_t> level;      // level of the recorded operation that will write the slot (0: an input)
     std::vector<uint8_t> pending;    // 1 = written by a recorded operation that has not run yet
     int32_t const_slot[2] = {-1, -1};   // shared read-only trivial samples (0, -1/8) and (0, +1/8)
 private:
+    void grow(size_t new_cap);
     int words_, stride_;
-    size_t cap_;
+    size_t cap_ = 0, max_cap_;
     int32_t *data_ = nullptr;
     std::vector<int32_t> ref_;
     std::vector<int32_t> free_;

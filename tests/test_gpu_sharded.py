@@ -182,6 +182,47 @@ def test_cfg4_identification_streams_matches_through_bounded_flushes(p128_keys):
     assert got == want and got.count(0) == 1 and got[genuine] == 0
 
 
+def test_cfg4_identification_at_the_per_gpu_size_of_configs3(p128_keys):
+    """BASELINE configs[3] at its own per-GPU size (only the builder had run it): ONE probe against 128
+    enrolled 128-slot x 8-bit templates -- 128 independent runs of the reference's Function_f, 27.6 M blind rotations
+    -- streamed through the slot pool four matches per flush (32 flushes), every one of the 128 decrypted match bits
+    equal to the plaintext rule and the genuine template the only 0.  About five minutes on one MI355X."""
+    import sys
+    import time
+    from peba1_amd import api, circuits, identify, lib
+    pp, ks, _ = p128_keys
+    L = lib.load()
+    L.tfhe_hip_set_encrypt_seed(4096)
+    nslots, M, group = 128, 128, 4
+    base = [(37 * i + 11) % 255 or 1 for i in range(nslots)]
+    probe_v = [v + 1 for v in base]
+    templates_v = [identify.synthetic_template(base, k + 1) for k in range(M)]
+    genuine = 77
+    templates_v[genuine] = base
+    probe = circuits.EncryptedVector(pp, probe_v, 8, ks).to_device()
+    templates = [circuits.EncryptedVector(pp, t, 8, ks).to_device() for t in templates_v]
+    bound = circuits.encrypt_number(pp, 256, 24, ks)
+    bound.set_words(bound.words())
+    api.reset_stats()
+    t0 = time.time()
+
+    def progress(first, count):          # one line per 16 matches: the run is long, show that it moves
+        if (first + count) % 16 == 0:
+            print(f"[identify] {first + count}/{M} matches, {time.time() - t0:.0f} s", file=sys.stderr, flush=True)
+
+    bits_ct = identify.identify(pp, ks, probe, templates, bound, 8, group=group, on_group=progress)
+    seconds = time.time() - t0
+    st = api.stats()
+    assert st["flushes"] == M // group
+    # the library's default sharing of identical pending gates is on: executed + shared == recorded
+    assert st["blind_rotates"] + st["reused_gates"] <= M * 215544 <= st["blind_rotates"] + 2 * st["reused_gates"]
+    got = [int(b) for b in bits_ct.decrypt(ks)]
+    want = [1 if sum((a - b) ** 2 for a, b in zip(probe_v, t)) > 256 else 0 for t in templates_v]
+    assert got == want and got.count(0) == 1 and got[genuine] == 0
+    print(f"[identify] {M} matches in {seconds:.1f} s = {seconds / M * 1e3:.0f} ms per match, "
+          f"{st['blind_rotates'] / seconds:.0f} executed gates/s", file=sys.stderr, flush=True)
+
+
 TWO_PROCESS_WORKER = r'''
 import ctypes as C, hashlib, json, os, sys
 import numpy as np
