@@ -239,7 +239,7 @@ const char *unsupported_reason(const Params &p) {
     if (p.ks_t < 1 || p.ks_basebit < 1 || p.ks_t * p.ks_basebit > 31 || p.ks_basebit > 8) return "key-switch digits out of range";
     // exactness of the CRT range: (k+1) l N (Bg/2) 2^31 must stay below P0*P1/2
     const double bound = (double)(p.k + 1) * p.l * p.N * (double)(1u << (p.Bgbit - 1)) * 2147483648.0;
-    if (bound >= (double)CRT_HALF) return "gadget parameters exceed the exact range of the two-prime NTT";
+    if (bound >= (double)CRT_EXACT_LIMIT) return "gadget parameters exceed the exact range of the two-prime NTT";
     // at least one kernel form must keep its lazy-arithmetic bounds for this (l, Bgbit) (br_forms.hpp)
     for (int f = 0; f < BR_FORM_COUNT; ++f)
         for (int t = 0; t < 3; ++t)

@@ -63,18 +63,15 @@ __device__ __forceinline__ PrimeCtx make_sub_ctx(int q, int h, const uint32_t *t
 }
 
 // acc64 (sum of <= 6 products x*bk, |x| < 11.1P, 0 <= bk < P, so |acc| < 2^61) ->
-// Montgomery reduction (|.| < 2.6P), inverse NTT, canonical residue in [0,P)
+// Montgomery reduction (|.| < 2.6P), inverse NTT: signed residue, |y| < P (the CRT takes it as it is)
 template <int LOGN>
 __device__ __forceinline__ void finish_inverse(const int64_t (&acc)[WaveNtt<LOGN>::REGS],
-                                               uint32_t (&y)[WaveNtt<LOGN>::REGS],
+                                               int32_t (&y)[WaveNtt<LOGN>::REGS],
                                                const PrimeCtx &c, uint32_t *scr, int lane) {
     constexpr int REGS = WaveNtt<LOGN>::REGS;
-    int32_t t[REGS];
 #pragma unroll
-    for (int r = 0; r < REGS; ++r) t[r] = mont_redc(acc[r], c.P, c.pinv);
-    WaveNtt<LOGN>::inverse(t, c, scr, lane);
-#pragma unroll
-    for (int r = 0; r < REGS; ++r) y[r] = canon(t[r], c.P);
+    for (int r = 0; r < REGS; ++r) y[r] = mont_redc(acc[r], c.P, c.pinv);
+    WaveNtt<LOGN>::inverse(y, c, scr, lane);
 }
 
 // ---------------------------------------------------------------------------
@@ -157,16 +154,16 @@ __global__ __launch_bounds__(128) void negacyclic_kernel(const int32_t *__restri
         acc[4 * g + 2] = (int64_t)x[4 * g + 2] * (int32_t)b.z;
         acc[4 * g + 3] = (int64_t)x[4 * g + 3] * (int32_t)b.w;
     }
-    uint32_t y[REGS];
+    int32_t y[REGS];
     finish_inverse<LOGN>(acc, y, c, scr, lane);
 #pragma unroll
-    for (int r = 0; r < REGS; ++r) scr[r * 64 + lane] = y[r];
+    for (int r = 0; r < REGS; ++r) scr[r * 64 + lane] = (uint32_t)y[r];
     __syncthreads();
     if (q == 0) {
         const uint32_t *oscr = lds_scr[1];
 #pragma unroll
         for (int r = 0; r < REGS; ++r)
-            res[(size_t)blockIdx.x * N + r * 64 + lane] = (int32_t)crt_to_torus(y[r], oscr[r * 64 + lane]);
+            res[(size_t)blockIdx.x * N + r * 64 + lane] = (int32_t)crt_signed_to_torus(y[r], (int32_t)oscr[r * 64 + lane]);
     }
 }
 
@@ -278,12 +275,15 @@ struct AccLds {
 // Digits (tfhe tGswTorus32PolynomialDecompH): digit_jj = ((D + offset) >> s_jj) & (Bg-1)) - Bg/2.  The
 // offset holds Bg/2 at every digit position, so XOR-ing it back flips the top bit of every digit
 // field, and a digit is then the SIGNED bit field of (D + offset) ^ offset: one v_bfe_i32.
+// t0: the twiddles of the transforms' first pass -- lane-uniform and the same for every row and step, so the caller
+// loads them ONCE per kernel (they then live in scalar registers; round 3: -1.4 % of a wide launch against loading
+// them per row, and 12 fewer vector registers)
 template <int LOGN, bool FRESH, bool KEEP_D, bool EARLY_TW, bool TABLE, typename Acc0T, typename Acc1T>
 __device__ __forceinline__ void forward_poly(const DevParams &p, const DevKey &key, const PrimeCtx &c,
                                              const AccLds<LOGN> &lds_acc, uint32_t *scr,
                                              int lane, int q, int i, int u, int abar, bool swap_outputs,
                                              Acc0T (&acc0)[WaveNtt<LOGN>::REGS], Acc1T (&acc1)[WaveNtt<LOGN>::REGS],
-                                             int jbegin = 0, int jend = -1) {
+                                             const typename WaveNtt<LOGN>::FwdTw0 &t0, int jbegin = 0, int jend = -1) {
     using NTT = WaveNtt<LOGN>;
     constexpr int N = NTT::N, REGS = NTT::REGS, G4 = REGS / 4;
     // a sum is kept in 64 bits and reduced once, or Montgomery-reduced per row (|.| < 0.72P each)
@@ -312,11 +312,11 @@ __device__ __forceinline__ void forward_poly(const DevParams &p, const DevKey &k
         const int shift = 32 - (jj + 1) * width;
         int32_t x[REGS];
         if constexpr (KEEP_D) {
-            NTT::template forward_digits<EARLY_TW, TABLE>(x, Dk, shift, width, c, scr, lane);
+            NTT::template forward_digits<EARLY_TW, TABLE>(x, Dk, shift, width, c, scr, lane, t0);
         } else {
             uint32_t D[REGS];
             lds_acc.template rotated_difference<REGS>(D, u, lane, abar, p.decomp_offset);
-            NTT::template forward_digits<EARLY_TW, TABLE>(x, D, shift, width, c, scr, lane);
+            NTT::template forward_digits<EARLY_TW, TABLE>(x, D, shift, width, c, scr, lane, t0);
         }
         if constexpr (LATE_B0) {
 #pragma unroll
@@ -416,16 +416,17 @@ __global__ __launch_bounds__(128) void blind_rotate_kernel(DevParams p, DevKey k
     }
     __syncthreads();
 
-
+    typename NTT::FwdTw0 t0;
+    t0.load(c, lane);
     for (int i = 0; i < n; ++i) {
         const int abar = __builtin_amdgcn_readfirstlane((int)lds_bar[i]);
         if (abar == 0) continue;                            // tfhe_blindRotate_FFT skips these too
 
         int64_t acc0[REGS], acc1[REGS];
-        forward_poly<LOGN, true, true, true, false>(p, key, c, lds_acc, scr, lane, q, i, 0, abar, false, acc0, acc1);
-        forward_poly<LOGN, false, true, true, false>(p, key, c, lds_acc, scr, lane, q, i, 1, abar, false, acc0, acc1);
+        forward_poly<LOGN, true, true, true, false>(p, key, c, lds_acc, scr, lane, q, i, 0, abar, false, acc0, acc1, t0);
+        forward_poly<LOGN, false, true, true, false>(p, key, c, lds_acc, scr, lane, q, i, 1, abar, false, acc0, acc1, t0);
 
-        uint32_t y0[REGS], y1[REGS];
+        int32_t y0[REGS], y1[REGS];
         finish_inverse<LOGN>(acc0, y0, c, scr, lane);
         finish_inverse<LOGN>(acc1, y1, c, scr, lane);
 
@@ -433,18 +434,18 @@ __global__ __launch_bounds__(128) void blind_rotate_kernel(DevParams p, DevKey k
         const uint32_t *oscr = lds_scr[1 - q];
         if (q == 0) {
 #pragma unroll
-            for (int r = 0; r < REGS; ++r) scr[r * 64 + lane] = y1[r];
+            for (int r = 0; r < REGS; ++r) scr[r * 64 + lane] = (uint32_t)y1[r];
             __syncthreads();
 #pragma unroll
             for (int r = 0; r < REGS; ++r)
-                lds_acc.set(0, r * 64 + lane, lds_acc.get(0, r * 64 + lane) + crt_to_torus(y0[r], oscr[r * 64 + lane]));
+                lds_acc.set(0, r * 64 + lane, lds_acc.get(0, r * 64 + lane) + crt_signed_to_torus(y0[r], (int32_t)oscr[r * 64 + lane]));
         } else {
 #pragma unroll
-            for (int r = 0; r < REGS; ++r) scr[r * 64 + lane] = y0[r];
+            for (int r = 0; r < REGS; ++r) scr[r * 64 + lane] = (uint32_t)y0[r];
             __syncthreads();
 #pragma unroll
             for (int r = 0; r < REGS; ++r)
-                lds_acc.set(1, r * 64 + lane, lds_acc.get(1, r * 64 + lane) + crt_to_torus(oscr[r * 64 + lane], y1[r]));
+                lds_acc.set(1, r * 64 + lane, lds_acc.get(1, r * 64 + lane) + crt_signed_to_torus((int32_t)oscr[r * 64 + lane], y1[r]));
         }
         __syncthreads();
     }
@@ -537,6 +538,8 @@ __device__ __forceinline__ void blind_rotate4_body(const DevParams &p, const Dev
     __syncthreads();
 
     STAMP_DECL;
+    typename NTT::FwdTw0 t0;                 // first-pass twiddles of every forward transform: loaded once (forward_poly)
+    t0.load(c, lane);
 
     for (int i = 0; i < n; ++i) {
         if (p.fair_shift > 0) {
@@ -556,7 +559,7 @@ __device__ __forceinline__ void blind_rotate4_body(const DevParams &p, const Dev
         Acc0T acc0[REGS];
         Acc1T acc1[REGS];
         forward_poly<LOGN, true, TR::KEEP_D, TR::EARLY_TW, TAB, Acc0T, Acc1T>(p, key, c, sh.acc, scr, lane, q, i, u, abar,
-                                                                             u != 0, acc0, acc1);
+                                                                             u != 0, acc0, acc1, t0);
         STAMP(1);
 
         int32_t t[REGS];
@@ -571,8 +574,11 @@ __device__ __forceinline__ void blind_rotate4_body(const DevParams &p, const Dev
             }
             NTT::write_row(send, sh.x1(wv), lane);
         }
+        // the first twiddles of the inverse transform are requested before the barrier and arrive while the wave waits
+        typename NTT::InvTw2 t2;
+        t2.load(c, lane);
         STAMP(2);
-        __syncthreads();
+        lds_barrier();
         STAMP(3);
         {
             int32_t other[REGS];
@@ -580,11 +586,8 @@ __device__ __forceinline__ void blind_rotate4_body(const DevParams &p, const Dev
 #pragma unroll
             for (int r = 0; r < REGS; ++r) t[r] += other[r];       // |.| < 3.4P (the inverse takes < 4P)
         }
-        if constexpr (TR::MERGED_BUFFERS) __syncthreads();         // partner has read my sums: the buffer is scratch again
-        NTT::template inverse<TR::EARLY_TW>(t, c, scr, lane);
-        uint32_t y[REGS];
-#pragma unroll
-        for (int r = 0; r < REGS; ++r) y[r] = canon(t[r], c.P);
+        if constexpr (TR::MERGED_BUFFERS) lds_barrier();          // partner has read my sums: the buffer is scratch again
+        NTT::template inverse<TR::EARLY_TW>(t, c, scr, lane, t2);  // signed residues, |t| < P: recombined as they are
         STAMP(4);
 
         // CRT of output poly u is split with wave (1-q,u): wave q recombines registers [q*HALF, (q+1)*HALF)
@@ -592,22 +595,22 @@ __device__ __forceinline__ void blind_rotate4_body(const DevParams &p, const Dev
         uint32_t *mx = sh.x2(wv);
         if (q == 0) {
 #pragma unroll
-            for (int r = 0; r < HALF; ++r) mx[r * 64 + lane] = y[HALF + r];
-            __syncthreads();
+            for (int r = 0; r < HALF; ++r) mx[r * 64 + lane] = (uint32_t)t[HALF + r];
+            lds_barrier();
 #pragma unroll
             for (int r = 0; r < HALF; ++r)
-                sh.acc.set(u, r * 64 + lane, sh.acc.get(u, r * 64 + lane) + crt_to_torus(y[r], ox[r * 64 + lane]));
+                sh.acc.set(u, r * 64 + lane, sh.acc.get(u, r * 64 + lane) + crt_signed_to_torus(t[r], (int32_t)ox[r * 64 + lane]));
         } else {
 #pragma unroll
-            for (int r = 0; r < HALF; ++r) mx[r * 64 + lane] = y[r];
-            __syncthreads();
+            for (int r = 0; r < HALF; ++r) mx[r * 64 + lane] = (uint32_t)t[r];
+            lds_barrier();
 #pragma unroll
             for (int r = 0; r < HALF; ++r)
                 sh.acc.set(u, (HALF + r) * 64 + lane,
-                           sh.acc.get(u, (HALF + r) * 64 + lane) + crt_to_torus(ox[r * 64 + lane], y[HALF + r]));
+                           sh.acc.get(u, (HALF + r) * 64 + lane) + crt_signed_to_torus((int32_t)ox[r * 64 + lane], t[HALF + r]));
         }
         STAMP(5);
-        __syncthreads();
+        lds_barrier();
         STAMP(6);
     }
     STAMP_FLUSH;
@@ -722,6 +725,8 @@ __global__ __launch_bounds__(512, 2) void blind_rotate8_kernel(
     __syncthreads();
 
     const int last = p.l - 1;
+    typename NTT::FwdTw0 t0;
+    t0.load(c, lane);
     for (int i = 0; i < n; ++i) {
         const int abar = __builtin_amdgcn_readfirstlane((int)sh.bar[i]);
         if (abar == 0) continue;
@@ -729,7 +734,7 @@ __global__ __launch_bounds__(512, 2) void blind_rotate8_kernel(
         int32_t t[REGS];
         if (!role_b) {
             forward_poly<LOGN, true, true, true, TAB, int64_t, int64_t>(p, key, c, sh.acc, scr, lane, q, i, u, abar, u != 0,
-                                                                      acc0, acc1, 0, last);
+                                                                      acc0, acc1, t0, 0, last);
             int32_t s1[REGS];
 #pragma unroll
             for (int r = 0; r < REGS; ++r) {
@@ -740,7 +745,7 @@ __global__ __launch_bounds__(512, 2) void blind_rotate8_kernel(
             NTT::write_row(s1, sh.pa1[base], lane);
         } else {
             forward_poly<LOGN, true, true, true, TAB, int64_t, int64_t>(p, key, c, sh.acc, scr, lane, q, i, u, abar, u != 0,
-                                                                      acc0, acc1, last, last + 1);
+                                                                      acc0, acc1, t0, last, last + 1);
             int32_t s1[REGS];
 #pragma unroll
             for (int r = 0; r < REGS; ++r) {
@@ -749,8 +754,9 @@ __global__ __launch_bounds__(512, 2) void blind_rotate8_kernel(
             }
             NTT::write_row(s1, sh.pb[base], lane);
         }
-        __syncthreads();
-        uint32_t y[REGS];
+        typename NTT::InvTw2 t2;                            // requested before the barrier, in flight across it
+        if (role_b) t2.load(c, lane);
+        lds_barrier();
         if (role_b) {
             int32_t o[REGS];
             NTT::read_row(o, sh.pa0[base], lane);
@@ -762,28 +768,26 @@ __global__ __launch_bounds__(512, 2) void blind_rotate8_kernel(
             NTT::read_row(o, sh.pb[base ^ 2], lane);
 #pragma unroll
             for (int r = 0; r < REGS; ++r) t[r] += o[r];                // |.| < 3.3P (the inverse takes < 4P)
-            NTT::template inverse<true>(t, c, scr, lane);
-#pragma unroll
-            for (int r = 0; r < REGS; ++r) y[r] = canon(t[r], c.P);
+            NTT::template inverse<true>(t, c, scr, lane, t2);           // signed residues, |t| < P
             uint32_t *mx = sh.half[base];
 #pragma unroll
-            for (int r = 0; r < HALF; ++r) mx[r * 64 + lane] = q == 0 ? y[HALF + r] : y[r];
+            for (int r = 0; r < HALF; ++r) mx[r * 64 + lane] = (uint32_t)(q == 0 ? t[HALF + r] : t[r]);
         }
-        __syncthreads();
+        lds_barrier();
         if (role_b) {
             const uint32_t *ox = sh.half[base ^ 1];
             if (q == 0) {
 #pragma unroll
                 for (int r = 0; r < HALF; ++r)
-                    sh.acc.set(u, r * 64 + lane, sh.acc.get(u, r * 64 + lane) + crt_to_torus(y[r], ox[r * 64 + lane]));
+                    sh.acc.set(u, r * 64 + lane, sh.acc.get(u, r * 64 + lane) + crt_signed_to_torus(t[r], (int32_t)ox[r * 64 + lane]));
             } else {
 #pragma unroll
                 for (int r = 0; r < HALF; ++r)
                     sh.acc.set(u, (HALF + r) * 64 + lane,
-                               sh.acc.get(u, (HALF + r) * 64 + lane) + crt_to_torus(ox[r * 64 + lane], y[HALF + r]));
+                               sh.acc.get(u, (HALF + r) * 64 + lane) + crt_signed_to_torus((int32_t)ox[r * 64 + lane], t[HALF + r]));
             }
         }
-        __syncthreads();
+        lds_barrier();
     }
     extract_sample<LOGN, 512>(p, rd, sh.acc, u_buf, acc_dbg, tid);
     clk.end(p);
@@ -830,23 +834,13 @@ struct BrSplitLds {
     uint32_t tab[2][2][TM == 2 ? 11 << SPLIT_TAB2_BITS : DIGIT_TAB];     // [prime][h][table][digit field]
 };
 
-// representative in (-2P, 2P) -> canonical
-__device__ __forceinline__ uint32_t canon2(int32_t x, uint32_t P) {
-    return csub((uint32_t)x + (((uint32_t)(x >> 31)) & (2u * P)), P);
-}
-// last inverse stage on half-transform outputs (a0, a1 modulo P0; b0, b1 modulo P1) of one coefficient
-// pair, canonical residues, CRT: the Torus32 increment of coefficient j (h = 0) or j + N/2 (h = 1)
+// last inverse stage on half-transform outputs (a0, a1 modulo P0; b0, b1 modulo P1, each below P in magnitude) of one
+// coefficient pair, then the CRT on the signed residues (|.| < 2P): the Torus32 increment of coefficient j (h = 0)
+// or j + N/2 (h = 1)
 __device__ __forceinline__ uint32_t split_finish(int h, int32_t a0, int32_t a1, int32_t b0, int32_t b1, uint32_t iw1_0,
                                                  uint32_t iw1_1) {
-    uint32_t y0, y1;
-    if (h == 0) {
-        y0 = canon2(a0 + a1, NTT_P0);
-        y1 = canon2(b0 + b1, NTT_P1);
-    } else {
-        y0 = canon(mont_mul(a0 - a1, iw1_0, NTT_P0, NTT_PINV0), NTT_P0);
-        y1 = canon(mont_mul(b0 - b1, iw1_1, NTT_P1, NTT_PINV1), NTT_P1);
-    }
-    return crt_to_torus(y0, y1);
+    if (h == 0) return crt_signed_to_torus(a0 + a1, b0 + b1);
+    return crt_signed_to_torus(mont_mul(a0 - a1, iw1_0, NTT_P0, NTT_PINV0), mont_mul(b0 - b1, iw1_1, NTT_P1, NTT_PINV1));
 }
 
 template <int LOGN, int TM>
@@ -915,6 +909,8 @@ __global__ __launch_bounds__(512, (LOGN == 10 ? 4 : 2)) void blind_rotate_split_
     // (full-size layout L2: slot j = 2 RS * lane' + reg; this lane holds slots h N/2 + RS * lane + reg)
     const int lane_off = G4 * (lane & 1) * 64 + h * 32 + (lane >> 1);
     const int o0 = u ? N / 4 : 0, o1 = N / 4 - o0;          // acc0 <- output polynomial u (kept), acc1 <- 1-u (sent)
+    typename SUB::FwdTw0 t0;                              // first-pass twiddles of the half transforms: loaded once
+    t0.load(c, lane);
     for (int i = 0; i < n; ++i) {
         const int abar = __builtin_amdgcn_readfirstlane((int)sh.bar[i]);
         if (abar == 0) continue;
@@ -930,8 +926,6 @@ __global__ __launch_bounds__(512, (LOGN == 10 ? 4 : 2)) void blind_rotate_split_
             for (int g = 0; g < G4; ++g) b0[g] = bp[o0 + g * 64];
 #pragma unroll
             for (int g = 0; g < G4; ++g) b1[g] = bp[o1 + g * 64];
-            typename SUB::FwdTw0 t0;
-            t0.load(c, lane);
             const int shift = 32 - (jj + 1) * width;
             int32_t x[RS];
             if constexpr (TM == 2) {
@@ -1006,17 +1000,19 @@ __global__ __launch_bounds__(512, (LOGN == 10 ? 4 : 2)) void blind_rotate_split_
             }
             SUB::write_row(send, sh.x1[wv], lane);
         }
-        __syncthreads();
+        typename SUB::InvTw2 t2;                            // requested before the barrier, in flight across it
+        t2.load(c, lane);
+        lds_barrier();
         {
             int32_t other[RS];
             SUB::read_row(other, sh.x1[wv ^ 2], lane);
 #pragma unroll
             for (int r = 0; r < RS; ++r) t[r] += other[r];          // |.| < 3.6P (the inverse takes < 4P)
         }
-        SUB::template inverse<true>(t, c, scr, lane);
+        SUB::template inverse<true>(t, c, scr, lane, t2);
 #pragma unroll
         for (int r = 0; r < RS; ++r) scr[r * 64 + lane] = (uint32_t)t[r];
-        __syncthreads();
+        lds_barrier();
         {
             // the four waves of output polynomial u take a quarter of the register rows each and finish
             // coefficients j and j + N/2 of it (equal work for every wave; the four words read serve both)
@@ -1031,7 +1027,7 @@ __global__ __launch_bounds__(512, (LOGN == 10 ? 4 : 2)) void blind_rotate_split_
                 sh.acc.set(u, M + jl, sh.acc.get(u, M + jl) + split_finish(1, va0, va1, vb0, vb1, iw1_0, iw1_1));
             }
         }
-        __syncthreads();
+        lds_barrier();
     }
     extract_sample<LOGN, 512>(p, rd, sh.acc, u_buf, acc_dbg, tid);
     clk.end(p);

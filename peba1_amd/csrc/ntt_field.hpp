@@ -47,5 +47,11 @@ constexpr uint32_t NTT_PINV0 = NTT_PINV_NEG[0], NTT_PINV1 = NTT_PINV_NEG[1];
 constexpr uint64_t CRT_M = (uint64_t)NTT_P[0] * NTT_P[1];
 constexpr uint64_t CRT_HALF = (CRT_M - 1) / 2;
 constexpr uint32_t CRT_M_LO = (uint32_t)CRT_M;
+// The kernels recombine SIGNED lazy residues (ntt_wave.hpp crt_signed_to_torus): the integer they form is
+// r0 + P0 t with |r0| < 2P and |t| < 0.63 P1, i.e. below 0.63 M + 2P in magnitude.  It equals the true centred
+// value -- not merely modulo M -- as long as that value is below M - (0.63 M + 2P); a key is accepted only if the
+// bound of its external product, (k+1) l N (Bg/2) 2^31, stays below this limit (0.36 M = 2^52.5; TFHE's sets reach
+// 2^49.6, the legacy Bg = 2^10 set 2^52).
+constexpr uint64_t CRT_EXACT_LIMIT = CRT_M / 100 * 36;
 
 }  // namespace tfhe_hip

@@ -91,6 +91,13 @@ __device__ __forceinline__ uint32_t canon(int32_t x, uint32_t P) { return min((u
 // needs no barrier; this only stops the compiler from reordering across it.
 __device__ __forceinline__ void wave_lds_fence() { asm volatile("" ::: "memory"); }
 
+// Workgroup barrier for data exchanged through LDS only.  __syncthreads() drains the wave's vector-memory counter too
+// (s_waitcnt vmcnt(0) in front of s_barrier), so a global load cannot be in flight across it; this one waits for the
+// wave's LDS operations alone and leaves its outstanding global loads (the next phase's twiddles and key rows,
+// requested just before) running while the wave waits for its siblings.  Nothing in the blind-rotate loop stores to
+// global memory, so there is nothing else for the barrier to order.
+__device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
 __device__ __forceinline__ void ct_bfly(int32_t &a, int32_t &b, uint32_t w, const PrimeCtx &c) {
     const int32_t t = mont_mul(b, w, c.P, c.pinv);
     const int32_t a0 = a;
@@ -416,6 +423,12 @@ struct WaveNtt {
                                                           const PrimeCtx &c, uint32_t *scr, int lane) {
         FwdTw0 t0;
         t0.load(c, lane);
+        forward_digits<EARLY, TABLE>(x, D, shift, width, c, scr, lane, t0);
+    }
+    // t0: the first pass's twiddles (lane-uniform and the same for every transform: a caller may load them once)
+    template <bool EARLY, bool TABLE>
+    static __device__ __forceinline__ void forward_digits(int32_t (&x)[REGS], const uint32_t (&D)[REGS], int shift, int width,
+                                                          const PrimeCtx &c, uint32_t *scr, int lane, const FwdTw0 &t0) {
         if constexpr (!TABLE) {
 #pragma unroll
             for (int r = 0; r < REGS; ++r) x[r] = __builtin_amdgcn_sbfe((int32_t)D[r], shift, width);
@@ -520,6 +533,18 @@ __device__ __forceinline__ uint32_t crt_to_torus(uint32_t r0, uint32_t r1) {
     t = csub(t, NTT_P1);
     const uint64_t v = (uint64_t)NTT_P0 * t + r0;
     return (uint32_t)v - (v > CRT_HALF ? CRT_M_LO : 0u);
+}
+
+// CRT of SIGNED representatives r0 (modulo P0) and r1 (modulo P1), |r0|, |r1| < 2P -- what the inverse transforms
+// leave, no canonicalisation.  With t = (r1 - r0) P0^-1 mod P1 taken as the signed Montgomery output (|t| <=
+// 4P P1 / 2^32 + P1 / 2 < 0.63 P1), x = r0 + P0 t is congruent to the value modulo both primes and |x| < 0.63 M + 2P.
+// The true centred value v satisfies |v| < CRT_EXACT_LIMIT = 0.36 M (checked at key upload), so x - v, a multiple of
+// M below M in magnitude, is 0: x IS the centred integer and its low 32 bits are r0 + P0 t in wrapping arithmetic.
+// 4 multiplier-class + 2 add instructions, where the canonical form above takes 4 + 9 and needs canonical inputs
+// (2 more per residue): 88 VALU instructions less per wave and blind-rotate step (round 3).
+__device__ __forceinline__ uint32_t crt_signed_to_torus(int32_t r0, int32_t r1) {
+    const int32_t t = mont_mul(r1 - r0, CRT_P0INV_MONT, NTT_P1, NTT_PINV1);
+    return (uint32_t)r0 + NTT_P0 * (uint32_t)t;
 }
 
 }  // namespace tfhe_hip

@@ -35,9 +35,101 @@ KEY_SEED, ENC_SEED = 0x5EBA2, 777
 TEMPLATE, PROBE, BOUND, BITS = [37, 200], [40, 190], 100, 8
 
 
+def small_circuits():
+    """--small-circuits: writes function_g_digest.json (peba1_function_g, Math.cpp:390-417 with the D4 overflow fixed:
+    b = 1, r0 = 17, r1 = 99 on 8 bits -- 2,874 blind rotations) and hamming16_digest.json (peba1_hamming_match on two
+    16-bit words against a 5-bit bound, both sides of the threshold).  A few CPU-minutes with --threads 7."""
+    threads = int(sys.argv[sys.argv.index("--threads") + 1]) if "--threads" in sys.argv else 7
+    subprocess.check_call(["make", "-s", "-C", os.path.join(ROOT, "oracle")])
+    B = C.CDLL(os.path.join(ROOT, "oracle", "liboracle_boots.so"))
+    V = C.c_void_p
+    B.orc_keygen.restype = V
+    B.orc_keygen.argtypes = [C.POINTER(O.OrcParams), C.c_uint64]
+    B.orc_boots_bind.argtypes = [V, C.c_uint64]
+    B.orc_boots_params.restype = V
+    B.orc_boots_cloud.restype = V
+    B.orc_boots_gate_count.restype = C.c_longlong
+    B.new_gate_bootstrapping_ciphertext_array.restype = V
+    B.new_gate_bootstrapping_ciphertext_array.argtypes = [C.c_int32, V]
+    B.bootsSymEncrypt.argtypes = [V, C.c_int32, V]
+    B.bootsSymDecrypt.argtypes = [V, V]
+    B.orc_boots_export.argtypes = [V, C.c_int32, V]
+    B.peba1_function_g.argtypes = [V, V, V, V, C.c_int, V]
+    B.peba1_hamming_match.argtypes = [V, V, V, C.c_int, V, V]
+    B.peba1_hamming_count_bits.argtypes = [C.c_int]
+    p = O.params("P128")
+    ks = B.orc_keygen(C.byref(p), KEY_SEED)
+    SZ = 24
+
+    def start(seed):
+        B.orc_boots_bind(ks, seed)
+        B.orc_boots_set_recording(threads)
+        return B.orc_boots_params(), B.orc_boots_cloud()
+
+    def enc(v, nb, params):
+        a = B.new_gate_bootstrapping_ciphertext_array(nb, params)
+        for i in range(nb):
+            B.bootsSymEncrypt(a + i * SZ, (v >> i) & 1, None)
+        return a
+
+    def words_of(arr, count):
+        w = np.zeros((count, p.n + 1), dtype=np.int32)
+        B.orc_boots_export(arr, count, w.ctypes.data_as(V))
+        return w
+
+    def value_of(arr, count):
+        return sum(B.bootsSymDecrypt(arr + i * SZ, None) << i for i in range(count))
+
+    # ---- Function_g ----
+    t0 = time.time()
+    params, cloud = start(778)
+    bits, b, r0, r1 = 8, 1, 17, 99
+    eb = enc(b, bits, params)          # encryption order: result_b, r0, r1
+    e0 = enc(r0, bits, params)
+    e1 = enc(r1, bits, params)
+    res = B.new_gate_bootstrapping_ciphertext_array(bits, params)
+    B.peba1_function_g(res, eb, e0, e1, bits, cloud)
+    w = words_of(res, bits)
+    assert value_of(res, bits) == r1
+    out = {"params": "P128", "circuit": "peba1_function_g", "key_seed": KEY_SEED, "encrypt_seed": 778, "bits": bits, "b": b, "r0": r0,
+           "r1": r1, "value": r1, "blind_rotates": int(B.orc_boots_gate_count()),
+           "result_sha256": hashlib.sha256(w.tobytes()).hexdigest(), "oracle_seconds": round(time.time() - t0, 1)}
+    with open(os.path.join(ROOT, "tests", "golden", "function_g_digest.json"), "w") as f:
+        json.dump(out, f, indent=1)
+    print(json.dumps(out, indent=1), flush=True)
+
+    # ---- Hamming distance + threshold on 16 bits ----
+    t0 = time.time()
+    params, cloud = start(779)
+    nbits, wa, wb = 16, 0xB3C5, 0x2E9D
+    dist = bin(wa ^ wb).count("1")
+    w_bits = B.peba1_hamming_count_bits(nbits)
+    ea = enc(wa, nbits, params)        # encryption order: a, b, then the bounds
+    eb = enc(wb, nbits, params)
+    bounds = [dist, dist - 1]
+    ebs = [enc(v, w_bits, params) for v in bounds]
+    runs = []
+    for bound, ebound in zip(bounds, ebs):
+        before = B.orc_boots_gate_count()
+        rb = B.new_gate_bootstrapping_ciphertext_array(w_bits, params)
+        B.peba1_hamming_match(rb, ea, eb, nbits, ebound, cloud)
+        w = words_of(rb, w_bits)
+        bit = B.bootsSymDecrypt(rb, None)
+        assert bit == (1 if dist > bound else 0)
+        runs.append({"bound": bound, "match_bit": int(bit), "blind_rotates_recorded": int(B.orc_boots_gate_count() - before),
+                     "result_b_sha256": hashlib.sha256(w.tobytes()).hexdigest()})
+    out = {"params": "P128", "circuit": "peba1_hamming_match", "key_seed": KEY_SEED, "encrypt_seed": 779, "nbits": nbits, "a": wa, "b": wb,
+           "distance": dist, "count_bits": w_bits, "runs": runs, "oracle_seconds": round(time.time() - t0, 1)}
+    with open(os.path.join(ROOT, "tests", "golden", "hamming16_digest.json"), "w") as f:
+        json.dump(out, f, indent=1)
+    print(json.dumps(out, indent=1), flush=True)
+
+
 def main():
     if "--slots128" in sys.argv[1:]:
         return slots128()
+    if "--small-circuits" in sys.argv[1:]:
+        return small_circuits()
     fast = "--fast" in sys.argv[1:]
     pname = "P2048" if "--p2048" in sys.argv[1:] else "P128"
     subprocess.check_call(["make", "-s", "-C", os.path.join(ROOT, "oracle")])

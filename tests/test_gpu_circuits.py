@@ -203,6 +203,83 @@ def test_function_f_ciphertexts_match_oracle_digest(p128_keys, fixture, circuit,
             own_keys.close()
 
 
+def test_function_f_128_slots_ciphertexts_match_oracle_digest(p128_keys):
+    """BASELINE configs[1] at its own size, word for word (VERDICT r2 top item; SURVEY 8(d) cfg2: "memcmp vs CPU oracle on
+    every output ciphertext"): the complete 128-slot x 8-bit Function_f of /root/reference/src/Math.cpp:379-387 -- 215,544
+    blind rotations, the 6,276-wide first level, the 260-level ripple tail, 377 scheduled levels with slack moves -- on the
+    inputs of SURVEY 8(c) (template (37 i + 11) mod 255, genuine probe = template + 1), against the encrypted bounds 256
+    and 0, in the library's default mode.  All 24 output ciphertexts of both runs hash to what the CPU oracle produced
+    through the same circuit library (tests/golden/make_function_f_digest.py --slots128: the recorded DAG evaluated level
+    by level on host threads, about an hour of 7 cores)."""
+    import hashlib
+    import json
+    from types import SimpleNamespace
+    from peba1_amd import api, circuits, lib
+    pp, ks, _ = p128_keys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    with open(os.path.join(root, "tests", "golden", "function_f_128_digest.json")) as f:
+        g = json.load(f)
+    assert g["key_seed"] == 0x5EBA2 and g["nslots"] == 128 and g["bits"] == 8
+    L = lib.load()
+    L.tfhe_hip_set_encrypt_seed(g["encrypt_seed"])
+    template = [(37 * i + 11) % 255 for i in range(g["nslots"])]
+    probe = [t + 1 for t in template]
+    assert sum((a - b) ** 2 for a, b in zip(probe, template)) == g["distance"]
+    T, S = [], []
+    for t, s in zip(template, probe):                    # encryption order is part of the fixture
+        T.append(circuits.encrypt_number(pp, t, g["bits"], ks))
+        S.append(circuits.encrypt_number(pp, s, g["bits"], ks))
+    bounds = [circuits.encrypt_number(pp, b, 3 * g["bits"], ks) for b in g["bounds"]]
+    assert api.get_deferred()                            # the default: the reference's calls are recorded
+    for run, bound in zip(g["runs"], bounds):
+        rb = api.CiphertextArray(pp, 3 * g["bits"])
+        api.reset_stats()
+        circuits.function_f(rb, SimpleNamespace(slots=S), SimpleNamespace(slots=T), bound, g["bits"], ks)
+        words = rb.words()                               # runs the pending gates
+        st = api.stats()
+        assert st["blind_rotates"] + st["reused_gates"] <= run["blind_rotates_recorded"] <= st["blind_rotates"] + 2 * st["reused_gates"]
+        assert hashlib.sha256(words[0].tobytes()).hexdigest() == run["result_b0_sha256"], run["bound"]
+        assert hashlib.sha256(words.tobytes()).hexdigest() == run["result_b_sha256"], run["bound"]
+        assert rb.decrypt(ks)[0] == run["match_bit"] == (1 if g["distance"] > run["bound"] else 0)
+
+
+def test_function_g_and_hamming_ciphertexts_match_oracle_digests(p128_keys):
+    """the protocol's second function and the Hamming workload were checked at decrypt level only.
+    peba1_function_g (Math.cpp:390-417, b = 1: selects r1; 2,874 blind rotations) and peba1_hamming_match on 16-bit words
+    (both sides of the threshold) reproduce, word for word, the SHA-256 of the output ciphertexts the CPU oracle produced
+    through the same circuit library (tests/golden/make_function_f_digest.py --small-circuits)."""
+    import hashlib
+    import json
+    from peba1_amd import api, circuits, lib
+    pp, ks, _ = p128_keys
+    L = lib.load()
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    with open(os.path.join(root, "tests", "golden", "function_g_digest.json")) as f:
+        g = json.load(f)
+    assert g["key_seed"] == 0x5EBA2
+    L.tfhe_hip_set_encrypt_seed(g["encrypt_seed"])
+    eb = circuits.encrypt_number(pp, g["b"], g["bits"], ks)          # encryption order is part of the fixture
+    e0 = circuits.encrypt_number(pp, g["r0"], g["bits"], ks)
+    e1 = circuits.encrypt_number(pp, g["r1"], g["bits"], ks)
+    res = api.CiphertextArray(pp, g["bits"])
+    circuits.function_g(res, eb, e0, e1, g["bits"], ks)
+    assert hashlib.sha256(res.words().tobytes()).hexdigest() == g["result_sha256"]
+    assert circuits.decrypt_number(res, ks) == g["value"] == g["r1"]
+
+    with open(os.path.join(root, "tests", "golden", "hamming16_digest.json")) as f:
+        h = json.load(f)
+    L.tfhe_hip_set_encrypt_seed(h["encrypt_seed"])
+    ea = circuits.encrypt_number(pp, h["a"], h["nbits"], ks)
+    eb = circuits.encrypt_number(pp, h["b"], h["nbits"], ks)
+    assert circuits.hamming_count_bits(h["nbits"]) == h["count_bits"]
+    bounds = [circuits.encrypt_number(pp, r["bound"], h["count_bits"], ks) for r in h["runs"]]
+    for run, bound in zip(h["runs"], bounds):
+        rb = api.CiphertextArray(pp, h["count_bits"])
+        circuits.hamming_match(rb, ea, eb, h["nbits"], bound, ks)
+        assert hashlib.sha256(rb.words().tobytes()).hexdigest() == run["result_b_sha256"], run["bound"]
+        assert rb.decrypt(ks)[0] == run["match_bit"] == (1 if h["distance"] > run["bound"] else 0)
+
+
 def test_gate_reuse_is_transparent(p128_keys):
     """reuse_gates: a 3-slot Function_f with and without sharing of identical pending gates --
     fewer blind rotations, the same 24 output ciphertexts."""
