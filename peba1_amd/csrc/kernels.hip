@@ -53,6 +53,8 @@ __device__ __forceinline__ PrimeCtx make_ctx(int q, const uint32_t *tw, int n_ri
     c.qf = quads + (size_t)(q * 2 + 0) * (n_ring / 2);
     c.qi = quads + (size_t)(q * 2 + 1) * (n_ring / 2);
     c.dtab = nullptr;
+    c.fw1 = nullptr;
+    c.fw2 = nullptr;
     return c;
 }
 
@@ -232,6 +234,9 @@ struct BrTraits {
     static constexpr bool EARLY_TW = true;                      // twiddles of a pass loaded before the transpose in front of it
     static constexpr int ACC_RUNS = LOGN == 10 ? 3 : 2;
     static constexpr bool MERGED_BUFFERS = LEAN;
+    // the per-lane twiddles of the forward transforms' second and third pass live in LDS (ntt_wave.hpp forward_digits
+    // LDSTW): the default form at N = 1024, whose 80,400 bytes still let two workgroups share a CU
+    static constexpr bool LDS_TWIDDLES = LOGN == 10 && V == 0;
     static constexpr int WAVES_PER_SIMD = LOGN == 10 && V == 1 ? 3 : 2;
 };
 
@@ -278,7 +283,7 @@ struct AccLds {
 // t0: the twiddles of the transforms' first pass -- lane-uniform and the same for every row and step, so the caller
 // loads them ONCE per kernel (they then live in scalar registers; round 3: -1.4 % of a wide launch against loading
 // them per row, and 12 fewer vector registers)
-template <int LOGN, bool FRESH, bool KEEP_D, bool EARLY_TW, bool TABLE, typename Acc0T, typename Acc1T>
+template <int LOGN, bool FRESH, bool KEEP_D, bool EARLY_TW, bool TABLE, typename Acc0T, typename Acc1T, bool LDSTW = false>
 __device__ __forceinline__ void forward_poly(const DevParams &p, const DevKey &key, const PrimeCtx &c,
                                              const AccLds<LOGN> &lds_acc, uint32_t *scr,
                                              int lane, int q, int i, int u, int abar, bool swap_outputs,
@@ -312,11 +317,11 @@ __device__ __forceinline__ void forward_poly(const DevParams &p, const DevKey &k
         const int shift = 32 - (jj + 1) * width;
         int32_t x[REGS];
         if constexpr (KEEP_D) {
-            NTT::template forward_digits<EARLY_TW, TABLE>(x, Dk, shift, width, c, scr, lane, t0);
+            NTT::template forward_digits<EARLY_TW, TABLE, LDSTW>(x, Dk, shift, width, c, scr, lane, t0);
         } else {
             uint32_t D[REGS];
             lds_acc.template rotated_difference<REGS>(D, u, lane, abar, p.decomp_offset);
-            NTT::template forward_digits<EARLY_TW, TABLE>(x, D, shift, width, c, scr, lane, t0);
+            NTT::template forward_digits<EARLY_TW, TABLE, LDSTW>(x, D, shift, width, c, scr, lane, t0);
         }
         if constexpr (LATE_B0) {
 #pragma unroll
@@ -484,23 +489,28 @@ __device__ unsigned long long g_stamps[4][8];
 // inverse NTT for output polynomial u, and shares the CRT with wave (1-q,u).
 // Three workgroup barriers per step.  N = 1024: 2 workgroups per CU; N = 2048: 1.
 // ---------------------------------------------------------------------------
-// LDS of one 4-wave workgroup.  Each wave has three exchange areas: scratch of its NTT transposes
-// (private), the partial sums it sends to the wave of the other input polynomial, and the
-// residues of the half its CRT partner recombines.  MERGED_BUFFERS: all three are one buffer (the
-// uses are disjoint in time given one more barrier per step, see blind_rotate4_body).
+// LDS of one 4-wave workgroup.  Each wave has two exchange areas: the scratch of its NTT transposes (private while
+// a transform runs; from the end of its inverse transform to the step's last barrier it carries the residues of the
+// half its CRT partner recombines -- nobody else touches it in between) and the partial sums it sends to the wave of
+// the other input polynomial.  MERGED_BUFFERS: both are one buffer (one more barrier per step, blind_rotate4_body).
 template <int LOGN, int V = 0>
 struct Br4Lds {
     using NTT = WaveNtt<LOGN>;
     static constexpr bool MERGED = BrTraits<LOGN, V>::MERGED_BUFFERS;
+    static constexpr bool LTW = BrTraits<LOGN, V>::LDS_TWIDDLES;
     AccLds<LOGN> acc;                              // the accumulator (signed runs), resident for all n steps
     uint32_t buf[MERGED ? 1 : 2][4][NTT::SCRATCH_WORDS];
-    uint32_t half[MERGED ? 1 : 4][MERGED ? 4 : NTT::N / 2];     // separate buffers: the CRT partner's residues (half a polynomial)
     uint16_t bar[1024 + 8];                        // modulus-switched mask and body
     uint32_t dtab[2][5 * DIGIT_TAB];               // per prime: first-step products of the gadget digits (ntt_wave.hpp)
+    // per prime: the forward transforms' second-pass twiddles (one image per group of 2^LC lanes) and third-pass
+    // twiddles (one per lane)
+    uint4 ft1[LTW ? 2 : 1][LTW ? (64 >> NTT::LC) : 1][NTT::FwdTw1::IMAGE16];
+    uint4 ft2[LTW ? 2 : 1][LTW ? 64 : 1][NTT::FwdTw2::IMAGE16];
     __device__ __forceinline__ uint32_t *scr(int wv) { return buf[0][wv]; }
     __device__ __forceinline__ uint32_t *x1(int wv) { return buf[MERGED ? 0 : 1][wv]; }
-    __device__ __forceinline__ uint32_t *x2(int wv) { if constexpr (MERGED) return buf[0][wv]; else return half[wv]; }
+    __device__ __forceinline__ uint32_t *x2(int wv) { return buf[0][wv]; }
 };
+static_assert(sizeof(Br4Lds<10, 0>) <= 80 * 1024, "two workgroups of the default form must fit the 160 KB of a CU");
 
 // prelude + modulus switch + the n-step blind rotation of one descriptor; the result is left
 // in sh.acc (complete for every thread on return)
@@ -525,6 +535,19 @@ __device__ __forceinline__ void blind_rotate4_body(const DevParams &p, const Dev
         // the two waves of prime q (tid bits 6 and 7 = q and u) fill that prime's table
         NTT::build_digit_table(sh.dtab[q], c, p.Bgbit, (u << 6) | lane, 128);
         c.dtab = sh.dtab[q];
+    }
+    if constexpr (TR::LDS_TWIDDLES) {
+        // wave (q, 0) copies prime q's pass-2 / pass-3 twiddles of the forward transforms into LDS, once
+        if (u == 0) {
+            typename NTT::FwdTw1 a;
+            a.load(c, lane);
+            if ((lane & ((1 << NTT::LC) - 1)) == 0) a.to_image(sh.ft1[q][lane >> NTT::LC]);
+            typename NTT::FwdTw2 b;
+            b.load(c, lane);
+            b.to_image(sh.ft2[q][lane]);
+        }
+        c.fw1 = sh.ft1[q][lane >> NTT::LC];
+        c.fw2 = sh.ft2[q][lane];
     }
     __syncthreads();
     if (q == 0) {
@@ -558,8 +581,8 @@ __device__ __forceinline__ void blind_rotate4_body(const DevParams &p, const Dev
         using Acc1T = typename std::conditional<TR::WIDE_SEND, int64_t, int32_t>::type;
         Acc0T acc0[REGS];
         Acc1T acc1[REGS];
-        forward_poly<LOGN, true, TR::KEEP_D, TR::EARLY_TW, TAB, Acc0T, Acc1T>(p, key, c, sh.acc, scr, lane, q, i, u, abar,
-                                                                             u != 0, acc0, acc1, t0);
+        forward_poly<LOGN, true, TR::KEEP_D, TR::EARLY_TW, TAB, Acc0T, Acc1T, TR::LDS_TWIDDLES>(p, key, c, sh.acc, scr, lane, q, i, u,
+                                                                                               abar, u != 0, acc0, acc1, t0);
         STAMP(1);
 
         int32_t t[REGS];
@@ -667,14 +690,27 @@ __global__ __launch_bounds__(256, (BrTraits<LOGN, V>::WAVES_PER_SIMD)) void blin
 // multiplier-class instructions at half the rate two waves share (v_mad_i64_i32: 10 cycles
 // against 5; profiles/r01_valu_rates.txt).  Here a second wave sits on each SIMD: for prime q and
 // input polynomial u, wave A = (q,u,0) transforms and multiplies the gadget rows 0..l-2, wave
-// B = (q,u,1) the last row, then B adds the four partial sums of its output polynomial (its own,
-// A's, and the two the waves of the other input polynomial send), runs the inverse transform,
-// shares the CRT with B of the other prime and updates the accumulator.  A is idle during the
-// inverse: the gain is the forward phase at shared issue rates (~25 % per step), which is what a
-// narrow level, a single gate (immediate mode) or a short circuit between two decryptions
-// (the reference's own test program) are made of.  Same integers as the other forms.  N = 1024,
-// l >= 2; three workgroup barriers per step.
+// B = (q,u,1) the last row; all four partial sums of an output polynomial (A's and B's own, and the
+// two the waves of the other input polynomial send) go through LDS.  The inverse transform is then SPLIT
+// over the pair (round 3): a Cooley-Tukey spectrum is two independent half-size spectra, so A takes the
+// lower half of the summed spectrum and B the upper half, each runs an N/2-point inverse transform
+// (WaveNtt<LOGN-1> with the sub-tree twiddles of the split kernel), and the stage-0 butterflies, the CRT
+// and the accumulator update are shared by the four waves of the output polynomial exactly as in the
+// split kernel (split_finish).  In round 2 only B ran a (full-size) inverse while A idled: a lone wave
+// issues multiplier-class instructions at half the rate two waves share, and the inverse phase was 40 %
+// of a step.  This is the form for narrow levels, single gates (immediate mode) and the short circuits
+// between two decryptions that the reference's own test program is made of.  Same integers as the
+// other forms.  N = 1024, l >= 2; three workgroup barriers per step.
 // ---------------------------------------------------------------------------
+// last inverse stage on half-transform outputs (a0, a1 modulo P0; b0, b1 modulo P1, each below P in magnitude) of one
+// coefficient pair, then the CRT on the signed residues (|.| < 2P): the Torus32 increment of coefficient j (h = 0)
+// or j + N/2 (h = 1)
+__device__ __forceinline__ uint32_t split_finish(int h, int32_t a0, int32_t a1, int32_t b0, int32_t b1, uint32_t iw1_0,
+                                                 uint32_t iw1_1) {
+    if (h == 0) return crt_signed_to_torus(a0 + a1, b0 + b1);
+    return crt_signed_to_torus(mont_mul(a0 - a1, iw1_0, NTT_P0, NTT_PINV0), mont_mul(b0 - b1, iw1_1, NTT_P1, NTT_PINV1));
+}
+
 template <int LOGN>
 struct Br8Lds {
     using NTT = WaveNtt<LOGN>;
@@ -682,10 +718,13 @@ struct Br8Lds {
     uint32_t scr[8][NTT::SCRATCH_WORDS];           // wave-private NTT transposes
     uint32_t pa0[4][NTT::SCRATCH_WORDS];           // A's sum for its own output polynomial (read by its B)
     uint32_t pa1[4][NTT::SCRATCH_WORDS];           // A's sum for the other output polynomial (read by the other B)
+    uint32_t pb0[4][NTT::SCRATCH_WORDS];           // B's sum for its own output polynomial
     uint32_t pb[4][NTT::SCRATCH_WORDS];            // B's sum for the other output polynomial
-    uint32_t half[4][NTT::N / 2];                  // residues of the half the CRT partner recombines
     uint16_t bar[1024 + 8];
     uint32_t dtab[2][5 * DIGIT_TAB];
+    // per prime: LDS copies of the forward transforms' second- and third-pass twiddles (as in Br4Lds)
+    uint4 ft1[2][64 >> NTT::LC][NTT::FwdTw1::IMAGE16];
+    uint4 ft2[2][64][NTT::FwdTw2::IMAGE16];
 };
 
 template <int LOGN, bool TAB>
@@ -693,14 +732,18 @@ __global__ __launch_bounds__(512, 2) void blind_rotate8_kernel(
     DevParams p, DevKey key, const int32_t *__restrict__ pool, const RotDesc *__restrict__ rots,
     int32_t *__restrict__ u_buf, int32_t *__restrict__ acc_dbg) {
     using NTT = WaveNtt<LOGN>;
-    constexpr int N = NTT::N, REGS = NTT::REGS, HALF = REGS / 2;
+    using SUB = WaveNtt<LOGN - 1>;
+    constexpr int N = NTT::N, M = N / 2, REGS = NTT::REGS, RS = SUB::REGS, QUARTER = RS / 4;
     __shared__ __align__(16) Br8Lds<LOGN> sh;
     const int tid = threadIdx.x;
     const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int base = wv & 3, q = base & 1, u = base >> 1;
     const bool role_b = wv >= 4;
+    const int h = wv >> 2;                              // the half of every inverse transform this wave runs
     const int lane = tid & 63;
     PrimeCtx c = make_ctx(q, key.tw, N);
+    const PrimeCtx ch = make_sub_ctx(q, h, key.tw, N);  // twiddles of half h (engine.cpp make_twiddles)
+    const uint32_t iw1_0 = key.tw[(size_t)1 * N + 1], iw1_1 = key.tw[(size_t)3 * N + 1];   // inverse stage 0, both primes
     uint32_t *scr = sh.scr[wv];
     const int n = p.n;
     const RotDesc rd = rots[blockIdx.x];
@@ -713,6 +756,16 @@ __global__ __launch_bounds__(512, 2) void blind_rotate8_kernel(
         NTT::build_digit_table(sh.dtab[q], c, p.Bgbit, ((wv >> 1) << 6) | lane, 256);
         c.dtab = sh.dtab[q];
     }
+    if (wv < 2) {                                    // waves 0 and 1 = (q, u = 0, A): prime q's twiddles into LDS, once
+        typename NTT::FwdTw1 a;
+        a.load(c, lane);
+        if ((lane & ((1 << NTT::LC) - 1)) == 0) a.to_image(sh.ft1[q][lane >> NTT::LC]);
+        typename NTT::FwdTw2 b;
+        b.load(c, lane);
+        b.to_image(sh.ft2[q][lane]);
+    }
+    c.fw1 = sh.ft1[q][lane >> NTT::LC];
+    c.fw2 = sh.ft2[q][lane];
     __syncthreads();
     if (q == 0 && !role_b) {
         const int barb = sh.bar[n];
@@ -730,61 +783,58 @@ __global__ __launch_bounds__(512, 2) void blind_rotate8_kernel(
     for (int i = 0; i < n; ++i) {
         const int abar = __builtin_amdgcn_readfirstlane((int)sh.bar[i]);
         if (abar == 0) continue;
-        int64_t acc0[REGS], acc1[REGS];                 // output poly u (kept in the pair), output poly 1-u (sent)
-        int32_t t[REGS];
-        if (!role_b) {
-            forward_poly<LOGN, true, true, true, TAB, int64_t, int64_t>(p, key, c, sh.acc, scr, lane, q, i, u, abar, u != 0,
-                                                                      acc0, acc1, t0, 0, last);
-            int32_t s1[REGS];
+        {
+            int64_t acc0[REGS], acc1[REGS];             // output poly u, output poly 1-u
+            if (!role_b)
+                forward_poly<LOGN, true, true, true, TAB, int64_t, int64_t, true>(p, key, c, sh.acc, scr, lane, q, i, u, abar, u != 0,
+                                                                                acc0, acc1, t0, 0, last);
+            else
+                forward_poly<LOGN, true, true, true, TAB, int64_t, int64_t, true>(p, key, c, sh.acc, scr, lane, q, i, u, abar, u != 0,
+                                                                                acc0, acc1, t0, last, last + 1);
+            int32_t s0[REGS], s1[REGS];
 #pragma unroll
             for (int r = 0; r < REGS; ++r) {
-                t[r] = mont_redc(acc0[r], c.P, c.pinv);                 // l-1 rows: |.| < 0.93P
+                s0[r] = mont_redc(acc0[r], c.P, c.pinv);                // at most l-1 rows: |.| < 0.93P
                 s1[r] = mont_redc(acc1[r], c.P, c.pinv);
             }
-            NTT::write_row(t, sh.pa0[base], lane);
-            NTT::write_row(s1, sh.pa1[base], lane);
-        } else {
-            forward_poly<LOGN, true, true, true, TAB, int64_t, int64_t>(p, key, c, sh.acc, scr, lane, q, i, u, abar, u != 0,
-                                                                      acc0, acc1, t0, last, last + 1);
-            int32_t s1[REGS];
-#pragma unroll
-            for (int r = 0; r < REGS; ++r) {
-                t[r] = mont_redc(acc0[r], c.P, c.pinv);                 // one row: |.| < 0.72P
-                s1[r] = mont_redc(acc1[r], c.P, c.pinv);
-            }
-            NTT::write_row(s1, sh.pb[base], lane);
+            NTT::write_row(s0, role_b ? sh.pb0[base] : sh.pa0[base], lane);
+            NTT::write_row(s1, role_b ? sh.pb[base] : sh.pa1[base], lane);
         }
-        typename NTT::InvTw2 t2;                            // requested before the barrier, in flight across it
-        if (role_b) t2.load(c, lane);
+        typename SUB::InvTw2 t2;                            // requested before the barrier, in flight across it
+        t2.load(ch, lane);
         lds_barrier();
-        if (role_b) {
-            int32_t o[REGS];
-            NTT::read_row(o, sh.pa0[base], lane);
+        {
+            // Half h of the summed spectrum of output polynomial u, in the half transform's layout: slot 8 lane + reg of
+            // the half is slot 16 (32 h + lane / 2) + 8 (lane & 1) + reg of the full-size rows the forward phase wrote
+            const int off = NTT::row_base(32 * h + (lane >> 1)) + RS * (lane & 1);
+            const uint32_t *rows[4] = {sh.pa0[base] + off, sh.pb0[base] + off, sh.pa1[base ^ 2] + off, sh.pb[base ^ 2] + off};
+            int32_t t[RS];
 #pragma unroll
-            for (int r = 0; r < REGS; ++r) t[r] += o[r];
-            NTT::read_row(o, sh.pa1[base ^ 2], lane);
+            for (int k = 0; k < 4; ++k) {
 #pragma unroll
-            for (int r = 0; r < REGS; ++r) t[r] += o[r];
-            NTT::read_row(o, sh.pb[base ^ 2], lane);
+                for (int g = 0; g < RS / 4; ++g) {
+                    const uint4 v = reinterpret_cast<const uint4 *>(rows[k])[g];
+                    if (k == 0) { t[4 * g] = (int32_t)v.x; t[4 * g + 1] = (int32_t)v.y; t[4 * g + 2] = (int32_t)v.z; t[4 * g + 3] = (int32_t)v.w; }
+                    else { t[4 * g] += (int32_t)v.x; t[4 * g + 1] += (int32_t)v.y; t[4 * g + 2] += (int32_t)v.z; t[4 * g + 3] += (int32_t)v.w; }
+                }
+            }                                                           // |.| < 3.3P (the inverse takes < 4P)
+            SUB::template inverse<true>(t, ch, scr, lane, t2);          // half-transform outputs, natural order, |t| < P
 #pragma unroll
-            for (int r = 0; r < REGS; ++r) t[r] += o[r];                // |.| < 3.3P (the inverse takes < 4P)
-            NTT::template inverse<true>(t, c, scr, lane, t2);           // signed residues, |t| < P
-            uint32_t *mx = sh.half[base];
-#pragma unroll
-            for (int r = 0; r < HALF; ++r) mx[r * 64 + lane] = (uint32_t)(q == 0 ? t[HALF + r] : t[r]);
+            for (int r = 0; r < RS; ++r) scr[r * 64 + lane] = (uint32_t)t[r];
         }
         lds_barrier();
-        if (role_b) {
-            const uint32_t *ox = sh.half[base ^ 1];
-            if (q == 0) {
+        {
+            // the four waves of output polynomial u take a quarter of the register rows each and finish coefficients
+            // j and j + N/2 of it, for both primes (split_finish: last inverse stage, CRT)
+            const uint32_t *a0 = sh.scr[(u << 1)], *a1 = sh.scr[(u << 1) | 4];
+            const uint32_t *b0 = sh.scr[(u << 1) | 1], *b1 = sh.scr[(u << 1) | 5];
+            const int part = q | (h << 1);
 #pragma unroll
-                for (int r = 0; r < HALF; ++r)
-                    sh.acc.set(u, r * 64 + lane, sh.acc.get(u, r * 64 + lane) + crt_signed_to_torus(t[r], (int32_t)ox[r * 64 + lane]));
-            } else {
-#pragma unroll
-                for (int r = 0; r < HALF; ++r)
-                    sh.acc.set(u, (HALF + r) * 64 + lane,
-                               sh.acc.get(u, (HALF + r) * 64 + lane) + crt_signed_to_torus((int32_t)ox[r * 64 + lane], t[HALF + r]));
+            for (int r = 0; r < QUARTER; ++r) {
+                const int jl = (part * QUARTER + r) * 64 + lane;
+                const int32_t va0 = (int32_t)a0[jl], va1 = (int32_t)a1[jl], vb0 = (int32_t)b0[jl], vb1 = (int32_t)b1[jl];
+                sh.acc.set(u, jl, sh.acc.get(u, jl) + split_finish(0, va0, va1, vb0, vb1, iw1_0, iw1_1));
+                sh.acc.set(u, M + jl, sh.acc.get(u, M + jl) + split_finish(1, va0, va1, vb0, vb1, iw1_0, iw1_1));
             }
         }
         lds_barrier();
@@ -833,15 +883,6 @@ struct BrSplitLds {
     uint16_t bar[1024 + 8];
     uint32_t tab[2][2][TM == 2 ? 11 << SPLIT_TAB2_BITS : DIGIT_TAB];     // [prime][h][table][digit field]
 };
-
-// last inverse stage on half-transform outputs (a0, a1 modulo P0; b0, b1 modulo P1, each below P in magnitude) of one
-// coefficient pair, then the CRT on the signed residues (|.| < 2P): the Torus32 increment of coefficient j (h = 0)
-// or j + N/2 (h = 1)
-__device__ __forceinline__ uint32_t split_finish(int h, int32_t a0, int32_t a1, int32_t b0, int32_t b1, uint32_t iw1_0,
-                                                 uint32_t iw1_1) {
-    if (h == 0) return crt_signed_to_torus(a0 + a1, b0 + b1);
-    return crt_signed_to_torus(mont_mul(a0 - a1, iw1_0, NTT_P0, NTT_PINV0), mont_mul(b0 - b1, iw1_1, NTT_P1, NTT_PINV1));
-}
 
 template <int LOGN, int TM>
 __global__ __launch_bounds__(512, (LOGN == 10 ? 4 : 2)) void blind_rotate_split_kernel(
@@ -1601,6 +1642,7 @@ void launch_blind_rotate4(hipStream_t s, const DevParams &p, const DevKey &key, 
     const bool tab = digit_table_usable(p);
     if (p.N == 2048) { if (tab) BR4(11, 0, true); else BR4(11, 0, false); }
     else if (p.br_variant == 1) { if (tab) BR4(10, 1, true); else BR4(10, 1, false); }
+    else if (p.br_variant == 6 && tab) BR4(10, 2, true);          // A/B form: the default without the LDS copy of the twiddles
     else { if (tab) BR4(10, 0, true); else BR4(10, 0, false); }
 #undef BR4
 }

@@ -57,6 +57,8 @@ struct PrimeCtx {
     const uint4 *__restrict__ qf;      // forward quads [N/2]: entry 2^s + t = {w2, w3, w1 w2, P - w1 w3} of the
     const uint4 *__restrict__ qi;      // radix-4 step on stages (s, s+1), block t; inverse likewise
     const uint32_t *dtab;              // LDS, or null: first-step products of gadget digits, [5][DIGIT_TAB] (forward_digits)
+    const void *fw1, *fw2;             // LDS, or null: this lane's twiddles of the forward transforms' second and third
+                                       // pass (PassTw::to_image of a WaveNtt::FwdTw1 / FwdTw2), for the LDSTW forms of forward_digits
 };
 
 // The first radix-4 step of a forward transform of gadget digits multiplies 7-bit numbers by five
@@ -270,10 +272,40 @@ struct WaveNtt {
             if constexpr (PAIR) load_quads<CNT>(q, (FWD ? c.qf : c.qi) + base);
             rest.load(c, lane);
         }
+        // packed image for an LDS copy (16-byte units: the twiddles, then the quads, then the later steps)
+        static constexpr int TW16 = (CNT + 3) / 4;
+        static constexpr int IMAGE16 = TW16 + (PAIR ? CNT : 0) + decltype(rest)::IMAGE16;
+        __device__ __forceinline__ void to_image(uint4 *img) const {
+#pragma unroll
+            for (int g = 0; g < TW16; ++g)
+                img[g] = make_uint4(tw[4 * g], 4 * g + 1 < CNT ? tw[4 * g + 1] : 0u, 4 * g + 2 < CNT ? tw[4 * g + 2] : 0u,
+                                    4 * g + 3 < CNT ? tw[4 * g + 3] : 0u);
+            if constexpr (PAIR) {
+#pragma unroll
+                for (int e = 0; e < CNT; ++e) img[TW16 + e] = q[e];
+            }
+            rest.to_image(img + TW16 + (PAIR ? CNT : 0));
+        }
+        __device__ __forceinline__ void from_image(const uint4 *img) {
+#pragma unroll
+            for (int g = 0; g < TW16; ++g) {
+                const uint4 v = img[g];
+                tw[4 * g] = v.x;
+                if constexpr (CNT > 1) { if (4 * g + 1 < CNT) tw[4 * g + 1] = v.y; if (4 * g + 2 < CNT) tw[4 * g + 2] = v.z; if (4 * g + 3 < CNT) tw[4 * g + 3] = v.w; }
+            }
+            if constexpr (PAIR) {
+#pragma unroll
+                for (int e = 0; e < CNT; ++e) q[e] = img[TW16 + e];
+            }
+            rest.from_image(img + TW16 + (PAIR ? CNT : 0));
+        }
     };
     template <int S, bool FWD>
     struct PassTw<S, S, FWD> {
+        static constexpr int IMAGE16 = 0;
         __device__ __forceinline__ void load(const PrimeCtx &, int) {}
+        __device__ __forceinline__ void to_image(uint4 *) const {}
+        __device__ __forceinline__ void from_image(const uint4 *) {}
     };
     using FwdTw0 = PassTw<0, RB, true>;
     using FwdTw1 = PassTw<RB, 2 * RB, true>;
@@ -426,13 +458,19 @@ struct WaveNtt {
         forward_digits<EARLY, TABLE>(x, D, shift, width, c, scr, lane, t0);
     }
     // t0: the first pass's twiddles (lane-uniform and the same for every transform: a caller may load them once)
-    template <bool EARLY, bool TABLE>
+    // LDSTW: the per-lane twiddles of the second and third pass come from the workgroup's LDS copy (c.fw1, c.fw2)
+    // instead of global memory.  They are the same for every row and step; from LDS they cost 13 ds_read_b128 per
+    // transform where the global form issues 16 loads through the vector-memory pipe -- and, more to the point, they
+    // leave the vector-memory counter to the key rows alone: a wait for twiddles no longer waits for the (older,
+    // slower) key loads, whose latency then hides under the whole transform (round 3).
+    template <bool EARLY, bool TABLE, bool LDSTW = false>
     static __device__ __forceinline__ void forward_digits(int32_t (&x)[REGS], const uint32_t (&D)[REGS], int shift, int width,
                                                           const PrimeCtx &c, uint32_t *scr, int lane, const FwdTw0 &t0) {
         if constexpr (!TABLE) {
 #pragma unroll
             for (int r = 0; r < REGS; ++r) x[r] = __builtin_amdgcn_sbfe((int32_t)D[r], shift, width);
-            forward<EARLY>(x, c, scr, lane, t0);
+            fwd_pass(x, c, t0);
+            forward_tail<EARLY, LDSTW>(x, c, scr, lane);
         } else {
             static_assert(FwdTw0::PAIR && FwdTw0::CNT == 1, "the first step is a radix-4 step with one block");
             constexpr int RBIT = rbit_of(0), h = 1 << RBIT, l = h >> 1;
@@ -451,33 +489,40 @@ struct WaveNtt {
                     const int32_t u = x0 + A, v = x0 - A;
                     x[r] = u + S; x[r | l] = u - S; x[r | h] = v + T; x[r | h | l] = v - T;
                 }
-            forward_rest<EARLY>(x, c, scr, lane, t0);
+            forward_rest<EARLY, LDSTW>(x, c, scr, lane, t0);
         }
     }
     // everything after the first radix-4 step of a forward transform (for callers that produce that
     // step's outputs themselves, from tables)
-    template <bool EARLY>
+    template <bool EARLY, bool LDSTW = false>
     static __device__ __forceinline__ void forward_rest(int32_t (&x)[REGS], const PrimeCtx &c, uint32_t *scr, int lane,
                                                         const FwdTw0 &t0) {
         static_assert(FwdTw0::PAIR, "the first step is a radix-4 step");
         if constexpr (RB > 2) fwd_pass(x, c, t0.rest);               // the other steps of the first pass
+        forward_tail<EARLY, LDSTW>(x, c, scr, lane);
+    }
+    // second and third pass of a forward transform, with the two transposes in front of them
+    template <bool EARLY, bool LDSTW>
+    static __device__ __forceinline__ void forward_tail(int32_t (&x)[REGS], const PrimeCtx &c, uint32_t *scr, int lane) {
         FwdTw1 t1;
-        if constexpr (EARLY) t1.load(c, lane);
+        auto get1 = [&] { if constexpr (LDSTW) t1.from_image(static_cast<const uint4 *>(c.fw1)); else t1.load(c, lane); };
+        if constexpr (EARLY) get1();
 #pragma unroll
         for (int r = 0; r < REGS; ++r) scr[t1_l0_addr(lane, r)] = (uint32_t)x[r];
         wave_lds_fence();
         read_row(x, scr, lane);
         wave_lds_fence();
-        if constexpr (!EARLY) t1.load(c, lane);
+        if constexpr (!EARLY) get1();
         fwd_pass(x, c, t1);
         FwdTw2 t2;
-        if constexpr (EARLY) t2.load(c, lane);
+        auto get2 = [&] { if constexpr (LDSTW) t2.from_image(static_cast<const uint4 *>(c.fw2)); else t2.load(c, lane); };
+        if constexpr (EARLY) get2();
 #pragma unroll
         for (int r = 0; r < REGS; ++r) scr[t2_l1_addr(lane, r)] = (uint32_t)x[r];
         wave_lds_fence();
         read_row(x, scr, lane);
         wave_lds_fence();
-        if constexpr (!EARLY) t2.load(c, lane);
+        if constexpr (!EARLY) get2();
         fwd_pass(x, c, t2);
     }
     // fills this prime's digit table for digits of `width` bits (threads tid, tid + nthreads, ... of

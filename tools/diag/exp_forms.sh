@@ -7,7 +7,7 @@ export TMPDIR=/tmp
 for round in 1 2 3; do
   for x in $FORMS; do
     echo "=== round $round TFHE_HIP_BR_EXP=$x" >> $OUT/forms.txt
-    TFHE_HIP_BR_EXP=$x timeout -k 10 200 python tools/gate_throughput.py 512 512 4096 4096 2>&1 | grep "G=" >> $OUT/forms.txt || exit 1
+    TFHE_HIP_BR_VARIANT=$x timeout -k 10 200 python tools/gate_throughput.py 512 512 4096 4096 2>&1 | grep "G=" >> $OUT/forms.txt || exit 1
   done
 done
 python - <<PY
