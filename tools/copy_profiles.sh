@@ -1,12 +1,12 @@
 #!/bin/bash
-# copies the summaries tools/gpu_profile.sh left under gpurun_out/prof_<tag>/ into profiles/ (round 2 names),
+# copies the summaries tools/gpu_profile.sh left under gpurun_out/prof_<tag>/ into profiles/ (round 3 names),
 # adding the wave-cycle shares to the VALU summary
 set -e
 P=gpurun_out/prof_${1:?tag}
-cp $P/kernel_stats.csv profiles/r02_kernel_stats.csv
+cp $P/kernel_stats.csv profiles/r03_kernel_stats.csv
 cp $P/pmc_blind_rotate.json profiles/pmc_blind_rotate.json
-cp $P/sq_counters_blind_rotate.txt profiles/r02_sq_counters_blind_rotate.txt
-cp $P/bench_under_rocprof.json profiles/r02_bench_under_rocprof.json
+cp $P/sq_counters_blind_rotate.txt profiles/r03_sq_counters_blind_rotate.txt
+cp $P/bench_under_rocprof.json profiles/r03_bench_under_rocprof.json
 python3 - "$P" <<'PY'
 import json, re, sys
 P = sys.argv[1] + "/"

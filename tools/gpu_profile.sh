@@ -2,10 +2,10 @@
 # Round profiles (one gpurun call): kernel-trace statistics of the bench command, HBM traffic from
 # separate --pmc FETCH_SIZE / WRITE_SIZE passes (the HBM/rocprofv3 recipe of MI355X_MICROARCH.md),
 # SQ counters of the blind-rotate kernel on a 4,096-rotation launch (issue, LDS, stalls).
-#   gpurun --timeout 1200 -- 'bash tools/gpu_profile.sh r02'
+#   gpurun --timeout 1200 -- 'bash tools/gpu_profile.sh r03'
 # Counter passes never carry a trace option (gpurun refuses --pmc with trace domains).
 set -o pipefail
-TAG=${1:-r02}
+TAG=${1:-r03}
 OUT=gpurun_out/prof_$TAG; mkdir -p $OUT
 export TMPDIR=/tmp
 B="python3 bench.py --extras 0 --no-cpu-baseline"
