@@ -422,7 +422,6 @@ bool Engine::launch_br(const DeviceKeyImage *key, const int32_t *pool, const Rot
     dp.wave_prio = wave_prio;
     dp.digit_table = tables;
     dp.br_variant = dp.N == 1024 && form == BR_FORM_LEAN4 ? 1 : 0;
-    if (br_variant == 6 && form == BR_FORM_WIDE4) dp.br_variant = 6;      // A/B form (kernels.hip launch_blind_rotate4)
     if (kernel_timing) {
         if (!clock_acc_) {
             hip_check(hipMalloc(&clock_acc_, 2 * sizeof(unsigned long long)), "hipMalloc(clock sums)");

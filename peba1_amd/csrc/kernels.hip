@@ -616,21 +616,15 @@ __device__ __forceinline__ void blind_rotate4_body(const DevParams &p, const Dev
         // CRT of output poly u is split with wave (1-q,u): wave q recombines registers [q*HALF, (q+1)*HALF)
         const uint32_t *ox = sh.x2(wv ^ 1);
         uint32_t *mx = sh.x2(wv);
-        if (q == 0) {
+        const int mine = q * HALF, theirs = HALF - mine;
 #pragma unroll
-            for (int r = 0; r < HALF; ++r) mx[r * 64 + lane] = (uint32_t)t[HALF + r];
-            lds_barrier();
+        for (int r = 0; r < HALF; ++r) mx[r * 64 + lane] = (uint32_t)t[theirs + r];
+        lds_barrier();
 #pragma unroll
-            for (int r = 0; r < HALF; ++r)
-                sh.acc.set(u, r * 64 + lane, sh.acc.get(u, r * 64 + lane) + crt_signed_to_torus(t[r], (int32_t)ox[r * 64 + lane]));
-        } else {
-#pragma unroll
-            for (int r = 0; r < HALF; ++r) mx[r * 64 + lane] = (uint32_t)t[r];
-            lds_barrier();
-#pragma unroll
-            for (int r = 0; r < HALF; ++r)
-                sh.acc.set(u, (HALF + r) * 64 + lane,
-                           sh.acc.get(u, (HALF + r) * 64 + lane) + crt_signed_to_torus((int32_t)ox[r * 64 + lane], t[HALF + r]));
+        for (int r = 0; r < HALF; ++r) {
+            const int32_t other = (int32_t)ox[r * 64 + lane];
+            const uint32_t inc = q == 0 ? crt_signed_to_torus(t[mine + r], other) : crt_signed_to_torus(other, t[mine + r]);
+            sh.acc.set(u, (mine + r) * 64 + lane, sh.acc.get(u, (mine + r) * 64 + lane) + inc);
         }
         STAMP(5);
         lds_barrier();
@@ -1642,7 +1636,6 @@ void launch_blind_rotate4(hipStream_t s, const DevParams &p, const DevKey &key, 
     const bool tab = digit_table_usable(p);
     if (p.N == 2048) { if (tab) BR4(11, 0, true); else BR4(11, 0, false); }
     else if (p.br_variant == 1) { if (tab) BR4(10, 1, true); else BR4(10, 1, false); }
-    else if (p.br_variant == 6 && tab) BR4(10, 2, true);          // A/B form: the default without the LDS copy of the twiddles
     else { if (tab) BR4(10, 0, true); else BR4(10, 0, false); }
 #undef BR4
 }

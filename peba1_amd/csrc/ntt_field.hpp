@@ -45,8 +45,6 @@ constexpr uint32_t CRT_P0INV_MONT = (uint32_t)mulmod_c(powmod_c(NTT_P[0], NTT_P[
 constexpr uint32_t NTT_P0 = NTT_P[0], NTT_P1 = NTT_P[1];
 constexpr uint32_t NTT_PINV0 = NTT_PINV_NEG[0], NTT_PINV1 = NTT_PINV_NEG[1];
 constexpr uint64_t CRT_M = (uint64_t)NTT_P[0] * NTT_P[1];
-constexpr uint64_t CRT_HALF = (CRT_M - 1) / 2;
-constexpr uint32_t CRT_M_LO = (uint32_t)CRT_M;
 // The kernels recombine SIGNED lazy residues (ntt_wave.hpp crt_signed_to_torus): the integer they form is
 // r0 + P0 t with |r0| < 2P and |t| < 0.63 P1, i.e. below 0.63 M + 2P in magnitude.  It equals the true centred
 // value -- not merely modulo M -- as long as that value is below M - (0.63 M + 2P); a key is accepted only if the

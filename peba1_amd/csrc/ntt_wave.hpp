@@ -77,18 +77,6 @@ __device__ __forceinline__ int32_t mont_redc(int64_t T, uint32_t P, uint32_t pin
 __device__ __forceinline__ int32_t mont_mul(int32_t b, uint32_t w, uint32_t P, uint32_t pinv) {
     return mont_redc((int64_t)b * (int64_t)(int32_t)w, P, pinv);
 }
-// unsigned form, operands below P (CRT only): result in [0,2P)
-__device__ __forceinline__ uint32_t mont_mul_u(uint32_t b, uint32_t w, uint32_t P, uint32_t pinv) {
-    const uint64_t T = (uint64_t)b * (uint64_t)w;
-    const uint32_t m = (uint32_t)T * pinv;
-    const uint64_t U = T + (uint64_t)m * (uint64_t)P;
-    return (uint32_t)(U >> 32);
-}
-// x in [0,2B) -> [0,B)
-__device__ __forceinline__ uint32_t csub(uint32_t x, uint32_t B) { return min(x, x - B); }
-// representative in (-P,P) -> canonical [0,P)
-__device__ __forceinline__ uint32_t canon(int32_t x, uint32_t P) { return min((uint32_t)x, (uint32_t)x + P); }
-
 // LDS is processed in issue order for one wave, so a wave-private transpose
 // needs no barrier; this only stops the compiler from reordering across it.
 __device__ __forceinline__ void wave_lds_fence() { asm volatile("" ::: "memory"); }
@@ -571,22 +559,14 @@ struct WaveNtt {
     }
 };
 
-// CRT of canonical residues r0 (mod P0) and r1 (mod P1): the centred integer
-// they represent, reduced mod 2^32
-__device__ __forceinline__ uint32_t crt_to_torus(uint32_t r0, uint32_t r1) {
-    uint32_t t = mont_mul_u(r1 + NTT_P1 - r0, CRT_P0INV_MONT, NTT_P1, NTT_PINV1);
-    t = csub(t, NTT_P1);
-    const uint64_t v = (uint64_t)NTT_P0 * t + r0;
-    return (uint32_t)v - (v > CRT_HALF ? CRT_M_LO : 0u);
-}
-
 // CRT of SIGNED representatives r0 (modulo P0) and r1 (modulo P1), |r0|, |r1| < 2P -- what the inverse transforms
 // leave, no canonicalisation.  With t = (r1 - r0) P0^-1 mod P1 taken as the signed Montgomery output (|t| <=
 // 4P P1 / 2^32 + P1 / 2 < 0.63 P1), x = r0 + P0 t is congruent to the value modulo both primes and |x| < 0.63 M + 2P.
 // The true centred value v satisfies |v| < CRT_EXACT_LIMIT = 0.36 M (checked at key upload), so x - v, a multiple of
 // M below M in magnitude, is 0: x IS the centred integer and its low 32 bits are r0 + P0 t in wrapping arithmetic.
-// 4 multiplier-class + 2 add instructions, where the canonical form above takes 4 + 9 and needs canonical inputs
-// (2 more per residue): 88 VALU instructions less per wave and blind-rotate step (round 3).
+// 4 multiplier-class + 2 add instructions, where the round-2 form on canonical residues (compare against M/2, conditional
+// subtraction) took 4 + 9 and needed canonical inputs (2 more per residue): 184 VALU instructions less per wave and
+// blind-rotate step by static count (round 3).
 __device__ __forceinline__ uint32_t crt_signed_to_torus(int32_t r0, int32_t r1) {
     const int32_t t = mont_mul(r1 - r0, CRT_P0INV_MONT, NTT_P1, NTT_PINV1);
     return (uint32_t)r0 + NTT_P0 * (uint32_t)t;

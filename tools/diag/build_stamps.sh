@@ -8,7 +8,8 @@ O=${1:-/tmp/stamps}
 mkdir -p $O
 ROCM=${ROCM_PATH:-/opt/rocm}
 F="-O3 -std=c++17 -fPIC -ffp-contract=off -DTFHE_HIP_STAMPS"
-$ROCM/bin/hipcc $F --offload-arch=gfx950 -c $S/kernels.hip -o $O/kernels.o
+KF="-mllvm -amdgpu-sched-strategy=max-ilp"
+$ROCM/bin/hipcc $F $KF --offload-arch=gfx950 -c $S/kernels.hip -o $O/kernels.o
 for f in host_keys engine shim scheduler io; do $ROCM/lib/llvm/bin/clang++ $F -D__HIP_PLATFORM_AMD__ -I$ROCM/include -c $S/$f.cpp -o $O/$f.o; done
 $ROCM/bin/hipcc -shared -o $O/libtfhe-hip-stamps.so $O/kernels.o $O/host_keys.o $O/engine.o $O/shim.o $O/scheduler.o $O/io.o
 $ROCM/lib/llvm/bin/clang++ -O2 -std=c++17 -I$ROOT/include $ROOT/tools/diag/stamp_main.cpp -o $O/stamp_main -L$O -ltfhe-hip-stamps -Wl,-rpath,$O

@@ -3,9 +3,11 @@
 #include <cstdlib>
 #include <vector>
 #include "tfhe/tfhe.h"
+#include "tfhe_hip.h"
 namespace tfhe_hip { void read_stamps(unsigned long long *out, bool reset); }
 int main(int argc, char **argv) {
     int G = argc > 1 ? atoi(argv[1]) : 64;
+    tfhe_hip_set_deferred(0);                      // the launches below must run when they are issued
     auto *params = new_default_gate_bootstrapping_parameters(128);
     auto *key = tfhe_hip_new_secret_keyset_seeded(params, 0x5EBA2);
     LweSample *a = new_gate_bootstrapping_ciphertext_array(G, params), *b = new_gate_bootstrapping_ciphertext_array(G, params),
