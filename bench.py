@@ -220,6 +220,7 @@ def main():
     # pending gates (tuning "reuse_gates", on by default) is switched off for the timed steps
     # and reported separately, so that `value` counts 215,544 blind rotations per 128-slot match.
     api.set_tuning("reuse_gates", 0)
+    api.set_tuning("eliminate_dead", 0)     # likewise: gates whose result nothing can observe are executed too
 
     checked = None          # what the in-run check of the timed work was
     if mode == "match":
@@ -364,7 +365,7 @@ def main():
                                    f"established by the -m gpu tests (every kernel and gate word for word; whole 2-slot "
                                    f"Function_f and the 3-slot sharded DAG by SHA-256 digest), not re-checked here",
                        "mode": mode, "parallelism": parallelism,
-                       "levels_per_step_rank0": int(st["levels"] / steps), "gate_sharing": "off"},
+                       "levels_per_step_rank0": int(st["levels"] / steps), "gate_sharing": "off", "dead_gate_elimination": "off"},
             "match_ms": elapsed * 1e3 / steps if mode != "identify" else elapsed * 1e3 / steps / max(1, args.matches),
             # The mandated HBM roofline: ALGORITHMIC bytes (the whole 59 MiB key image per blind
             # rotation, no reuse) per second of blind-rotate launch time, against the 8 TB/s peak.  The kernel
@@ -433,6 +434,19 @@ def extras(api, circuits, identify, lib, pd, pp, ks, probe, tmpl, bound, base, p
     assert (rbg.words() == last.words()).all()          # the same ciphertexts, word for word
     out["match_with_gate_sharing"] = {"match_ms": t * 1e3, "blind_rotates": int(s["blind_rotates"]),
                                       "gates_shared": int(s["reused_gates"])}
+    # ... and with every library default (gate sharing + dead-gate elimination: what an unmodified caller gets)
+    api.set_tuning("eliminate_dead", 1)
+    api.reset_stats()
+    t = time.perf_counter()
+    rbd = api.CiphertextArray(pp, 3 * bitsize)
+    circuits.function_f(rbd, probe, tmpl, bound, bitsize, ks)
+    api.flush()
+    t = time.perf_counter() - t
+    s = api.stats()
+    assert (rbd.words() == last.words()).all()
+    out["match_library_defaults"] = {"match_ms": t * 1e3, "blind_rotates": int(s["blind_rotates"]),
+                                     "gates_shared": int(s["reused_gates"]), "gates_dropped_as_dead": int(s["dead_gates"])}
+    api.set_tuning("eliminate_dead", 0)
     api.set_tuning("reuse_gates", 0)
     # BASELINE configs[3] shape, small: one probe against 4 templates in one flush
     tv = [identify.synthetic_template(base, k) for k in range(4)]

@@ -140,6 +140,9 @@ int tfhe_hip_gate_batch(int gate, LweSample *result, const LweSample *a, const L
  * "reuse_gates": 1 (default) = in deferred mode a gate recorded again with the same operand
  * samples before the flush shares the pending gate's result instead of being evaluated again
  * (same function of the same ciphertexts, so the same words); 0 = evaluate every call.
+ * "eliminate_dead": 1 (default) = at a flush, a recorded gate whose result no sample handle holds any more and no
+ * live gate reads is not evaluated (the reference's adders compute carries they then drop: 3 % of a match); nothing
+ * observable changes; 0 = evaluate every recorded gate.
  * "balance_levels": 1 (default) = slack-aware level filling at flush, 0 = plain ASAP
  * levels.
  * Only in a library built with -DTFHE_HIP_EXPERIMENTAL (tfhe_hip_has_experimental() == 1; build.sh leaves it
@@ -181,6 +184,9 @@ typedef struct TfheHipStats {
      * timed launches ran at (a cold chip runs them at ~2.0 GHz, a warm one at ~2.37) */
     uint64_t clk_shader_cycles;
     uint64_t clk_ref_ticks;
+    /* recorded gates (and NOTs) dropped at a flush because nothing could ever observe their result: no sample
+     * handle held it and no live gate read it ("eliminate_dead") */
+    uint64_t dead_gates;
 } TfheHipStats;
 void tfhe_hip_get_stats(TfheHipStats *out);
 void tfhe_hip_reset_stats(void);

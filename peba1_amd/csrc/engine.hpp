@@ -50,6 +50,7 @@ public:
     ~SlotPool();
     int32_t alloc();                 // refcount 1, level 0
     void retain(int32_t s) { ++ref_[s]; }
+    int32_t refs(int32_t s) const { return ref_[s]; }
     void release(int32_t s);
     int32_t *data() { return data_; }
     int ct_stride() const { return stride_; }

@@ -192,7 +192,8 @@ def test_function_f_ciphertexts_match_oracle_digest(p128_keys, fixture, circuit,
         assert api.stats()["br_launches"] > api.stats()["levels"]      # both lanes really launched
     st = api.stats()
     # the recorder shares the result of a gate recorded twice with the same operands (reuse_gates)
-    assert st["blind_rotates"] <= g["blind_rotates"] <= st["blind_rotates"] + 2 * st["reused_gates"]
+    # (and drops gates whose result nothing can observe: eliminate_dead); a shared or dropped gate is 1 or 2 rotations
+    assert st["blind_rotates"] <= g["blind_rotates"] <= st["blind_rotates"] + 2 * (st["reused_gates"] + st["dead_gates"])
     words = rb.words()
     try:
         assert hashlib.sha256(words[0].tobytes()).hexdigest() == g["result_b0_sha256"]
@@ -240,7 +241,7 @@ def test_function_f_128_slots_ciphertexts_match_oracle_digest(p128_keys):
             st = api.stats()
             assert st["levels"] == 377
             # the recorder shares the result of a gate recorded twice with the same operands (a shared gate is 1 or 2 rotations)
-            assert st["blind_rotates"] <= run["blind_rotates_recorded"] <= st["blind_rotates"] + 2 * st["reused_gates"]
+            assert st["blind_rotates"] <= run["blind_rotates_recorded"] <= st["blind_rotates"] + 2 * (st["reused_gates"] + st["dead_gates"])
             assert hashlib.sha256(words[0].tobytes()).hexdigest() == run["result_b0_sha256"], run["bound"]
             assert hashlib.sha256(words.tobytes()).hexdigest() == run["result_b_sha256"], run["bound"]
             assert rb.decrypt(ks)[0] == run["match_bit"] == (1 if g["distance"] > run["bound"] else 0)
@@ -300,8 +301,9 @@ def test_gate_reuse_is_transparent(p128_keys):
     pp, ks, _ = p128_keys
     out, rots = [], []
     try:
-        for reuse in (1, 0):
+        for reuse, dead in ((1, 1), (0, 0), (0, 1)):
             api.set_tuning("reuse_gates", reuse)
+            api.set_tuning("eliminate_dead", dead)
             lib.load().tfhe_hip_set_encrypt_seed(333)
             T = circuits.EncryptedVector(pp, [12, 200, 77], 8, ks)
             S = circuits.EncryptedVector(pp, [15, 190, 78], 8, ks)
@@ -316,11 +318,15 @@ def test_gate_reuse_is_transparent(p128_keys):
                 api.set_deferred(False)
             st = api.stats()
             out.append(rb.words())
-            rots.append((st["blind_rotates"], st["reused_gates"]))
+            rots.append((st["blind_rotates"], st["reused_gates"], st["dead_gates"]))
     finally:
         api.set_tuning("reuse_gates", 1)
-    assert (out[0] == out[1]).all()
-    assert rots[1][1] == 0 and rots[0][1] > 0 and rots[0][0] < rots[1][0], rots
+        api.set_tuning("eliminate_dead", 1)
+    assert (out[0] == out[1]).all() and (out[2] == out[1]).all()
+    assert rots[1][1] == 0 and rots[1][2] == 0 and rots[0][1] > 0 and rots[0][0] < rots[1][0], rots
+    # dead-gate elimination alone: the dropped carries of the reference's adders (5 gates per adder whose carry-out
+    # nothing reads), nothing else changes
+    assert rots[2][1] == 0 and rots[2][2] > 100 and 0 < rots[1][0] - rots[2][0] <= 2 * rots[2][2], rots
     assert rb.decrypt(ks)[0] == 1                                   # 9 + 100 + 1 > 100
 
 
@@ -344,7 +350,7 @@ def test_optimised_match_full_size(p128_keys):
             levels = api.flush()
             st = api.stats()
             assert rb.decrypt(ks).tolist() == [want] + [0] * 23
-            assert 25000 < st["blind_rotates"] <= 29536 and levels < 110, (st["blind_rotates"], levels)
+            assert 20000 < st["blind_rotates"] <= 29536 and levels < 110, (st["blind_rotates"], levels)
         dist = api.CiphertextArray(pp, 24)
         circuits.euclidean_distance_fast(dist, S, T, 8, ks)
         assert circuits.decrypt_number(dist, ks) == 1400950          # SURVEY 8c known answer

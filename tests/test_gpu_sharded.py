@@ -53,7 +53,7 @@ def test_sharded_dag_ciphertexts_match_oracle_digest(p128_keys):
     finally:
         api.set_deferred(False)
     st = api.stats()
-    assert st["blind_rotates"] <= g["blind_rotates"] <= st["blind_rotates"] + 2 * st["reused_gates"]
+    assert st["blind_rotates"] <= g["blind_rotates"] <= st["blind_rotates"] + 2 * (st["reused_gates"] + st["dead_gates"])
     assert [digests[r] for r in range(g["world"])] == g["partial_sha256"]
     res_ls = C.cast(res, lib.LS)
     words = np.zeros((24, pp.words), dtype=np.int32)
@@ -105,7 +105,7 @@ def test_cfg3_256_slot_match_sharded_over_logical_ranks(p128_keys, world):
     finally:
         api.set_deferred(False)
     # 1,683 blind rotations per slot + the adder tree + the comparator (24 XNOR, 48 MUX = 96 rotations)
-    assert st["blind_rotates"] + 2 * st["reused_gates"] >= nslots * 1683 + (world - 1) * 161 + 24 + 96
+    assert st["blind_rotates"] + 2 * (st["reused_gates"] + st["dead_gates"]) >= nslots * 1683 + (world - 1) * 161 + 24 + 96
     for bound_v, res in outs:
         assert L.bootsSymDecrypt(res, ks.ptr) == (1 if d > bound_v else 0), (world, bound_v)
         L.delete_gate_bootstrapping_ciphertext_array(24, res)
@@ -171,10 +171,12 @@ def test_cfg4_identification_streams_matches_through_bounded_flushes(p128_keys):
     bound.set_words(bound.words())
     api.reset_stats()
     api.set_tuning("reuse_gates", 0)
+    api.set_tuning("eliminate_dead", 0)
     try:
         bits_ct = identify.identify(pp, ks, probe, templates, bound, 8, group=group)
     finally:
         api.set_tuning("reuse_gates", 1)
+        api.set_tuning("eliminate_dead", 1)
     st = api.stats()
     assert st["flushes"] == M // group and st["blind_rotates"] == M * 215544
     got = [int(b) for b in bits_ct.decrypt(ks)]
@@ -215,7 +217,7 @@ def test_cfg4_identification_at_the_per_gpu_size_of_configs3(p128_keys):
     st = api.stats()
     assert st["flushes"] == M // group
     # the library's default sharing of identical pending gates is on: executed + shared == recorded
-    assert st["blind_rotates"] <= M * 215544 <= st["blind_rotates"] + 2 * st["reused_gates"]
+    assert st["blind_rotates"] <= M * 215544 <= st["blind_rotates"] + 2 * (st["reused_gates"] + st["dead_gates"])
     got = [int(b) for b in bits_ct.decrypt(ks)]
     want = [1 if sum((a - b) ** 2 for a, b in zip(probe_v, t)) > 256 else 0 for t in templates_v]
     assert got == want and got.count(0) == 1 and got[genuine] == 0
