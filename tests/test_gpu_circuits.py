@@ -239,7 +239,7 @@ def test_function_f_128_slots_ciphertexts_match_oracle_digest(p128_keys):
             circuits.function_f(rb, SimpleNamespace(slots=S), SimpleNamespace(slots=T), bound, g["bits"], ks)
             words = rb.words()                           # runs the pending gates
             st = api.stats()
-            assert st["levels"] == 377
+            assert st["levels"] in (376, 377)            # 377 recorded; the deepest level holds only results nobody reads
             # the recorder shares the result of a gate recorded twice with the same operands (a shared gate is 1 or 2 rotations)
             assert st["blind_rotates"] <= run["blind_rotates_recorded"] <= st["blind_rotates"] + 2 * (st["reused_gates"] + st["dead_gates"])
             assert hashlib.sha256(words[0].tobytes()).hexdigest() == run["result_b0_sha256"], run["bound"]
