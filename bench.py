@@ -378,7 +378,7 @@ def main():
                          "valu": valu, "counters_measured_on_kernels_sha16": khash if (traffic or valu) else None,
                          "kernels_sha16": khash,
                          "launches": int(dn), "avg_launch_ms": dms / max(1, dn), "rotations_per_launch": drot / max(1, dn),
-                         # shader clock of the timed blind-rotate launches: cycles / 100 MHz reference ticks of workgroup 0
+                         # shader clock of the timed blind-rotate launches: cycles / 100 MHz reference ticks of every 61st workgroup
                          # of every launch (the same launch is ~15 % slower at the ~2.0 GHz of a cold or power-limited
                          # chip than at ~2.37 GHz) -- explains run-to-run and box-to-box differences
                          "shader_clock_ghz": 0.1 * st["clk_shader_cycles"] / st["clk_ref_ticks"] if st["clk_ref_ticks"] else None,

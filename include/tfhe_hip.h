@@ -179,7 +179,7 @@ typedef struct TfheHipStats {
     uint64_t br8_launches;
     uint64_t br8_rotations;
     double   ms_blind_rotate8;
-    /* with kernel timing on: shader cycles (s_memtime) and 100 MHz reference ticks (s_memrealtime) that workgroup 0
+    /* with kernel timing on: shader cycles (s_memtime) and 100 MHz reference ticks (s_memrealtime) that every 61st workgroup
      * of every blind-rotate launch of the flushes lived for; 0.1 * cycles / ticks = the shader clock in GHz the
      * timed launches ran at (a cold chip runs them at ~2.0 GHz, a warm one at ~2.37) */
     uint64_t clk_shader_cycles;

@@ -186,13 +186,13 @@ __device__ __forceinline__ void prelude_modswitch(const DevParams &p, const RotD
 }
 
 // Shader clock of a launch (bench.py reports it beside the times: the same launch takes 15 % longer at the 2.0 GHz
-// a cold chip runs than at the 2.37 GHz of a warm one): lane 0 of workgroup 0 adds the shader
-// cycles and the 100 MHz reference ticks it lived for to two running sums.
+// a cold chip runs than at the 2.37 GHz of a warm one): lane 0 of every 61st workgroup adds the
+// shader cycles and the 100 MHz reference ticks it lived for to two running sums.
 struct ClockProbe {
     unsigned long long c0 = 0, r0 = 0;
     bool on = false;
     __device__ __forceinline__ void begin(const DevParams &p) {
-        on = p.clock_acc != nullptr && blockIdx.x == 0 && threadIdx.x == 0;
+        on = p.clock_acc != nullptr && blockIdx.x % 61 == 0 && threadIdx.x == 0;    // a sample of workgroups across the launch
         if (on) { c0 = __builtin_amdgcn_s_memtime(); r0 = __builtin_amdgcn_s_memrealtime(); }
     }
     __device__ __forceinline__ void end(const DevParams &p) {

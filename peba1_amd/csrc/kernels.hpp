@@ -21,7 +21,7 @@ struct DevParams {
                             // (2 = split transforms: only read by the negacyclic test launcher)
     uint32_t *cu_arrivals;  // [4096] arrival counters per CU (never reset: only the parity of the arrival order is used)
     unsigned long long *clock_acc;  // kernel timing: [2] running sums of shader cycles (s_memtime) and of 100 MHz ticks
-                                    // (s_memrealtime) over workgroup 0 of every blind-rotate launch -> the shader
+                                    // (s_memrealtime) over every 61st workgroup of every blind-rotate launch -> the shader
                                     // clock the launches ran at; or null
     unsigned long long *wg_times;   // diagnostic: [4 * grid] s_memtime (shader cycles) at workgroup start and end, then
                                     // s_memrealtime (100 MHz) at start and end; or null
