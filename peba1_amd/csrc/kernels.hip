@@ -876,7 +876,13 @@ struct BrSplitLds {
     uint32_t x1[8][SUB::SCRATCH_WORDS];            // partial sums sent to the wave of the other input polynomial
     uint16_t bar[1024 + 8];
     uint32_t tab[2][2][TM == 2 ? 11 << SPLIT_TAB2_BITS : DIGIT_TAB];     // [prime][h][table][digit field]
+    // N = 2048 (one workgroup per CU, 30 KB of LDS to spare): per prime and half, LDS copies of the half transforms'
+    // second- and third-pass forward twiddles (ntt_wave.hpp forward_digits LDSTW)
+    static constexpr bool LTW = LOGN == 11;
+    uint4 ft1[LTW ? 2 : 1][LTW ? 2 : 1][LTW ? (64 >> SUB::LC) : 1][SUB::FwdTw1::IMAGE16];
+    uint4 ft2[LTW ? 2 : 1][LTW ? 2 : 1][LTW ? 64 : 1][SUB::FwdTw2::IMAGE16];
 };
+static_assert(sizeof(BrSplitLds<11, 2>) <= 160 * 1024, "the N = 2048 split form must fit a CU's LDS");
 
 template <int LOGN, int TM>
 __global__ __launch_bounds__(512, (LOGN == 10 ? 4 : 2)) void blind_rotate_split_kernel(
@@ -890,7 +896,8 @@ __global__ __launch_bounds__(512, (LOGN == 10 ? 4 : 2)) void blind_rotate_split_
     const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int q = wv & 1, u = (wv >> 1) & 1, h = wv >> 2;
     const int lane = tid & 63;
-    const PrimeCtx c = make_sub_ctx(q, h, key.tw, N);
+    PrimeCtx c = make_sub_ctx(q, h, key.tw, N);
+    constexpr bool LTW = BrSplitLds<LOGN, TM>::LTW;
     uint32_t *scr = sh.scr[wv];
     const int n = p.n;
     const RotDesc rd = rots[blockIdx.x];
@@ -909,6 +916,18 @@ __global__ __launch_bounds__(512, (LOGN == 10 ? 4 : 2)) void blind_rotate_split_
             const int32_t v = mont_mul(d, w1, c.P, c.pinv);
             sh.tab[q][h][f] = (uint32_t)(h ? -v : v);
         }
+    }
+    if constexpr (LTW) {
+        if (u == 0) {                                // wave (q, 0, h) copies the twiddles of (q, h) into LDS, once
+            typename SUB::FwdTw1 a;
+            a.load(c, lane);
+            if ((lane & ((1 << SUB::LC) - 1)) == 0) a.to_image(sh.ft1[q][h][lane >> SUB::LC]);
+            typename SUB::FwdTw2 b;
+            b.load(c, lane);
+            b.to_image(sh.ft2[q][h][lane]);
+        }
+        c.fw1 = sh.ft1[q][h][lane >> SUB::LC];
+        c.fw2 = sh.ft2[q][h][lane];
     }
     if constexpr (TM == 2) {
         // table k of (q, h), entry f: digit(f) * [W[1] * (+1 | -1 for h = 1)] * constant_k, centred
@@ -1000,8 +1019,8 @@ __global__ __launch_bounds__(512, (LOGN == 10 ? 4 : 2)) void blind_rotate_split_
                     x[r] = __builtin_amdgcn_sbfe((int32_t)D[r], shift, width) + (h ? -v : v);
                 }
             }
-            if constexpr (TM == 2) SUB::template forward_rest<true>(x, c, scr, lane, t0);     // < 3.5P + 2^11 in, < 9.7P out
-            else SUB::template forward<true>(x, c, scr, lane, t0);    // |x| < P + 2^11 in, < 8.3P out
+            if constexpr (TM == 2) SUB::template forward_rest<true, LTW>(x, c, scr, lane, t0);     // < 3.5P + 2^11 in, < 9.7P out
+            else SUB::template forward<true, LTW>(x, c, scr, lane, t0);    // |x| < P + 2^11 in, < 8.3P out
 #pragma unroll
             for (int g = 0; g < G4; ++g) {
                 const int32_t bb0[4] = {(int32_t)b0[g].x, (int32_t)b0[g].y, (int32_t)b0[g].z, (int32_t)b0[g].w};

@@ -402,28 +402,11 @@ struct WaveNtt {
     // forward NTT: x in L0 (natural order) -> L2; |x| <= 2^11 ends below 6.7P, |x| < P below 8.2P.
     // t0: the first pass's twiddles, loaded by the caller (FwdTw0 t0; t0.load(c, lane);)
     // EARLY = false: a pass's twiddles are loaded after the transpose instead (fewer live registers).
-    template <bool EARLY = true>
+    template <bool EARLY = true, bool LDSTW = false>
     static __device__ __forceinline__ void forward(int32_t (&x)[REGS], const PrimeCtx &c, uint32_t *scr, int lane,
                                                    const FwdTw0 &t0) {
         fwd_pass(x, c, t0);
-        FwdTw1 t1;
-        if constexpr (EARLY) t1.load(c, lane);
-#pragma unroll
-        for (int r = 0; r < REGS; ++r) scr[t1_l0_addr(lane, r)] = (uint32_t)x[r];
-        wave_lds_fence();
-        read_row(x, scr, lane);
-        wave_lds_fence();
-        if constexpr (!EARLY) t1.load(c, lane);
-        fwd_pass(x, c, t1);
-        FwdTw2 t2;
-        if constexpr (EARLY) t2.load(c, lane);
-#pragma unroll
-        for (int r = 0; r < REGS; ++r) scr[t2_l1_addr(lane, r)] = (uint32_t)x[r];
-        wave_lds_fence();
-        read_row(x, scr, lane);
-        wave_lds_fence();
-        if constexpr (!EARLY) t2.load(c, lane);
-        fwd_pass(x, c, t2);
+        forward_tail<EARLY, LDSTW>(x, c, scr, lane);
     }
     template <bool EARLY = true>
     static __device__ __forceinline__ void forward(int32_t (&x)[REGS], const PrimeCtx &c, uint32_t *scr, int lane) {
