@@ -616,15 +616,21 @@ __device__ __forceinline__ void blind_rotate4_body(const DevParams &p, const Dev
         // CRT of output poly u is split with wave (1-q,u): wave q recombines registers [q*HALF, (q+1)*HALF)
         const uint32_t *ox = sh.x2(wv ^ 1);
         uint32_t *mx = sh.x2(wv);
-        const int mine = q * HALF, theirs = HALF - mine;
+        if (q == 0) {                                    // (two copies: register indices must be compile-time constants)
 #pragma unroll
-        for (int r = 0; r < HALF; ++r) mx[r * 64 + lane] = (uint32_t)t[theirs + r];
-        lds_barrier();
+            for (int r = 0; r < HALF; ++r) mx[r * 64 + lane] = (uint32_t)t[HALF + r];
+            lds_barrier();
 #pragma unroll
-        for (int r = 0; r < HALF; ++r) {
-            const int32_t other = (int32_t)ox[r * 64 + lane];
-            const uint32_t inc = q == 0 ? crt_signed_to_torus(t[mine + r], other) : crt_signed_to_torus(other, t[mine + r]);
-            sh.acc.set(u, (mine + r) * 64 + lane, sh.acc.get(u, (mine + r) * 64 + lane) + inc);
+            for (int r = 0; r < HALF; ++r)
+                sh.acc.set(u, r * 64 + lane, sh.acc.get(u, r * 64 + lane) + crt_signed_to_torus(t[r], (int32_t)ox[r * 64 + lane]));
+        } else {
+#pragma unroll
+            for (int r = 0; r < HALF; ++r) mx[r * 64 + lane] = (uint32_t)t[r];
+            lds_barrier();
+#pragma unroll
+            for (int r = 0; r < HALF; ++r)
+                sh.acc.set(u, (HALF + r) * 64 + lane,
+                           sh.acc.get(u, (HALF + r) * 64 + lane) + crt_signed_to_torus((int32_t)ox[r * 64 + lane], t[HALF + r]));
         }
         STAMP(5);
         lds_barrier();
