@@ -232,7 +232,9 @@ def main():
         def step():
             rb = api.CiphertextArray(pp, 3 * bitsize)
             circuits.function_f(rb, probe, tmpl, bound, bitsize, ks)   # records ~350k API calls
-            api.flush()                                                # levelised batched execution
+            # levelised batched execution, pipelined: the launches are enqueued and the next step's recording and
+            # levelling overlap their execution (at most one flush in flight); the timed region ends with api.wait()
+            api.flush_async()
             if use_dist:
                 # the only exchange: every rank's match-bit ciphertext to rank 0 (libpeba1-dist: RCCL gather enqueued on
                 # the library's own stream between the stream-ordered export and import -- no host wait, and no
@@ -318,11 +320,13 @@ def main():
     last = None
     for _ in range(args.warmup):
         last = step()
+    api.wait()
     sync()
     api.reset_stats()
     t0 = time.perf_counter()
     for _ in range(args.steps):
         last = step()
+    api.wait()                      # every launch of the K steps has completed on the library's stream
     sync()
     elapsed = time.perf_counter() - t0
     st = api.stats()

@@ -109,6 +109,14 @@ int tfhe_hip_sync_samples(const LweSample *samples, int32_t count);
 void tfhe_hip_set_deferred(int on);
 int tfhe_hip_get_deferred(void);
 int tfhe_hip_flush(void);   /* returns the number of levels executed, <0 on error */
+/* Pipelined form for a stream of circuits (a server matching one probe after another): the pending gates are levelised and
+ * their launches ENQUEUED, and the call returns while the device works.  The caller goes on recording the next circuit --
+ * its recording, the elimination of dead gates, the levelling and the plan of its own flush all overlap the execution of
+ * this one (at most one flush is in flight: the next flush waits for it just before it launches).  Everything that
+ * observes a result (bootsSymDecrypt, exports, tfhe_hip_sync_samples, tfhe_hip_get_stats) waits first;
+ * tfhe_hip_wait() waits explicitly.  tfhe_hip_flush() is the synchronous form and also completes a flush in flight. */
+int tfhe_hip_flush_async(void);
+int tfhe_hip_wait(void);
 
 /* result[i] = gate(a[i], b[i]) for i < count, one batched launch */
 int tfhe_hip_gate_batch(int gate, LweSample *result, const LweSample *a, const LweSample *b,

@@ -253,6 +253,15 @@ def flush():
     return _l.load().tfhe_hip_flush()
 
 
+def flush_async():
+    """Enqueue the pending gates and return while the device works (tfhe_hip_flush_async); wait() completes it."""
+    return _l.load().tfhe_hip_flush_async()
+
+
+def wait():
+    return _l.load().tfhe_hip_wait()
+
+
 def set_tuning(name, value):
     if _l.load().tfhe_hip_set_tuning(name.encode(), int(value)) != 0:
         raise ValueError(last_error())

@@ -336,6 +336,7 @@ void Engine::write_slot(SlotPool *pool, int32_t slot, const Torus32 *a, Torus32 
 }
 
 void Engine::read_slot(SlotPool *pool, int32_t slot, Torus32 *a, Torus32 *b) {
+    wait_flight();          // a blocking copy on the null stream does not wait for the engine's non-blocking stream
     std::vector<int32_t> tmp(pool->ct_stride());
     hip_check(hipMemcpy(tmp.data(), pool->data() + (size_t)slot * pool->ct_stride(), tmp.size() * 4, hipMemcpyDeviceToHost),
               "read_slot");
@@ -497,8 +498,15 @@ void Engine::launch_ks(const DeviceKeyImage *key, const int32_t *u_buf, const Ks
     }
 }
 
-void Engine::execute(const DeviceKeyImage *key, SlotPool *pool, const LevelPlan &plan) {
-    const auto t0 = std::chrono::steady_clock::now();
+// wait = false: the launches are enqueued and the call returns; the flush is "in flight" until wait_flight() (called by
+// the next execute() before it touches the descriptor buffers, by every host read of a slot, by the statistics).  The
+// host work of the NEXT flush -- recording, dead-gate elimination, levelling, building its plan -- then overlaps this
+// one's execution (shim.cpp flush_locked).
+void Engine::execute(const DeviceKeyImage *key, SlotPool *pool, LevelPlan &&plan_in, bool wait) {
+    wait_flight();                                   // at most one flush in flight: its descriptors and scratch are in use
+    flight_t0_ = std::chrono::steady_clock::now();
+    flight_plan_ = std::move(plan_in);               // owns the host descriptors until the uploads have certainly happened
+    const LevelPlan &plan = flight_plan_;
     const int levels = plan.levels, K = plan.lanes;
     RotDesc *drots = static_cast<RotDesc *>(scratch(0, plan.rots.size() * sizeof(RotDesc) + 16));
     KsDesc *dks = static_cast<KsDesc *>(scratch(1, plan.kss.size() * sizeof(KsDesc) + 16));
@@ -548,9 +556,10 @@ void Engine::execute(const DeviceKeyImage *key, SlotPool *pool, const LevelPlan 
         }
         return timing_events_[nt++];
     };
-    struct Timed { hipEvent_t e0, e1, e2; bool wide8; int nrot; };
-    std::vector<Timed> timed;
-    hipEvent_t base = nullptr;
+    std::vector<Timed> &timed = flight_timed_;
+    timed.clear();
+    hipEvent_t &base = flight_base_;
+    base = nullptr;
     if (kernel_timing) {
         base = timing_event();
         hip_check(hipEventRecord(base, stream_), "event");
@@ -614,8 +623,19 @@ void Engine::execute(const DeviceKeyImage *key, SlotPool *pool, const LevelPlan 
 #ifdef TFHE_HIP_EXPERIMENTAL
     if (K > 1 && last_group[1] >= 0) hip_check(hipStreamWaitEvent(stream_, order_events_[last_group[1]], 0), "join lanes");
 #endif
+    flight_levels_ = levels;
+    in_flight_ = true;
+    if (wait) wait_flight();
+}
+
+void Engine::wait_flight() {
+    if (!in_flight_) return;
+    in_flight_ = false;
+    const int levels = flight_levels_;
+    std::vector<Timed> &timed = flight_timed_;
+    hipEvent_t base = flight_base_;
     hip_check(hipStreamSynchronize(stream_), "level execution");
-    if (kernel_timing) {
+    if (kernel_timing && base) {
         // durations per launch, and the union of the blind-rotate intervals (two lanes overlap)
         std::vector<std::pair<float, float>> br;
         br.reserve(timed.size());
@@ -656,7 +676,9 @@ void Engine::execute(const DeviceKeyImage *key, SlotPool *pool, const LevelPlan 
     }
     stats.levels += (uint64_t)levels;
     ++stats.flushes;
-    stats.ms_flush_wall += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+    stats.ms_flush_wall += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - flight_t0_).count();
+    timed.clear();
+    flight_plan_ = LevelPlan{};
 }
 
 #ifdef TFHE_HIP_EXPERIMENTAL
@@ -715,6 +737,7 @@ void Engine::execute_dataflow(const DeviceKeyImage *key, SlotPool *pool, const s
 #endif  // TFHE_HIP_EXPERIMENTAL
 
 void Engine::run_bootstrap_woks(const DeviceKeyImage *key, const Torus32 *lin, int count, Torus32 *u_out, Torus32 *acc_out) {
+    wait_flight();
     const DevParams &dp = key->dp;
     // temporary "pool": count slots holding lin
     std::vector<int32_t> padded((size_t)count * dp.ct_stride, 0);
@@ -740,6 +763,7 @@ void Engine::run_bootstrap_woks(const DeviceKeyImage *key, const Torus32 *lin, i
 }
 
 void Engine::run_keyswitch(const DeviceKeyImage *key, const Torus32 *u, int count, Torus32 *out) {
+    wait_flight();
     const DevParams &dp = key->dp;
     const int uw = dp.k * dp.N + 1;
     std::vector<int32_t> padded((size_t)count * dp.u_stride, 0);
@@ -761,6 +785,7 @@ void Engine::run_keyswitch(const DeviceKeyImage *key, const Torus32 *u, int coun
 }
 
 double Engine::run_lane_probe(const DeviceKeyImage *key, int lanes, int levels, int width, unsigned long long *wg_times) {
+    wait_flight();
     const DevParams &dp = key->dp;
     lanes = std::max(1, std::min(lanes, 8));
     const int per = width / lanes;
@@ -837,6 +862,7 @@ double Engine::run_lane_probe(const DeviceKeyImage *key, int lanes, int levels, 
 }
 
 void Engine::run_negacyclic(const DeviceKeyImage *key, const int32_t *ip, const Torus32 *tp, Torus32 *res, int count) {
+    wait_flight();
     DevParams dp = key->dp;
     // 2: through the split transforms; 3: first transpose through the cross-lane paths (N = 1024; same results);
     // 4 / 5: timing forms of the LDS / cross-lane transform repeated 64 times (results meaningless)

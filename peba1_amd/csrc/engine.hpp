@@ -3,6 +3,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 
+#include <chrono>
 #include <cstdint>
 #include <string>
 #include <vector>
@@ -106,8 +107,11 @@ public:
     void write_slots_packed(SlotPool *pool, const int32_t *slots, int count, const Torus32 *words, bool words_on_device, bool wait = true);
     void read_slots_packed(SlotPool *pool, const int32_t *slots, int count, Torus32 *words, bool words_on_device, bool wait = true);
 
-    // run a levelised plan; synchronises the stream before returning
-    void execute(const DeviceKeyImage *key, SlotPool *pool, const LevelPlan &plan);
+    // run a levelised plan.  wait = true: synchronises the stream before returning; false: returns with the launches
+    // enqueued ("in flight") -- see engine.cpp
+    void execute(const DeviceKeyImage *key, SlotPool *pool, LevelPlan &&plan, bool wait = true);
+    void wait_flight();                 // completes an asynchronous execute(): waits, then reads the timing events
+    bool in_flight() const { return in_flight_; }
 #ifdef TFHE_HIP_EXPERIMENTAL
     // run a whole DAG (tasks in topological priority order) as one dataflow launch
     void execute_dataflow(const DeviceKeyImage *key, SlotPool *pool, const std::vector<GateTask> &tasks, int depth);
@@ -168,6 +172,13 @@ public:
 private:
     Engine() = default;
     void *scratch(size_t idx, size_t bytes);   // grow-only device scratch buffers
+    struct Timed { hipEvent_t e0, e1, e2; bool wide8; int nrot; };
+    std::vector<Timed> flight_timed_;
+    hipEvent_t flight_base_ = nullptr;
+    LevelPlan flight_plan_;
+    int flight_levels_ = 0;
+    bool in_flight_ = false;
+    std::chrono::steady_clock::time_point flight_t0_;
     int32_t *stage_slots(const int32_t *slots, int count);
     int32_t *slot_ring_ = nullptr;
     size_t slot_ring_pos_ = 0;

@@ -122,6 +122,10 @@ struct Recorder {
     // ripple adders compute a carry out of their last bit and drop it (Math.cpp:60-64 into a freed temporary): 5 of the
     // 7 gates of that bit, ~55 gates per slot of the match.
     bool eliminate_dead = true;
+    // operations of a flush that was launched without waiting (tfhe_hip_flush_async): their pending references are
+    // released when the flush is known to be complete (finish_flight_locked)
+    std::vector<PendingOp> flight_ops;
+    SlotPool *flight_pool = nullptr;
     std::unordered_map<uint64_t, int32_t> pending_gate;            // two-input gates and NOT: key -> result slot
     std::map<std::array<int32_t, 3>, int32_t> pending_mux;         // MUX: (a, b, c) -> result slot
 };
@@ -165,7 +169,8 @@ SlotPool *pool_of_key(const TFheGateBootstrappingCloudKeySet *bk) {
     return Engine::get().pool_for(bk->bk->p);
 }
 
-int flush_locked();
+int flush_locked(bool wait = true);
+void finish_flight_locked();
 
 // a fresh slot; when the pool is dry, the pending operations (which pin their operands and
 // results) are run first.  Throws ApiError if that frees nothing.
@@ -276,13 +281,32 @@ void record_gate2_locked(int code, LweSample *result, const LweSample *ca, const
 namespace {
 int32_t alloc_slot(SlotPool *pool) {
     Recorder &r = rec();
-    if (pool->in_use() == pool->capacity() && !r.ops.empty() && r.pool == pool) flush_locked();
+    if (pool->in_use() == pool->capacity()) {
+        finish_flight_locked();                          // a completed asynchronous flush still pins its slots
+        if (pool->in_use() == pool->capacity() && !r.ops.empty() && r.pool == pool) flush_locked();
+    }
     return pool->alloc();
 }
 
-int flush_locked() {
+// the asynchronous flush (if any) is complete after this: wait for it, release what it pinned
+void finish_flight_locked() {
     Recorder &r = rec();
-    if (r.ops.empty()) return 0;
+    Engine::get().wait_flight();
+    if (r.flight_ops.empty()) return;
+    SlotPool *pool = r.flight_pool;
+    for (const PendingOp &op : r.flight_ops) {
+        pool->release(op.dst);
+        pool->release(op.a);
+        if (op.b >= 0) pool->release(op.b);
+        if (op.c >= 0) pool->release(op.c);
+    }
+    r.flight_ops.clear();
+    r.flight_pool = nullptr;
+}
+
+int flush_locked(bool wait) {
+    Recorder &r = rec();
+    if (r.ops.empty()) { if (wait) finish_flight_locked(); return 0; }
     SlotPool *pool = r.pool;
     if (r.eliminate_dead) {
         // reverse recording order = reverse topological order: dropping a consumer first lets its producers die too
@@ -310,6 +334,7 @@ int flush_locked() {
             Engine::get().stats.dead_gates += dead;
             if (r.ops.empty()) {
                 r.not_origin.clear(); r.pending_gate.clear(); r.pending_mux.clear(); r.max_level = 0;
+                if (wait) finish_flight_locked();
                 return 0;
             }
         }
@@ -448,15 +473,33 @@ int flush_locked() {
             plan.kss[kpos[g]++] = KsDesc{i0 - base, -1, 0, op.dst};
         }
     }
-    Engine::get().execute(r.key->bk->dev, pool, plan);
-    for (const PendingOp &op : r.ops) {
-        pool->level[op.dst] = 0;
-        pool->pending[op.dst] = 0;
-        pool->release(op.dst);
-        pool->release(op.a);
-        if (op.b >= 0) pool->release(op.b);
-        if (op.c >= 0) pool->release(op.c);
+    // (execute() first waits for a flush still in flight: everything above -- elimination, levelling, the plan -- ran
+    // while the device was busy with it)
+    Engine::get().execute(r.key->bk->dev, pool, std::move(plan), wait);
+    {
+        // the PREVIOUS asynchronous flush is complete now (execute waited for it): release what it pinned
+        if (!r.flight_ops.empty()) {
+            for (const PendingOp &op : r.flight_ops) {
+                r.flight_pool->release(op.dst);
+                r.flight_pool->release(op.a);
+                if (op.b >= 0) r.flight_pool->release(op.b);
+                if (op.c >= 0) r.flight_pool->release(op.c);
+            }
+            r.flight_ops.clear();
+            r.flight_pool = nullptr;
+        }
     }
+    for (const PendingOp &op : r.ops) {
+        pool->level[op.dst] = 0;          // a later recording reads these slots as inputs: the stream orders it behind
+        pool->pending[op.dst] = 0;
+        if (wait) {
+            pool->release(op.dst);
+            pool->release(op.a);
+            if (op.b >= 0) pool->release(op.b);
+            if (op.c >= 0) pool->release(op.c);
+        }
+    }
+    if (!wait) { r.flight_ops.swap(r.ops); r.flight_pool = pool; }
     r.ops.clear();
     r.not_origin.clear();
     r.pending_gate.clear();
@@ -942,6 +985,16 @@ int tfhe_hip_flush(void) {
     std::lock_guard<std::recursive_mutex> g(r.mtx);
     return guarded_rc([&] { return flush_locked(); });
 }
+int tfhe_hip_flush_async(void) {
+    Recorder &r = rec();
+    std::lock_guard<std::recursive_mutex> g(r.mtx);
+    return guarded_rc([&] { return flush_locked(false); });
+}
+int tfhe_hip_wait(void) {
+    Recorder &r = rec();
+    std::lock_guard<std::recursive_mutex> g(r.mtx);
+    return guarded_rc([&] { finish_flight_locked(); return 0; });
+}
 
 int tfhe_hip_gate_batch(int gate, LweSample *result, const LweSample *a, const LweSample *b, int32_t count,
                         const TFheGateBootstrappingCloudKeySet *bk) {
@@ -999,6 +1052,7 @@ int tfhe_hip_set_tuning(const char *name, int64_t value) {
 // the statistics are only ever written under the recorder lock (flushes, reuse counters, test paths)
 void tfhe_hip_get_stats(TfheHipStats *out) {
     std::lock_guard<std::recursive_mutex> g(rec().mtx);
+    Engine::get().wait_flight();          // the times of an asynchronous flush are read when it has completed
     if (out) *out = Engine::get().stats;
 }
 void tfhe_hip_reset_stats(void) {

@@ -42,9 +42,12 @@ def identify(params, key, probe, templates, bound, bitsize, group=4, on_group=No
                 circuit(rb, probe, templates[m], bound, bitsize, key)
                 L.bootsCOPY(bits.at(m), rb.at(0), key.cloud)      # re-points a handle: no data moves
                 rb.close()
-            api.flush()
+            # pipelined: the launches of this group are enqueued and the host goes on recording the next group while the
+            # device works; the next flush (or the final wait) completes this one
+            api.flush_async()
             if on_group is not None:
                 on_group(first, count)
+        api.wait()
     finally:
         api.set_deferred(was_deferred)
     return bits

@@ -118,6 +118,8 @@ SIGNATURES = {
     "tfhe_hip_set_deferred": (None, [C.c_int]),
     "tfhe_hip_get_deferred": (C.c_int, []),
     "tfhe_hip_flush": (C.c_int, []),
+    "tfhe_hip_flush_async": (C.c_int, []),
+    "tfhe_hip_wait": (C.c_int, []),
     "tfhe_hip_gate_batch": (C.c_int, [C.c_int, LS, LS, LS, C.c_int32, CK]),
     "tfhe_hip_set_tuning": (C.c_int, [C.c_char_p, C.c_int64]),
     "tfhe_hip_has_experimental": (C.c_int, []),

@@ -408,3 +408,39 @@ def test_priority_swapping_does_not_change_results(p128_keys, oracle):
     wa, wb = a.words(), b.words()
     for i in (0, 255, 256, 699):
         assert (out[0][i] == oks.gate("XNOR", wa[i], wb[i])).all(), i
+
+
+def test_asynchronous_flush_pipelines_circuits_with_the_same_results(p128_keys):
+    """tfhe_hip_flush_async: the launches of one recording are enqueued and the caller goes on recording the next --
+    here a chain of three multipliers, each reading the one before (so a flush in flight feeds the next recording),
+    temporaries freed while their flush is still in flight, a decrypt in the middle.  Same ciphertexts as three
+    synchronous flushes."""
+    from peba1_amd import api, circuits, lib
+    pp, ks, _ = p128_keys
+    L = lib.load()
+    results = []
+    for mode in ("sync", "async"):
+        L.tfhe_hip_set_encrypt_seed(4711)
+        a = circuits.encrypt_number(pp, 11, 9, ks)
+        b = circuits.encrypt_number(pp, 13, 9, ks)
+        api.set_deferred(True)
+        try:
+            prods = []
+            x = a
+            for k in range(3):
+                p = api.CiphertextArray(pp, 24)
+                circuits.load().peba1_multiply(p.ptr, x.ptr, b.ptr, 4, ks.cloud)      # 4-bit operands: low bits of x
+                (api.flush if mode == "sync" else api.flush_async)()
+                if k == 1:
+                    assert circuits.decrypt_number(p, ks, 23) == ((11 * 13) % 16) * 13  # observing waits for the flight
+                prods.append(p)
+                x = p
+                del p
+            if mode == "async":
+                assert api.wait() == 0
+            words = np.concatenate([q.words() for q in prods])
+        finally:
+            api.set_deferred(False)
+        results.append(words)
+        assert circuits.decrypt_number(prods[0], ks, 23) == 11 * 13
+    assert (results[0] == results[1]).all()
