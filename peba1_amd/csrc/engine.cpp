@@ -122,6 +122,7 @@ void Engine::ensure_init() {
     if (const char *env = std::getenv("TFHE_HIP_LANE_PRIO")) lane_prio = std::atoi(env);
     if (const char *env = std::getenv("TFHE_HIP_BR_FAIR")) br_fair = std::atoi(env);
     if (const char *env = std::getenv("TFHE_HIP_BR8_MAX")) br8_max_rotations = std::atoi(env);
+    if (const char *env = std::getenv("TFHE_HIP_BR_TAIL8")) br_tail8 = std::atoi(env);
     if (const char *env = std::getenv("TFHE_HIP_BR_VARIANT")) br_variant = std::atoi(env);
     if (const char *env = std::getenv("TFHE_HIP_BR_TABLE")) br_digit_table = std::atoi(env);
     for (auto &e : ev_) hip_check(hipEventCreate(&e), "hipEventCreate");
@@ -452,6 +453,18 @@ bool Engine::launch_br(const DeviceKeyImage *key, const int32_t *pool, const Rot
     if (form == BR_FORM_WAVE8) {
         launch_blind_rotate8(stream, dp, key->key, pool, rots, count, u_buf, acc_dbg);
         return true;
+    }
+    // the last, at most half-filled round of a wide launch on the 8-wave form (descriptors carry their own output
+    // index, so a level splits anywhere; the debug probes index by workgroup and keep one launch)
+    const int round = 2 * cu_count_, tail = count % round;
+    if (br_tail8 && count > round && tail > 0 && tail <= std::min(br8_max_rotations, cu_count_) && dp.N == 1024 && dp.l >= 2 &&
+        !acc_dbg && !wg_times_dbg_ && key->form_ok[BR_FORM_WAVE8][tables]) {
+        launch_blind_rotate4(stream, dp, key->key, pool, rots, count - tail, u_buf, nullptr);
+        DevParams dp8 = dp;                                   // as a narrow launch gets them: no turn-taking
+        dp8.fair_shift = 0;
+        dp8.cu_arrivals = nullptr;
+        launch_blind_rotate8(stream, dp8, key->key, pool, rots + (count - tail), tail, u_buf, nullptr);
+        return false;
     }
     launch_blind_rotate4(stream, dp, key->key, pool, rots, count, u_buf, acc_dbg);
     return false;

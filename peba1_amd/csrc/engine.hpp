@@ -153,6 +153,10 @@ public:
     // launches of at most min(this, CU count) rotations (at most one workgroup per CU) use the 8-wave form
     // of the kernel, N = 1024 only; 0 = never (env TFHE_HIP_BR8_MAX, tuning "br8_max_rotations")
     int br8_max_rotations = 1 << 30;
+    // A 4-wave launch whose last round would leave at most one workgroup per CU (count = q * 2 * CUs + r, q >= 1,
+    // 0 < r <= CUs) hands those r rotations to the 8-wave form as a second launch: 2.9 ms instead of the 3.75 ms a
+    // lone 4-wave workgroup per CU takes (env TFHE_HIP_BR_TAIL8, tuning "br_tail8"; 0 = one launch)
+    int br_tail8 = 1;
     // 1 = the first radix-4 step of the forward transforms looks digit products up in LDS (gadget digits
     // of at most 7 bits; split form: stage 0, and the first radix-4 step too where digits have at most 6
     // bits); 2 = split form: stage 0 only; 0 = multiplies (env TFHE_HIP_BR_TABLE, tuning "br_digit_table")

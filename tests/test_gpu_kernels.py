@@ -408,11 +408,20 @@ def test_every_selectable_kernel_form_is_bit_exact(oracle, pname):
                 assert (um == ref_many).all(), (pname, variant, table, br4_max, br8_max)
                 ul = api.kernel_bootstrap_woks(ks, many[:200])           # 200 workgroups: one per CU, the 8-wave form's range
                 assert (ul == ref_many[:200]).all(), (pname, variant, table, br4_max, br8_max, "200-wide")
+            # 600 = one full round of two workgroups per CU + 88: by default the 88 run as a second launch of the
+            # 8-wave form ("br_tail8"); as one launch the words are the same
+            api.set_tuning("br_variant", -1)
+            api.set_tuning("br_digit_table", 1)
+            api.set_tuning("br8_max_rotations", 1 << 30)
+            for tail8 in (0, 1):
+                api.set_tuning("br_tail8", tail8)
+                assert (api.kernel_bootstrap_woks(ks, many) == ref_many).all(), (pname, "br_tail8", tail8)
         finally:
             api.set_tuning("br_variant", -1)
             api.set_tuning("br_digit_table", 1)
             api.set_tuning("br4_max_rotations", 1 << 30)
             api.set_tuning("br8_max_rotations", 1 << 30)
+            api.set_tuning("br_tail8", 1)
     finally:
         ks.close()
 
