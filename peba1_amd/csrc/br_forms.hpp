@@ -21,8 +21,7 @@ enum BrForm : int {
     BR_FORM_SPLIT = 2,    // 8 waves, half transforms, 64-bit sums
     BR_FORM_WAVE8 = 3,    // 8 waves for narrow launches (N = 1024): rows split over two waves
     BR_FORM_WAVE2 = 4,    // 2 waves (N = 1024)
-    BR_FORM_WAVE12 = 5,   // 12 waves for narrow launches (N = 1024, l = 3): one gadget row per wave
-    BR_FORM_COUNT = 6
+    BR_FORM_COUNT = 5
 };
 
 namespace br_forms_detail {
@@ -83,14 +82,6 @@ inline bool br_form_admissible(int form, int N, int l, int Bgbit, int tables) {
         into_inverse = 2 * ((l - 1) * F * kQ + 0.5) + 2 * (F * kQ + 0.5);          // A's two sums + B's two sums
         break;
     case BR_FORM_WAVE2: if (N != 1024) return false; into_inverse = 2 * l * F * kQ + 0.5; break;
-    case BR_FORM_WAVE12: {
-        // 2 l rows reduced one by one meet in a sum that is folded by the multiple of 4P nearest to it: the fold is
-        // exact for sums below 3 * 2^28 and leaves less than 2^28 + 2^18 < 2.01P
-        if (N != 1024 || l != 3) return false;
-        if (2 * per_row * kP >= 3.0 * 268435456.0) return false;
-        into_inverse = 2.01;
-        break;
-    }
     default: return false;
     }
     return into_inverse < 4.0;

@@ -123,7 +123,6 @@ void Engine::ensure_init() {
     if (const char *env = std::getenv("TFHE_HIP_BR_FAIR")) br_fair = std::atoi(env);
     if (const char *env = std::getenv("TFHE_HIP_BR8_MAX")) br8_max_rotations = std::atoi(env);
     if (const char *env = std::getenv("TFHE_HIP_BR_TAIL8")) br_tail8 = std::atoi(env);
-    if (const char *env = std::getenv("TFHE_HIP_BR12")) br12 = std::atoi(env);
     if (const char *env = std::getenv("TFHE_HIP_BR_VARIANT")) br_variant = std::atoi(env);
     if (const char *env = std::getenv("TFHE_HIP_BR_TABLE")) br_digit_table = std::atoi(env);
     for (auto &e : ev_) hip_check(hipEventCreate(&e), "hipEventCreate");
@@ -393,16 +392,6 @@ void Engine::read_slots_packed(SlotPool *pool, const int32_t *slots, int count, 
     if (wait || !on_device) hip_check(hipStreamSynchronize(stream_), "gather slots");
 }
 
-// launches of at most one workgroup per CU: the 12-wave form where the tuning and the key's gadget allow it, else
-// the 8-wave form (`forced12`: the form selection already chose the 12-wave form)
-void Engine::launch_narrow(hipStream_t stream, const DevParams &dp, const DeviceKeyImage *key, int tables, const int32_t *pool,
-                           const RotDesc *rots, int count, int32_t *u_buf, int32_t *acc_dbg, bool forced12) {
-    if (forced12 || (br12 && key->form_ok[BR_FORM_WAVE12][tables]))
-        launch_blind_rotate12(stream, dp, key->key, pool, rots, count, u_buf, acc_dbg);
-    else
-        launch_blind_rotate8(stream, dp, key->key, pool, rots, count, u_buf, acc_dbg);
-}
-
 bool Engine::launch_br(const DeviceKeyImage *key, const int32_t *pool, const RotDesc *rots, int count, int32_t *u_buf,
                        int32_t *acc_dbg, hipStream_t stream, int wave_prio) {
     if (!stream) stream = stream_;
@@ -421,11 +410,11 @@ bool Engine::launch_br(const DeviceKeyImage *key, const int32_t *pool, const Rot
     // except l = 3 in the 4-wave form at N = 2048); else the same form with smaller or no digit tables, else another form
     int tables = br_digit_table < 0 || br_digit_table > 2 ? 0 : br_digit_table;
     if (!key->form_ok[form][tables]) {
-        static const int order[BR_FORM_COUNT] = {BR_FORM_WIDE4, BR_FORM_SPLIT, BR_FORM_LEAN4, BR_FORM_WAVE2, BR_FORM_WAVE8, BR_FORM_WAVE12};
+        static const int order[BR_FORM_COUNT] = {BR_FORM_WIDE4, BR_FORM_SPLIT, BR_FORM_LEAN4, BR_FORM_WAVE2, BR_FORM_WAVE8};
         int pick_f = -1, pick_t = 0;
         for (int k = -1; k < BR_FORM_COUNT && pick_f < 0; ++k) {
             const int f = k < 0 ? form : order[k];
-            if ((f == BR_FORM_WAVE8 || f == BR_FORM_WAVE12) && count > cu_count_) continue;    // their LDS allows one workgroup per CU only
+            if (f == BR_FORM_WAVE8 && count > cu_count_) continue;          // its LDS allows one workgroup per CU only
             for (int t : {tables, 2, 0})
                 if (key->form_ok[f][t]) { pick_f = f; pick_t = t; break; }
         }
@@ -461,8 +450,8 @@ bool Engine::launch_br(const DeviceKeyImage *key, const int32_t *pool, const Rot
         dp.cu_arrivals = cu_arrivals_;
     }
     dp.wg_times = wg_times_dbg_;
-    if (form == BR_FORM_WAVE8 || form == BR_FORM_WAVE12) {
-        launch_narrow(stream, dp, key, tables, pool, rots, count, u_buf, acc_dbg, form == BR_FORM_WAVE12);
+    if (form == BR_FORM_WAVE8) {
+        launch_blind_rotate8(stream, dp, key->key, pool, rots, count, u_buf, acc_dbg);
         return true;
     }
     // the last, at most half-filled round of a wide launch on the 8-wave form (descriptors carry their own output
@@ -474,7 +463,7 @@ bool Engine::launch_br(const DeviceKeyImage *key, const int32_t *pool, const Rot
         DevParams dp8 = dp;                                   // as a narrow launch gets them: no turn-taking
         dp8.fair_shift = 0;
         dp8.cu_arrivals = nullptr;
-        launch_narrow(stream, dp8, key, tables, pool, rots + (count - tail), tail, u_buf, nullptr, false);
+        launch_blind_rotate8(stream, dp8, key->key, pool, rots + (count - tail), tail, u_buf, nullptr);
         return false;
     }
     launch_blind_rotate4(stream, dp, key->key, pool, rots, count, u_buf, acc_dbg);

@@ -154,9 +154,6 @@ public:
     // launches of at most min(this, CU count) rotations (at most one workgroup per CU) use the 8-wave form
     // of the kernel, N = 1024 only; 0 = never (env TFHE_HIP_BR8_MAX, tuning "br8_max_rotations")
     int br8_max_rotations = 1 << 30;
-    // the 12-wave form (one gadget row per wave) takes the 8-wave form's launches where l = 3 and N = 1024
-    // (env TFHE_HIP_BR12, tuning "br12"; 0 = 8-wave form)
-    int br12 = 1;
     // A 4-wave launch whose last round would leave at most one workgroup per CU (count = q * 2 * CUs + r, q >= 1,
     // 0 < r <= CUs) hands those r rotations to the 8-wave form as a second launch: 2.9 ms instead of the 3.75 ms a
     // lone 4-wave workgroup per CU takes (env TFHE_HIP_BR_TAIL8, tuning "br_tail8"; 0 = one launch)
@@ -169,8 +166,6 @@ public:
     void launch_ks(const DeviceKeyImage *key, const int32_t *u_buf, const KsDesc *descs, int count, int32_t *pool,
                    hipStream_t stream = nullptr, int lane = 0);
     // returns true when the launch used the 8-wave form
-    void launch_narrow(hipStream_t stream, const DevParams &dp, const DeviceKeyImage *key, int tables, const int32_t *pool,
-                       const RotDesc *rots, int count, int32_t *u_buf, int32_t *acc_dbg, bool forced12);
     bool launch_br(const DeviceKeyImage *key, const int32_t *pool, const RotDesc *rots, int count, int32_t *u_buf,
                    int32_t *acc_dbg, hipStream_t stream = nullptr, int wave_prio = 0);
     // diagnostic (tools/lane_probe.py): `levels` rounds of (blind rotate + key switch) of `width`

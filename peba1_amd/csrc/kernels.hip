@@ -711,11 +711,6 @@ __device__ __forceinline__ uint32_t split_finish(int h, int32_t a0, int32_t a1, 
     return crt_signed_to_torus(mont_mul(a0 - a1, iw1_0, NTT_P0, NTT_PINV0), mont_mul(b0 - b1, iw1_1, NTT_P1, NTT_PINV1));
 }
 
-#ifdef TFHE_HIP_BR8_NOLDSTW      // measurement only: the 8-wave form with its forward twiddles from global memory
-constexpr bool BR8_LDSTW = false;
-#else
-constexpr bool BR8_LDSTW = true;
-#endif
 template <int LOGN>
 struct Br8Lds {
     using NTT = WaveNtt<LOGN>;
@@ -791,10 +786,10 @@ __global__ __launch_bounds__(512, 2) void blind_rotate8_kernel(
         {
             int64_t acc0[REGS], acc1[REGS];             // output poly u, output poly 1-u
             if (!role_b)
-                forward_poly<LOGN, true, true, true, TAB, int64_t, int64_t, BR8_LDSTW>(p, key, c, sh.acc, scr, lane, q, i, u, abar, u != 0,
+                forward_poly<LOGN, true, true, true, TAB, int64_t, int64_t, true>(p, key, c, sh.acc, scr, lane, q, i, u, abar, u != 0,
                                                                                 acc0, acc1, t0, 0, last);
             else
-                forward_poly<LOGN, true, true, true, TAB, int64_t, int64_t, BR8_LDSTW>(p, key, c, sh.acc, scr, lane, q, i, u, abar, u != 0,
+                forward_poly<LOGN, true, true, true, TAB, int64_t, int64_t, true>(p, key, c, sh.acc, scr, lane, q, i, u, abar, u != 0,
                                                                                 acc0, acc1, t0, last, last + 1);
             int32_t s0[REGS], s1[REGS];
 #pragma unroll
@@ -845,131 +840,6 @@ __global__ __launch_bounds__(512, 2) void blind_rotate8_kernel(
         lds_barrier();
     }
     extract_sample<LOGN, 512>(p, rd, sh.acc, u_buf, acc_dbg, tid);
-    clk.end(p);
-}
-
-// ---------------------------------------------------------------------------
-// K1+K2: blind rotate, 12-wave latency form (l = 3, N = 1024): one wave per prime, input polynomial and gadget row.
-// In the 8-wave form wave A transforms two gadget rows and wave B one, so A runs its second row alone on the SIMD --
-// at the lone-wave issue rate -- while B waits at the barrier.  Here wave (q, u, j) transforms row j only: the three
-// waves of a SIMD run one row each side by side (the shared issue rate throughout), every product is reduced on its
-// own (|.| < 0.72P), the row for the wave's own output polynomial stays in the wave's transpose scratch and the row
-// for the other output polynomial goes to a second buffer.  The inverse is split over waves j = 0, 1 as in the
-// 8-wave form (lower / upper half of the spectrum); six rows meet in each sum, |.| < 4.32P, so the sum is brought
-// back under 2.01P by subtracting the multiple of 4P nearest to it (the inverse takes inputs below 4P); waves j = 2
-// sit the inverse out.  Same integers as the other forms; three workgroup barriers per step.
-// ---------------------------------------------------------------------------
-template <int LOGN>
-struct Br12Lds {
-    using NTT = WaveNtt<LOGN>;
-    using SUB = WaveNtt<LOGN - 1>;
-    AccLds<LOGN> acc;
-    uint32_t scr[12][NTT::SCRATCH_WORDS];          // wave-private transposes, then the wave's row for its own output polynomial
-    uint32_t px[12][NTT::SCRATCH_WORDS];           // the wave's row for the other output polynomial
-    uint32_t inv[8][SUB::SCRATCH_WORDS];           // half inverse transforms: transposes, then outputs (natural order)
-    uint16_t bar[1024 + 8];
-    uint32_t dtab[2][5 * DIGIT_TAB];
-};
-static_assert(sizeof(Br12Lds<10>) <= 160 * 1024, "the 12-wave form must fit a CU's LDS");
-
-template <int LOGN, bool TAB>
-__global__ __launch_bounds__(768, 1) void blind_rotate12_kernel(
-    DevParams p, DevKey key, const int32_t *__restrict__ pool, const RotDesc *__restrict__ rots,
-    int32_t *__restrict__ u_buf, int32_t *__restrict__ acc_dbg) {
-    using NTT = WaveNtt<LOGN>;
-    using SUB = WaveNtt<LOGN - 1>;
-    constexpr int N = NTT::N, M = N / 2, REGS = NTT::REGS, RS = SUB::REGS, QUARTER = RS / 4;
-    __shared__ __align__(16) Br12Lds<LOGN> sh;
-    const int tid = threadIdx.x;
-    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int base = wv & 3, q = base & 1, u = base >> 1;
-    const int row = wv >> 2;                            // the gadget row this wave transforms
-    const bool inv_wave = row < 2;
-    const int h = row & 1;                              // the half of every inverse transform waves j = 0, 1 run
-    const int lane = tid & 63;
-    PrimeCtx c = make_ctx(q, key.tw, N);
-    const PrimeCtx ch = make_sub_ctx(q, h, key.tw, N);
-    const uint32_t iw1_0 = key.tw[(size_t)1 * N + 1], iw1_1 = key.tw[(size_t)3 * N + 1];   // inverse stage 0, both primes
-    uint32_t *scr = sh.scr[wv];
-    uint32_t *isc = sh.inv[wv & 7];
-    const int n = p.n;
-    const RotDesc rd = rots[blockIdx.x];
-    ClockProbe clk;
-    clk.begin(p);
-
-    prelude_modswitch<LOGN, 768>(p, rd, pool, sh.bar, tid);
-    if constexpr (TAB) {
-        // the six waves of prime q fill that prime's table
-        NTT::build_digit_table(sh.dtab[q], c, p.Bgbit, ((wv >> 1) << 6) | lane, 384);
-        c.dtab = sh.dtab[q];
-    }
-    __syncthreads();
-    if (q == 0 && row == 0) {
-        const int barb = sh.bar[n];
-#pragma unroll
-        for (int r = 0; r < REGS; ++r) {
-            const int j = r * 64 + lane;
-            sh.acc.set(u, j, u == 0 ? 0u : testvector_coef<LOGN>(j, barb, p.mu));
-        }
-    }
-    __syncthreads();
-
-    typename NTT::FwdTw0 t0;
-    t0.load(c, lane);
-    for (int i = 0; i < n; ++i) {
-        const int abar = __builtin_amdgcn_readfirstlane((int)sh.bar[i]);
-        if (abar == 0) continue;
-        {
-            int32_t s0[REGS], s1[REGS];                 // output poly u, output poly 1-u: one reduced product each
-            forward_poly<LOGN, true, true, true, TAB, int32_t, int32_t, false>(p, key, c, sh.acc, scr, lane, q, i, u, abar, u != 0,
-                                                                              s0, s1, t0, row, row + 1);
-            NTT::write_row(s0, scr, lane);
-            NTT::write_row(s1, sh.px[wv], lane);
-        }
-        typename SUB::InvTw2 t2;                            // requested before the barrier, in flight across it
-        if (inv_wave) t2.load(ch, lane);
-        lds_barrier();
-        if (inv_wave) {
-            // half h of the summed spectrum of output polynomial u, in the half transform's layout (as in the 8-wave form)
-            const int off = NTT::row_base(32 * h + (lane >> 1)) + RS * (lane & 1);
-            int32_t t[RS];
-#pragma unroll
-            for (int k = 0; k < 6; ++k) {
-                const uint32_t *src = (k < 3 ? sh.scr[base + 4 * k] : sh.px[(base ^ 2) + 4 * (k - 3)]) + off;
-#pragma unroll
-                for (int g = 0; g < RS / 4; ++g) {
-                    const uint4 v = reinterpret_cast<const uint4 *>(src)[g];
-                    if (k == 0) { t[4 * g] = (int32_t)v.x; t[4 * g + 1] = (int32_t)v.y; t[4 * g + 2] = (int32_t)v.z; t[4 * g + 3] = (int32_t)v.w; }
-                    else { t[4 * g] += (int32_t)v.x; t[4 * g + 1] += (int32_t)v.y; t[4 * g + 2] += (int32_t)v.z; t[4 * g + 3] += (int32_t)v.w; }
-                }
-            }
-            // six rows below 0.72P each: |t| < 4.32P < 3 * 2^28.  Subtracting round(t / 2^29) * 4P (a multiple of P
-            // within 164k of 2^29 per unit) leaves |t| < 2^28 + 2^18 < 2.01P
-            const int32_t four_p = (int32_t)(4u * c.P);
-#pragma unroll
-            for (int r = 0; r < RS; ++r) t[r] -= ((t[r] + (1 << 28)) >> 29) * four_p;
-            SUB::template inverse<true>(t, ch, isc, lane, t2);          // half-transform outputs, natural order, |t| < P
-#pragma unroll
-            for (int r = 0; r < RS; ++r) isc[r * 64 + lane] = (uint32_t)t[r];
-        }
-        lds_barrier();
-        if (inv_wave) {
-            // the four inverse waves of output polynomial u take a quarter of the register rows each and finish
-            // coefficients j and j + N/2 of it, for both primes (split_finish: last inverse stage, CRT)
-            const uint32_t *a0 = sh.inv[(u << 1)], *a1 = sh.inv[(u << 1) | 4];
-            const uint32_t *b0 = sh.inv[(u << 1) | 1], *b1 = sh.inv[(u << 1) | 5];
-            const int part = q | (h << 1);
-#pragma unroll
-            for (int r = 0; r < QUARTER; ++r) {
-                const int jl = (part * QUARTER + r) * 64 + lane;
-                const int32_t va0 = (int32_t)a0[jl], va1 = (int32_t)a1[jl], vb0 = (int32_t)b0[jl], vb1 = (int32_t)b1[jl];
-                sh.acc.set(u, jl, sh.acc.get(u, jl) + split_finish(0, va0, va1, vb0, vb1, iw1_0, iw1_1));
-                sh.acc.set(u, M + jl, sh.acc.get(u, M + jl) + split_finish(1, va0, va1, vb0, vb1, iw1_0, iw1_1));
-            }
-        }
-        lds_barrier();
-    }
-    extract_sample<LOGN, 768>(p, rd, sh.acc, u_buf, acc_dbg, tid);
     clk.end(p);
 }
 
@@ -1758,15 +1628,6 @@ void launch_blind_rotate8(hipStream_t s, const DevParams &p, const DevKey &key, 
         hipLaunchKernelGGL((blind_rotate8_kernel<10, true>), dim3(count), dim3(512), 0, s, p, key, pool, rots, u_buf, acc_dbg);
     else
         hipLaunchKernelGGL((blind_rotate8_kernel<10, false>), dim3(count), dim3(512), 0, s, p, key, pool, rots, u_buf, acc_dbg);
-}
-
-void launch_blind_rotate12(hipStream_t s, const DevParams &p, const DevKey &key, const int32_t *pool,
-                           const RotDesc *rots, int count, int32_t *u_buf, int32_t *acc_dbg) {
-    if (count <= 0) return;
-    if (digit_table_usable(p))
-        hipLaunchKernelGGL((blind_rotate12_kernel<10, true>), dim3(count), dim3(768), 0, s, p, key, pool, rots, u_buf, acc_dbg);
-    else
-        hipLaunchKernelGGL((blind_rotate12_kernel<10, false>), dim3(count), dim3(768), 0, s, p, key, pool, rots, u_buf, acc_dbg);
 }
 
 void launch_blind_rotate_split(hipStream_t s, const DevParams &p, const DevKey &key, const int32_t *pool,

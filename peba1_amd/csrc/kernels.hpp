@@ -80,8 +80,6 @@ void launch_blind_rotate4(hipStream_t s, const DevParams &p, const DevKey &key, 
 // 8-wave form (N = 1024, l >= 2) for launches of at most one workgroup per CU: a second wave per SIMD
 void launch_blind_rotate8(hipStream_t s, const DevParams &p, const DevKey &key, const int32_t *pool,
                           const RotDesc *rots, int count, int32_t *u_buf, int32_t *acc_dbg);
-void launch_blind_rotate12(hipStream_t s, const DevParams &p, const DevKey &key, const int32_t *pool,
-                          const RotDesc *rots, int count, int32_t *u_buf, int32_t *acc_dbg);
 // split form (8 waves per rotation, every transform as two half-size ones; N = 1024 or 2048)
 void launch_blind_rotate_split(hipStream_t s, const DevParams &p, const DevKey &key, const int32_t *pool,
                                const RotDesc *rots, int count, int32_t *u_buf, int32_t *acc_dbg);

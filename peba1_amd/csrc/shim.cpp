@@ -1037,7 +1037,6 @@ int tfhe_hip_set_tuning(const char *name, int64_t value) {
     if (name && std::strcmp(name, "br_digit_table") == 0) { Engine::get().br_digit_table = (int)value; return 0; }
     if (name && std::strcmp(name, "br8_max_rotations") == 0) { Engine::get().br8_max_rotations = (int)value; return 0; }
     if (name && std::strcmp(name, "br_tail8") == 0) { Engine::get().br_tail8 = (int)value; return 0; }
-    if (name && std::strcmp(name, "br12") == 0) { Engine::get().br12 = (int)value; return 0; }
     if (name && std::strcmp(name, "br_variant") == 0) { Engine::get().br_variant = (int)value; return 0; }
     if (name && std::strcmp(name, "reuse_gates") == 0) { rec().reuse_gates = value != 0; return 0; }
     if (name && std::strcmp(name, "eliminate_dead") == 0) { rec().eliminate_dead = value != 0; return 0; }

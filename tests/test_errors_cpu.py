@@ -164,16 +164,12 @@ def test_kernel_form_admissibility_predicate():
     inside none."""
     from peba1_amd import lib
     ok = lib.load().tfhe_hip_test_form_admissible
-    WIDE4, LEAN4, SPLIT, WAVE8, WAVE2, WAVE12 = range(6)
+    WIDE4, LEAN4, SPLIT, WAVE8, WAVE2 = range(5)
     for N, l, B in ((1024, 3, 7), (1024, 2, 10)):
         assert all(ok(f, N, l, B, t) for f in range(5) for t in range(3))
-    # the 12-wave form is written for l = 3 at N = 1024 (one wave per gadget row)
-    assert all(ok(WAVE12, 1024, 3, 7, t) for t in range(3)) and ok(WAVE12, 1024, 3, 10, 0)
-    assert not ok(WAVE12, 1024, 2, 10, 1) and not ok(WAVE12, 1024, 4, 8, 1) and not ok(WAVE12, 2048, 3, 6, 1)
-    assert [ok(f, 2048, 3, 6, 1) for f in range(6)] == [0, 0, 1, 0, 0, 0]
-    assert [ok(f, 1024, 4, 8, 1) for f in range(6)] == [1, 0, 1, 1, 1, 0]
+    assert [ok(f, 2048, 3, 6, 1) for f in range(5)] == [0, 0, 1, 0, 0]
+    assert [ok(f, 1024, 4, 8, 1) for f in range(5)] == [1, 0, 1, 1, 1]
     assert [ok(SPLIT, 2048, 6, 4, t) for t in range(3)] == [1, 0, 1]
-    assert not any(ok(f, 2048, 8, 4, t) for f in range(6) for t in range(3))
-    assert not ok(6, 1024, 3, 7, 0)                                               # no such form
+    assert not any(ok(f, 2048, 8, 4, t) for f in range(5) for t in range(3))
     assert not ok(WIDE4, 1024, 8, 4, 0) and ok(WAVE2, 1024, 8, 4, 0)
     assert not ok(WIDE4, 4096, 3, 7, 0) and not ok(WIDE4, 1024, 5, 7, 0)          # ring size / l * Bgbit > 32

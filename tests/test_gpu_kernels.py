@@ -358,8 +358,8 @@ def test_lean_kernel_form_is_bit_exact(p128_keys, oracle):
 def test_every_selectable_kernel_form_is_bit_exact(oracle, pname):
     """Tunings never change results: for every parameter set, every combination of the blind-rotate
     form ("br_variant": wide, lean, split), the digit table of the first NTT step ("br_digit_table"; ignored where the
-    gadget digits are wider than 7 bits), the 12-wave and 8-wave forms for narrow launches ("br12",
-    "br8_max_rotations"; N = 1024 only) and the 2-wave kernel gives the oracle's accumulator, on gate preludes, on the
+    gadget digits are wider than 7 bits), the 8-wave form for narrow launches ("br8_max_rotations";
+    N = 1024 only) and the 2-wave kernel gives the oracle's accumulator, on gate preludes, on the
     sign-wrap edge inputs, on a 200-wide launch and on one random launch wide enough to share CUs."""
     from peba1_amd import api
     pp = {"P128": lambda: api.ParameterSet(128), "P80": lambda: api.ParameterSet(80),
@@ -385,37 +385,34 @@ def test_every_selectable_kernel_form_is_bit_exact(oracle, pname):
         many = rng.integers(-2**31, 2**31, (600, pp.words), dtype=np.int64).astype(np.int32)
         ref_many = None
         # (form, digit table, 4-wave limit, 8-wave limit): the small batch runs the 8-wave form where enabled
-        # narrow launches: the 12-wave form (l = 3 at N = 1024, "br12"), the 8-wave form, neither
-        forms = [(v, t, 1 << 30, b8, b12) for v in (0, 1) for t in (1, 0) for b8, b12 in ((1 << 30, 1), (1 << 30, 0), (0, 1))]
+        forms = [(v, t, 1 << 30, b8) for v in (0, 1) for t in (1, 0) for b8 in (1 << 30, 0)]
         # the split form (8 waves, half transforms); table 1 = the most the set allows (stage 0 and the first
         # radix-4 step at Bgbit <= 6), 2 = stage 0 only, 0 = none
-        forms += [(2, t, 1 << 30, 0, 1) for t in (1, 2, 0)]
-        forms += [(0, 1, 0, 0, 1)] if pp.N == 1024 else []
+        forms += [(2, t, 1 << 30, 0) for t in (1, 2, 0)]
+        forms += [(0, 1, 0, 0)] if pp.N == 1024 else []
         try:
-            for variant, table, br4_max, br8_max, br12 in forms:
+            for variant, table, br4_max, br8_max in forms:
                 api.set_tuning("br_variant", variant)
                 api.set_tuning("br_digit_table", table)
                 api.set_tuning("br4_max_rotations", br4_max)
                 api.set_tuning("br8_max_rotations", br8_max)
-                api.set_tuning("br12", br12)
                 u, acc = api.kernel_bootstrap_woks(ks, lins, want_acc=True)
                 for c in range(len(lins)):
-                    assert (acc[c] == want[c]).all(), (pname, variant, table, br4_max, br8_max, br12, c)
+                    assert (acc[c] == want[c]).all(), (pname, variant, table, br4_max, br8_max, c)
                     assert (u[c] == oks.sample_extract(want[c])).all()
                 um = api.kernel_bootstrap_woks(ks, many)
                 if ref_many is None:
                     ref_many = um
                     for c in (0, 599):
                         assert (um[c] == oks.bootstrap_woks(many[c])).all()
-                assert (um == ref_many).all(), (pname, variant, table, br4_max, br8_max, br12)
+                assert (um == ref_many).all(), (pname, variant, table, br4_max, br8_max)
                 ul = api.kernel_bootstrap_woks(ks, many[:200])           # 200 workgroups: one per CU, the 8-wave form's range
-                assert (ul == ref_many[:200]).all(), (pname, variant, table, br4_max, br8_max, br12, "200-wide")
+                assert (ul == ref_many[:200]).all(), (pname, variant, table, br4_max, br8_max, "200-wide")
             # 600 = one full round of two workgroups per CU + 88: by default the 88 run as a second launch of the
             # 8-wave form ("br_tail8"); as one launch the words are the same
             api.set_tuning("br_variant", -1)
             api.set_tuning("br_digit_table", 1)
             api.set_tuning("br8_max_rotations", 1 << 30)
-            api.set_tuning("br12", 1)
             for tail8 in (0, 1):
                 api.set_tuning("br_tail8", tail8)
                 assert (api.kernel_bootstrap_woks(ks, many) == ref_many).all(), (pname, "br_tail8", tail8)
@@ -425,7 +422,6 @@ def test_every_selectable_kernel_form_is_bit_exact(oracle, pname):
             api.set_tuning("br4_max_rotations", 1 << 30)
             api.set_tuning("br8_max_rotations", 1 << 30)
             api.set_tuning("br_tail8", 1)
-            api.set_tuning("br12", 1)
     finally:
         ks.close()
 
