@@ -147,6 +147,9 @@ def main():
     ap.add_argument("--slots", type=int, default=0, help="slots per template (default 128; 256 for --mode sharded)")
     ap.add_argument("--logical-ranks", type=int, default=0,
                     help="--mode sharded at --gpus 1: run the phases of this many logical ranks on the one device")
+    ap.add_argument("--fast-partial", action="store_true",
+                    help="--mode sharded: every rank computes its slots' distance with the depth-optimised circuit "
+                         "(PEBA1_DIST_FAST_PARTIAL; NOT the reference's gate sequence) -- the latency form of the sharded match")
     ap.add_argument("--ripple-combine", action="store_true",
                     help="--mode sharded: rank 0 adds the partial sums with the pairwise tree of the reference's ripple "
                          "adders and its bit-serial comparator (the DAG the golden digest pins) instead of the "
@@ -264,7 +267,8 @@ def main():
             if use_dist:
                 # libpeba1-dist (C++): partial sum of this rank's slots, ONE gather of 24 ciphertexts per rank, rank 0 combines
                 res = pd.sharded_match(dist, torch, L, circuits.load(), pp.ptr, ks.cloud, pp.words, S[lo:hi], T[lo:hi],
-                                       bound.ptr, bitsize, device=xdev, fast_combine=not args.ripple_combine, comm=comm)
+                                       bound.ptr, bitsize, device=xdev, fast_combine=not args.ripple_combine, comm=comm,
+                                       fast_partial=args.fast_partial)
                 api.flush()
                 return res
             # logical ranks on the one device: the same C phases (peba1_sharded_partial_packed / _combine_packed), timed one by one
@@ -272,7 +276,7 @@ def main():
             for r in range(nranks):
                 rlo, rhi = pd.shard_slots(nslots, nranks, r)
                 tr = time.perf_counter()
-                parts.append(pd.local_partial_packed(ks.cloud, pp.words, S[rlo:rhi], T[rlo:rhi], bitsize))
+                parts.append(pd.local_partial_packed(ks.cloud, pp.words, S[rlo:rhi], T[rlo:rhi], bitsize, fast=args.fast_partial))
                 rank_ms.append((time.perf_counter() - tr) * 1e3)
             tr = time.perf_counter()
             res = pd.combine_packed(L, pp.ptr, ks.cloud, parts, bound.ptr, fast=not args.ripple_combine)
@@ -290,7 +294,8 @@ def main():
             return "decrypted match bit of the last timed sharded match == plaintext rule (distance > bound)"
         workload = (f"slot-sharded Function_f: ONE {nslots} slots x {bitsize} bit match, slots partitioned over "
                     f"{nranks} {'ranks' if use_dist else 'logical ranks on one device'}, one gather of 24-ciphertext "
-                    f"partial sums, {'ripple-adder tree + bit-serial comparator' if args.ripple_combine else 'carry-save compressor + prefix adder + prefix comparator'} on rank 0")
+                    f"partial sums, {'ripple-adder tree + bit-serial comparator' if args.ripple_combine else 'carry-save compressor + prefix adder + prefix comparator'} on rank 0"
+                    + ("; per-rank phase: depth-optimised distance circuit (NOT the reference's gate sequence)" if args.fast_partial else ""))
         parallelism = f"{nslots} slots / {nranks} {('GPUs' if args.backend == 'nccl' else 'processes (gloo rehearsal)') if use_dist else 'logical ranks (1 GPU)'}"
         scaling = "strong"
     else:   # identify

@@ -60,6 +60,12 @@ const char *peba1_dist_last_error(void);
                                        (peba1_combine_and_compare_fast, ~20 levels) instead of the pairwise tree of the
                                        reference's ripple adders + its comparator (~290 levels at 8 ranks) */
 
+#define PEBA1_DIST_FAST_PARTIAL 2   /* every rank: its slots' squared distance from peba1_euclidean_distance_fast (borrow
+                                       chain, squarer, ONE carry-save column compressor, prefix adder: ~55 levels for 32
+                                       slots) instead of the reference's slot loop (peba1_partial_distance, ~183 levels).
+                                       NOT the reference's gate sequence: same decrypted partial sum.  Both flags
+                                       together are the latency form of the sharded match */
+
 /* Slot-sharded Function_f (Math.cpp:379-387 split as SURVEY.md 8e): a[i], b[i] (i < nslots_local) are THIS rank's
  * slots of the sample and the template, `bitsize` samples each; bound_match and result_b (3 * bitsize = 24 samples,
  * caller-allocated) are read / written on rank 0 only (may be NULL elsewhere).  result_b[0] = (distance > bound).
@@ -72,7 +78,7 @@ int peba1_sharded_function_f(Peba1Comm *comm, LweSample *result_b, LweSample *co
  * (24 * sample_words int32) in `packed` (host memory); phase 3 combines `nparts` packed partial sums (rank-major)
  * on the calling rank. */
 int peba1_sharded_partial_packed(LweSample *const *a, LweSample *const *b, int nslots_local, int bitsize,
-                                 const TFheGateBootstrappingCloudKeySet *ck, int32_t *packed);
+                                 const TFheGateBootstrappingCloudKeySet *ck, int32_t *packed, int flags);
 int peba1_sharded_combine_packed(LweSample *result_b, const int32_t *packed, int nparts, LweSample *bound_match,
                                  const TFheGateBootstrappingCloudKeySet *ck, int flags);
 

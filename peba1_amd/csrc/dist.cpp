@@ -171,11 +171,22 @@ void peba1_dist_destroy(Peba1Comm *c) {
     delete c;
 }
 
+// phase 1 of a rank: the reference's slot loop over its slots, or (PEBA1_DIST_FAST_PARTIAL) the depth-optimised
+// distance circuit -- its 24th bit is the carry the reference's 23-bit accumulator drops; both combines read 23 bits
+static void partial_phase(LweSample *partial, LweSample *const *a, LweSample *const *b, int nslots_local, int bitsize,
+                          const TFheGateBootstrappingCloudKeySet *ck, int flags) {
+    if (flags & PEBA1_DIST_FAST_PARTIAL) peba1_euclidean_distance_fast(partial, a, b, nslots_local, bitsize, ck);
+    else peba1_partial_distance(partial, a, b, nslots_local, bitsize, ck);
+}
+
 int peba1_sharded_partial_packed(LweSample *const *a, LweSample *const *b, int nslots_local, int bitsize,
-                                 const TFheGateBootstrappingCloudKeySet *ck, int32_t *packed) {
+                                 const TFheGateBootstrappingCloudKeySet *ck, int32_t *packed, int flags) {
+    if (!ck || !packed || nslots_local < 0 || (nslots_local > 0 && (!a || !b)) ||
+        ((flags & PEBA1_DIST_FAST_PARTIAL) && 3 * bitsize != PARTIAL_BITS))       // that circuit writes 3 * bitsize samples
+        return fail("peba1_sharded_partial_packed: bad arguments");
     LweSample *partial = new_gate_bootstrapping_ciphertext_array(PARTIAL_BITS, ck->params);
     if (!partial) return fail("allocation of the partial sum: " + provider_error());
-    peba1_partial_distance(partial, a, b, nslots_local, bitsize, ck);
+    partial_phase(partial, a, b, nslots_local, bitsize, ck, flags);
     const int rc = tfhe_hip_export_samples(partial, PARTIAL_BITS, ck->params, packed);
     delete_gate_bootstrapping_ciphertext_array(PARTIAL_BITS, partial);
     return rc == 0 ? 0 : fail("export of the partial sum: " + provider_error());
@@ -213,10 +224,12 @@ int peba1_sharded_function_f(Peba1Comm *c, LweSample *result_b, LweSample *const
                              const TFheGateBootstrappingCloudKeySet *ck, int flags) {
     if (!c || !ck || nslots_local < 0 || (nslots_local > 0 && (!a || !b)) || (c->rank == 0 && (!result_b || !bound_match)))
         return fail("peba1_sharded_function_f: bad arguments");
+    if ((flags & PEBA1_DIST_FAST_PARTIAL) && 3 * bitsize != PARTIAL_BITS)
+        return fail("peba1_sharded_function_f: PEBA1_DIST_FAST_PARTIAL needs bitsize 8 (a 24-sample partial sum)");
     // phase 1, every rank: the reference's slot loop over this rank's slots (recorded; the export runs it)
     LweSample *partial = new_gate_bootstrapping_ciphertext_array(PARTIAL_BITS, ck->params);
     if (!partial) return fail("allocation of the partial sum: " + provider_error());
-    peba1_partial_distance(partial, a, b, nslots_local, bitsize, ck);
+    partial_phase(partial, a, b, nslots_local, bitsize, ck, flags);
     // phase 2: ONE exchange, 24 ciphertexts per rank
     LweSample *parts = c->rank == 0 ? new_gate_bootstrapping_ciphertext_array(PARTIAL_BITS * c->world, ck->params) : nullptr;
     int rc = gather_samples(c, parts, partial, PARTIAL_BITS, ck->params);

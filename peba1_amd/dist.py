@@ -32,6 +32,7 @@ import numpy as np
 
 PARTIAL_BITS = 24
 FAST_COMBINE = 1
+FAST_PARTIAL = 2          # include/peba1_dist.h PEBA1_DIST_FAST_PARTIAL
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 DIST_PATH = os.path.join(_HERE, "libpeba1-dist.so")
@@ -62,7 +63,7 @@ def load():
         D.peba1_dist_world.argtypes = [V]
         D.peba1_dist_last_error.restype = C.c_char_p
         D.peba1_sharded_function_f.argtypes = [V, V, V, V, I, V, I, V, I]
-        D.peba1_sharded_partial_packed.argtypes = [V, V, I, I, V, V]
+        D.peba1_sharded_partial_packed.argtypes = [V, V, I, I, V, V, I]
         D.peba1_sharded_combine_packed.argtypes = [V, V, I, V, V, I]
         D.peba1_dist_gather_samples.argtypes = [V, V, V, I, V]
         _dlib = D
@@ -149,8 +150,12 @@ class Comm:
             self.ptr = None
 
 
+def _flags(fast_combine, fast_partial):
+    return (FAST_COMBINE if fast_combine else 0) | (FAST_PARTIAL if fast_partial else 0)
+
+
 def sharded_match(dist, torch, gate_lib, circ_lib, params_ptr, cloud_ptr, words, sample_slots, template_slots,
-                  bound_ptr, bitsize, device="cuda", fast_combine=False, partial_hook=None, comm=None):
+                  bound_ptr, bitsize, device="cuda", fast_combine=False, partial_hook=None, comm=None, fast_partial=False):
     """Slot-sharded Function_f across the ranks of `dist` (peba1_sharded_function_f).  `sample_slots` /
     `template_slots`: this rank's slot arrays (LweSample* each, `bitsize` samples).  Returns the 24-sample result
     array pointer on rank 0 (caller frees it with delete_gate_bootstrapping_ciphertext_array(24, p)), None
@@ -164,23 +169,26 @@ def sharded_match(dist, torch, gate_lib, circ_lib, params_ptr, cloud_ptr, words,
         if partial_hook is not None:
             packed = np.zeros(PARTIAL_BITS * words, dtype=np.int32)
             _check(D.peba1_sharded_partial_packed(_ptr_array(sample_slots), _ptr_array(template_slots), len(sample_slots),
-                                                  bitsize, cloud_ptr, packed.ctypes.data_as(C.c_void_p)), "partial sum")
+                                                  bitsize, cloud_ptr, packed.ctypes.data_as(C.c_void_p),
+                                                  _flags(False, fast_partial)), "partial sum")
             partial_hook(comm.rank, torch.from_numpy(packed))
         result_b = _new_array(gate_lib, PARTIAL_BITS, params_ptr) if comm.rank == 0 else None
         _check(D.peba1_sharded_function_f(comm.ptr, result_b, _ptr_array(sample_slots), _ptr_array(template_slots),
                                           len(sample_slots), bound_ptr, bitsize, cloud_ptr,
-                                          FAST_COMBINE if fast_combine else 0), "peba1_sharded_function_f")
+                                          _flags(fast_combine, fast_partial)), "peba1_sharded_function_f")
         return result_b
     finally:
         if own:
             comm.close()
 
 
-def local_partial_packed(cloud_ptr, words, sample_slots, template_slots, bitsize):
-    """Phase 1 of one (logical) rank: its packed partial sum, [24 * words] int32 (peba1_sharded_partial_packed)."""
+def local_partial_packed(cloud_ptr, words, sample_slots, template_slots, bitsize, fast=False):
+    """Phase 1 of one (logical) rank: its packed partial sum, [24 * words] int32 (peba1_sharded_partial_packed;
+    `fast`: the depth-optimised distance circuit, PEBA1_DIST_FAST_PARTIAL)."""
     packed = np.zeros(PARTIAL_BITS * words, dtype=np.int32)
     _check(load().peba1_sharded_partial_packed(_ptr_array(sample_slots), _ptr_array(template_slots), len(sample_slots),
-                                               bitsize, cloud_ptr, packed.ctypes.data_as(C.c_void_p)), "partial sum")
+                                               bitsize, cloud_ptr, packed.ctypes.data_as(C.c_void_p),
+                                               _flags(False, fast)), "partial sum")
     return packed
 
 
@@ -195,7 +203,7 @@ def combine_packed(gate_lib, params_ptr, cloud_ptr, parts, bound_ptr, fast=False
 
 
 def sharded_match_logical(torch, gate_lib, circ_lib, params_ptr, cloud_ptr, words, sample_slots, template_slots,
-                          bound_ptr, bitsize, world, device="cuda", partial_hook=None, fast_combine=False):
+                          bound_ptr, bitsize, world, device="cuda", partial_hook=None, fast_combine=False, fast_partial=False):
     """The same slot-sharded match with `world` LOGICAL ranks on one device: every rank's phase 1 runs in turn over
     its slot range of the full `sample_slots` / `template_slots` lists, the packed partial sums take the place of
     the gather's output, rank 0's phase 3 follows.  Gate for gate what `world` processes do; only the collective
@@ -204,7 +212,7 @@ def sharded_match_logical(torch, gate_lib, circ_lib, params_ptr, cloud_ptr, word
     parts = []
     for r in range(world):
         lo, hi = shard_slots(nslots, world, r)
-        mine = local_partial_packed(cloud_ptr, words, sample_slots[lo:hi], template_slots[lo:hi], bitsize)
+        mine = local_partial_packed(cloud_ptr, words, sample_slots[lo:hi], template_slots[lo:hi], bitsize, fast=fast_partial)
         if partial_hook is not None:
             partial_hook(r, torch.from_numpy(mine))
         parts.append(mine)

@@ -128,9 +128,88 @@ def slots256():
     print(json.dumps(out, indent=1))
 
 
+def latency_form():
+    """--latency-form: the sharded match with BOTH phases depth-optimised (PEBA1_DIST_FAST_PARTIAL | PEBA1_DIST_FAST_COMBINE:
+    peba1_euclidean_distance_fast per rank -> gather -> peba1_combine_and_compare_fast), 5 slots over 2 logical ranks
+    (3 + 2), on both sides of the threshold.  Writes tests/golden/sharded_match_latency_form_digest.json."""
+    threads = int(sys.argv[sys.argv.index("--threads") + 1]) if "--threads" in sys.argv else 4
+    template, probe, bits, world = [37, 200, 91, 5, 255], [40, 190, 92, 250, 1], 8, 2
+    d = sum((a - b) ** 2 for a, b in zip(probe, template))
+    subprocess.check_call(["make", "-s", "-C", os.path.join(ROOT, "oracle")])
+    B = C.CDLL(os.path.join(ROOT, "oracle", "liboracle_boots.so"))
+    V = C.c_void_p
+    B.orc_keygen.restype = V
+    B.orc_keygen.argtypes = [C.POINTER(O.OrcParams), C.c_uint64]
+    B.orc_boots_bind.argtypes = [V, C.c_uint64]
+    B.orc_boots_params.restype = V
+    B.orc_boots_cloud.restype = V
+    B.orc_boots_gate_count.restype = C.c_longlong
+    B.new_gate_bootstrapping_ciphertext_array.restype = V
+    B.new_gate_bootstrapping_ciphertext_array.argtypes = [C.c_int32, V]
+    B.bootsSymEncrypt.argtypes = [V, C.c_int32, V]
+    B.bootsSymDecrypt.argtypes = [V, V]
+    B.orc_boots_export.argtypes = [V, C.c_int32, V]
+    B.peba1_euclidean_distance_fast.argtypes = [V, V, V, C.c_int, C.c_int, V]
+    B.peba1_combine_and_compare_fast.argtypes = [V, V, C.c_int, V, V]
+    p = O.params("P128")
+    ks = B.orc_keygen(C.byref(p), KEY_SEED)
+    B.orc_boots_bind(ks, ENC_SEED + 77)
+    B.orc_boots_set_recording(threads)
+    params, cloud, SZ = B.orc_boots_params(), B.orc_boots_cloud(), 24
+
+    def enc(v, nb):
+        a = B.new_gate_bootstrapping_ciphertext_array(nb, params)
+        for i in range(nb):
+            B.bootsSymEncrypt(a + i * SZ, (v >> i) & 1, None)
+        return a
+
+    def words_of(arr, count):
+        w = np.zeros((count, p.n + 1), dtype=np.int32)
+        B.orc_boots_export(arr, count, w.ctypes.data_as(V))
+        return w
+
+    T, S = [], []
+    for t, s in zip(template, probe):                    # encryption order: per slot template then probe, then the two bounds
+        T.append(enc(t, bits))
+        S.append(enc(s, bits))
+    bounds = [enc(d - 1, 3 * bits), enc(d, 3 * bits)]
+    t0 = time.time()
+    partials = []
+    for r in range(world):
+        lo, hi = shard_slots(len(template), world, r)
+        part = B.new_gate_bootstrapping_ciphertext_array(24, params)
+        B.peba1_euclidean_distance_fast(part, (V * (hi - lo))(*S[lo:hi]), (V * (hi - lo))(*T[lo:hi]), hi - lo, bits, cloud)
+        partials.append(part)
+    results = []
+    for b in bounds:
+        rb = B.new_gate_bootstrapping_ciphertext_array(24, params)
+        B.peba1_combine_and_compare_fast(rb, (V * world)(*partials), world, b, cloud)
+        results.append(rb)
+    digests, values = [], []
+    for r, part in enumerate(partials):
+        w = words_of(part, 24)
+        digests.append(hashlib.sha256(w.tobytes()).hexdigest())
+        values.append(sum(B.bootsSymDecrypt(part + i * SZ, None) << i for i in range(24)))
+        lo, hi = shard_slots(len(template), world, r)
+        assert values[-1] == sum((a - b) ** 2 for a, b in zip(probe[lo:hi], template[lo:hi])), (r, values[-1])
+    bits_out = [int(B.bootsSymDecrypt(rb, None)) for rb in results]
+    assert bits_out == [1, 0], bits_out
+    out = {"params": "P128", "key_seed": KEY_SEED, "encrypt_seed": ENC_SEED + 77, "template": template, "probe": probe,
+           "bits": bits, "world": world, "distance": d, "bounds": [d - 1, d], "match_bits": bits_out,
+           "blind_rotates_recorded": int(B.orc_boots_gate_count()), "partial_values": values, "partial_sha256": digests,
+           "result_b_sha256": [hashlib.sha256(words_of(rb, 24).tobytes()).hexdigest() for rb in results],
+           "oracle_seconds": round(time.time() - t0, 1),
+           "circuit": "peba1_euclidean_distance_fast x 2 -> peba1_combine_and_compare_fast (bounds d-1, d)"}
+    with open(os.path.join(ROOT, "tests", "golden", "sharded_match_latency_form_digest.json"), "w") as f:
+        json.dump(out, f, indent=1)
+    print(json.dumps(out, indent=1))
+
+
 def main():
     if "--slots256" in sys.argv[1:]:
         return slots256()
+    if "--latency-form" in sys.argv[1:]:
+        return latency_form()
     subprocess.check_call(["make", "-s", "-C", os.path.join(ROOT, "oracle")])
     B = C.CDLL(os.path.join(ROOT, "oracle", "liboracle_boots.so"))
     V = C.c_void_p

@@ -44,9 +44,10 @@ int main(int argc, char **argv) {
         probe[i] = (91u * i + 5) % 256;
         d += ((long)probe[i] - (long)tmpl[i]) * ((long)probe[i] - (long)tmpl[i]);
     }
-    for (int pass = 0; pass < 4; ++pass) {
+    for (int pass = 0; pass < 6; ++pass) {
         const long bound = pass & 1 ? d : d - 1;               // both sides of the threshold
-        const int flags = pass & 2 ? PEBA1_DIST_FAST_COMBINE : 0;
+        // reference-order phases; fast combine; fast per-rank phase + fast combine (the latency form)
+        const int flags = pass < 2 ? 0 : pass < 4 ? PEBA1_DIST_FAST_COMBINE : PEBA1_DIST_FAST_COMBINE | PEBA1_DIST_FAST_PARTIAL;
         g_mail.assign((size_t)world, {});
         LweSample *result_b = new_gate_bootstrapping_ciphertext_array(24, pp);
         LweSample *enc_bound = encrypt_number((unsigned)bound, 24, pp, key);

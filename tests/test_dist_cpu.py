@@ -44,7 +44,8 @@ assert all(pd.shard_slots(n, w, r) == pd.shard_slots_c(n, w, r) for n in (1, 7, 
 S = [enc(probe[i], 8) for i in range(lo, hi)]
 T = [enc(tmpl[i], 8) for i in range(lo, hi)]
 bound = enc(int(os.environ["PEBA1_BOUND"]), 24)
-res = pd.sharded_match(dist, torch, gate, circ, params, cloud, 2, S, T, bound, 8, device="cpu")
+fast = os.environ.get("PEBA1_FAST") == "1"
+res = pd.sharded_match(dist, torch, gate, circ, params, cloud, 2, S, T, bound, 8, device="cpu", fast_combine=fast, fast_partial=fast)
 if rank == 0:
     bit = gate.bootsSymDecrypt(res, key)
     d = sum((a - b) ** 2 for a, b in zip(probe, tmpl))
@@ -79,11 +80,12 @@ def test_shard_slots_partition():
             assert max(sizes) - min(sizes) <= 1
 
 
-@pytest.mark.parametrize("world,case,bound", [(2, "genuine", 256), (2, "impostor", 256), (3, "genuine", 5)])
-def test_sharded_match_gloo(built, world, case, bound):
+@pytest.mark.parametrize("world,case,bound,fast", [(2, "genuine", 256, 0), (2, "impostor", 256, 0), (3, "genuine", 5, 0),
+                                                   (3, "impostor", 256, 1)])
+def test_sharded_match_gloo(built, world, case, bound, fast):
     env = dict(os.environ, PEBA1_ROOT=ROOT, PEBA1_TMP=built, PEBA1_SLOTS="12", PEBA1_CASE=case,
-               PEBA1_BOUND=str(bound), MASTER_ADDR="127.0.0.1")
-    port = 29600 + world * 7 + (1 if case == "impostor" else 0)
+               PEBA1_BOUND=str(bound), PEBA1_FAST=str(fast), MASTER_ADDR="127.0.0.1")
+    port = 29600 + world * 7 + (1 if case == "impostor" else 0) + 3 * fast
     out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={world}",
                           "--master-addr", "127.0.0.1", "--master-port", str(port), built + "/worker.py"],
                          env=env, capture_output=True, text=True, timeout=300)
@@ -129,6 +131,12 @@ for world in (1, 2, 3, 8, 12):            # 12 > slots: some ranks hold no slot
         fast = pd.sharded_match_logical(torch, gate, circ, params, cloud, 2, S, T, enc(bound, 24), 8, world, device="cpu",
                                         fast_combine=True)
         assert gate.bootsSymDecrypt(fast, key) == (1 if d > bound else 0), ("fast combine", world, bound)
+        both = pd.sharded_match_logical(torch, gate, circ, params, cloud, 2, S, T, enc(bound, 24), 8, world, device="cpu",
+                                        fast_combine=True, fast_partial=True)       # the latency form: both phases depth-optimised
+        assert gate.bootsSymDecrypt(both, key) == (1 if d > bound else 0), ("fast partial + combine", world, bound)
+        mixed = pd.sharded_match_logical(torch, gate, circ, params, cloud, 2, S, T, enc(bound, 24), 8, world, device="cpu",
+                                         fast_partial=True)                           # fast partial sums into the ripple combine
+        assert gate.bootsSymDecrypt(mixed, key) == (1 if d > bound else 0), ("fast partial, ripple combine", world, bound)
     assert seen == list(range(world)) * 2
 print("LOGICAL-OK")
 '''

@@ -64,6 +64,114 @@ def test_sharded_dag_ciphertexts_match_oracle_digest(p128_keys):
     L.delete_gate_bootstrapping_ciphertext_array(24, res_ls)
 
 
+def test_latency_form_of_the_sharded_match_ciphertexts_match_oracle_digest(p128_keys):
+    """PEBA1_DIST_FAST_PARTIAL | PEBA1_DIST_FAST_COMBINE: every rank's slots through the depth-optimised distance circuit,
+    the gather, the depth-optimised combine -- 5 slots over 2 logical ranks (3 + 2), both sides of the threshold.  Each
+    rank's packed partial sum and both 24-ciphertext results hash to what the CPU oracle produced for the same DAG
+    (tests/golden/make_sharded_digest.py --latency-form)."""
+    import torch
+    from peba1_amd import api, circuits, lib
+    from peba1_amd import dist as pd
+    pp, ks, _ = p128_keys
+    with open(os.path.join(ROOT, "tests", "golden", "sharded_match_latency_form_digest.json")) as f:
+        g = json.load(f)
+    assert g["key_seed"] == 0x5EBA2
+    L = lib.load()
+    L.tfhe_hip_set_encrypt_seed(g["encrypt_seed"])
+    bits, world = g["bits"], g["world"]
+    T, S = [], []
+    for t, s in zip(g["template"], g["probe"]):          # encryption order is part of the fixture
+        T.append(circuits.encrypt_number(pp, t, bits, ks))
+        S.append(circuits.encrypt_number(pp, s, bits, ks))
+    bounds = [circuits.encrypt_number(pp, b, 3 * bits, ks) for b in g["bounds"]]
+    api.set_deferred(True)
+    try:
+        parts = []
+        for r in range(world):
+            lo, hi = pd.shard_slots(len(T), world, r)
+            parts.append(pd.local_partial_packed(ks.cloud, pp.words, [a.ptr for a in S[lo:hi]], [a.ptr for a in T[lo:hi]], bits, fast=True))
+        results = [pd.combine_packed(L, pp.ptr, ks.cloud, parts, b.ptr, fast=True) for b in bounds]
+        api.flush()
+    finally:
+        api.set_deferred(False)
+    assert [hashlib.sha256(p.tobytes()).hexdigest() for p in parts] == g["partial_sha256"]
+    tmp = api.CiphertextArray(pp, 24)
+    for r in range(world):
+        assert L.tfhe_hip_import_samples(tmp.ptr, 24, pp.ptr, np.ascontiguousarray(parts[r]).ctypes.data_as(lib.I32P)) == 0
+        assert circuits.decrypt_number(tmp, ks) == g["partial_values"][r], r
+    for res, want_sha, want_bit in zip(results, g["result_b_sha256"], g["match_bits"]):
+        ls = C.cast(res, lib.LS)
+        words = np.zeros((24, pp.words), dtype=np.int32)
+        assert L.tfhe_hip_export_samples(ls, 24, pp.ptr, words.ctypes.data_as(lib.I32P)) == 0
+        assert hashlib.sha256(words.tobytes()).hexdigest() == want_sha
+        assert L.bootsSymDecrypt(ls, ks.ptr) == want_bit
+        L.delete_gate_bootstrapping_ciphertext_array(24, ls)
+
+
+def test_cfg3_256_slots_over_8_ranks_ciphertexts_match_oracle_digest(p128_keys):
+    """BASELINE configs[2] at its own size, word for word: 256 slots x 8 bit (uniform bytes from the fixture's LCG)
+    over 8 logical ranks of 32 slots.  Each rank's packed 24-ciphertext partial sum -- what crosses the exchange --
+    and the 24 outputs of rank 0's combine, in both forms (ripple tree and carry-save / prefix), hash to what the CPU
+    oracle produced evaluating the same 432k-rotation DAG (tests/golden/make_sharded_digest.py --slots256; the
+    bound sits just under the distance, so the comparator's whole chain decides the bit)."""
+    import torch
+    from peba1_amd import api, circuits, lib
+    from peba1_amd import dist as pd
+
+    def synthetic_bytes(n, seed):                        # the generator's LCG (make_sharded_digest.synthetic_bytes)
+        x, out = seed, []
+        for _ in range(n):
+            x = (x * 1103515245 + 12345) % (1 << 31)
+            out.append((x >> 16) & 255)
+        return out
+
+    pp, ks, _ = p128_keys
+    fixture = os.path.join(ROOT, "tests", "golden", "sharded_match_256_digest.json")
+    if not os.path.exists(fixture):
+        pytest.skip("fixture not generated yet (make_sharded_digest.py --slots256: about two CPU-hours)")
+    with open(fixture) as f:
+        g = json.load(f)
+    assert g["key_seed"] == 0x5EBA2 and g["world"] == 8 and g["nslots"] == 256
+    L = lib.load()
+    L.tfhe_hip_set_encrypt_seed(g["encrypt_seed"])
+    bits = g["bits"]
+    template = synthetic_bytes(g["nslots"], g["template_lcg_seed"])
+    probe = [v or 1 for v in synthetic_bytes(g["nslots"], g["probe_lcg_seed"])]
+    assert sum((a - b) ** 2 for a, b in zip(probe, template)) == g["distance"] == g["bound"] + 1
+    T, S = [], []
+    for t, s in zip(template, probe):                    # encryption order is part of the fixture
+        T.append(circuits.encrypt_number(pp, t, bits, ks))
+        S.append(circuits.encrypt_number(pp, s, bits, ks))
+    bound = circuits.encrypt_number(pp, g["bound"], 3 * bits, ks)
+    parts = {}
+    api.reset_stats()
+    api.set_deferred(True)
+    try:
+        res = pd.sharded_match_logical(torch, L, circuits.load(), pp.ptr, ks.cloud, pp.words,
+                                       [a.ptr for a in S], [a.ptr for a in T], bound.ptr, bits, g["world"],
+                                       device="cuda", partial_hook=lambda r, t: parts.__setitem__(r, t.numpy().copy()))
+        api.flush()
+        fast = pd.combine_packed(L, pp.ptr, ks.cloud, [parts[r] for r in range(g["world"])], bound.ptr, fast=True)
+        api.flush()
+    finally:
+        api.set_deferred(False)
+    st = api.stats()
+    assert st["blind_rotates"] <= g["blind_rotates_recorded"]
+    assert [hashlib.sha256(parts[r].tobytes()).hexdigest() for r in range(g["world"])] == g["partial_sha256"]
+    tmp = api.CiphertextArray(pp, 24)
+    for r in range(g["world"]):
+        host = np.ascontiguousarray(parts[r])
+        assert L.tfhe_hip_import_samples(tmp.ptr, 24, pp.ptr, host.ctypes.data_as(lib.I32P)) == 0
+        assert circuits.decrypt_number(tmp, ks) == g["partial_values"][r], r
+    for ptr, key in ((res, "result_b_sha256"), (fast, "result_b_fast_sha256")):
+        ls = C.cast(ptr, lib.LS)
+        words = np.zeros((24, pp.words), dtype=np.int32)
+        assert L.tfhe_hip_export_samples(ls, 24, pp.ptr, words.ctypes.data_as(lib.I32P)) == 0
+        assert hashlib.sha256(words.tobytes()).hexdigest() == g[key], key
+        assert L.bootsSymDecrypt(ls, ks.ptr) == g["match_bit"] == 1
+        L.delete_gate_bootstrapping_ciphertext_array(24, ls)
+
+
 @pytest.mark.parametrize("world", [2, 4, 8])
 def test_cfg3_256_slot_match_sharded_over_logical_ranks(p128_keys, world):
     """BASELINE configs[2] at size: 256 slots x 8 bit, uniform bytes, `world` logical ranks of
