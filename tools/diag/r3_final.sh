@@ -8,6 +8,7 @@ if [ "${1:-all}" != "bench" ]; then
   echo "pytest rc $rc"; tail -25 $OUT/tests.log
   [ $rc -eq 0 ] || exit $rc
 fi
+timeout -k 10 300 python -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')" 2>&1 | tail -2 || exit 1
 t0=$(date +%s)
 timeout -k 10 600 python bench.py > $OUT/bench.json 2> $OUT/bench.err || { tail -20 $OUT/bench.err; exit 1; }
 echo "bench.py (no flags) took $(( $(date +%s) - t0 )) s"
