@@ -54,8 +54,9 @@ void SlotPool::grow(size_t new_cap) {
     int32_t *fresh = nullptr;
     hip_check(hipMalloc(reinterpret_cast<void **>(&fresh), new_cap * (size_t)stride_ * sizeof(int32_t)), "hipMalloc(slot pool)");
     if (data_) {
-        // growth happens while recording (host side, nothing of this library in flight: a flush returns synchronised),
-        // but a caller's own stream may still read an exported buffer: wait for the device once, copy, release
+        // growth happens while recording (host side).  A pipelined flush may still be in flight -- its launches carry
+        // the old pointer -- and a caller's own stream may still read an exported buffer: wait for the whole device
+        // once (every launch enqueued so far has then finished with the old buffer), copy, release
         hip_check(hipDeviceSynchronize(), "sync before pool growth");
         hip_check(hipMemcpy(fresh, data_, cap_ * (size_t)stride_ * sizeof(int32_t), hipMemcpyDeviceToDevice), "copy slot pool");
         (void)hipFree(data_);
