@@ -126,10 +126,7 @@ def test_cfg3_256_slots_over_8_ranks_ciphertexts_match_oracle_digest(p128_keys):
         return out
 
     pp, ks, _ = p128_keys
-    fixture = os.path.join(ROOT, "tests", "golden", "sharded_match_256_digest.json")
-    if not os.path.exists(fixture):
-        pytest.skip("fixture not generated yet (make_sharded_digest.py --slots256: about two CPU-hours)")
-    with open(fixture) as f:
+    with open(os.path.join(ROOT, "tests", "golden", "sharded_match_256_digest.json")) as f:
         g = json.load(f)
     assert g["key_seed"] == 0x5EBA2 and g["world"] == 8 and g["nslots"] == 256
     L = lib.load()
