@@ -393,6 +393,15 @@ void Engine::read_slots_packed(SlotPool *pool, const int32_t *slots, int count, 
     if (wait || !on_device) hip_check(hipStreamSynchronize(stream_), "gather slots");
 }
 
+hipEvent_t Engine::next_timing_event() {
+    if (timing_used_ == timing_events_.size()) {
+        hipEvent_t e;
+        hip_check(hipEventCreate(&e), "timing event");
+        timing_events_.push_back(e);
+    }
+    return timing_events_[timing_used_++];
+}
+
 bool Engine::launch_br(const DeviceKeyImage *key, const int32_t *pool, const RotDesc *rots, int count, int32_t *u_buf,
                        int32_t *acc_dbg, hipStream_t stream, int wave_prio) {
     if (!stream) stream = stream_;
@@ -461,6 +470,8 @@ bool Engine::launch_br(const DeviceKeyImage *key, const int32_t *pool, const Rot
     if (br_tail8 && count > round && tail > 0 && tail <= std::min(br8_max_rotations, cu_count_) && dp.N == 1024 && dp.l >= 2 &&
         !acc_dbg && !wg_times_dbg_ && key->form_ok[BR_FORM_WAVE8][tables]) {
         launch_blind_rotate4(stream, dp, key->key, pool, rots, count - tail, u_buf, nullptr);
+        tail_count_ = tail;
+        if (kernel_timing) { tail_event_ = next_timing_event(); hip_check(hipEventRecord(tail_event_, stream), "event"); }
         DevParams dp8 = dp;                                   // as a narrow launch gets them: no turn-taking
         dp8.fair_shift = 0;
         dp8.cu_arrivals = nullptr;
@@ -561,15 +572,8 @@ void Engine::execute(const DeviceKeyImage *key, SlotPool *pool, LevelPlan &&plan
         hip_check(hipStreamWaitEvent(lane_stream_[1], order_events_[ngroups], 0), "wait upload");
     }
 #endif
-    size_t nt = 0;                                       // timing events used: base, then 3 per group
-    auto timing_event = [&]() {
-        if (nt == timing_events_.size()) {
-            hipEvent_t e;
-            hip_check(hipEventCreate(&e), "timing event");
-            timing_events_.push_back(e);
-        }
-        return timing_events_[nt++];
-    };
+    timing_used_ = 0;                                    // timing events used: base, then 3 (4 with a tail launch) per group
+    auto timing_event = [&]() { return next_timing_event(); };
     std::vector<Timed> &timed = flight_timed_;
     timed.clear();
     hipEvent_t &base = flight_base_;
@@ -605,8 +609,16 @@ void Engine::execute(const DeviceKeyImage *key, SlotPool *pool, LevelPlan &&plan
             Timed t{nullptr, nullptr, nullptr, false, nrot};
             if (kernel_timing) { t.e0 = timing_event(); hip_check(hipEventRecord(t.e0, st), "event"); }
             if (nrot) {
+                tail_event_ = nullptr;
+                tail_count_ = 0;
                 t.wide8 = launch_br(key, pool->data(), drots + plan.rot_off[gg], nrot, u_buf[s], nullptr, st, K > 1 && s == 0 ? lane_prio : 0);
                 if (t.wide8) { ++stats.br8_launches; stats.br8_rotations += (uint64_t)nrot; }
+                if (tail_count_) {                       // a second launch, of the 8-wave kernel
+                    t.em = tail_event_;
+                    t.tail = tail_count_;
+                    ++stats.br8_launches; ++stats.br_launches;
+                    stats.br8_rotations += (uint64_t)tail_count_;
+                }
             }
             if (kernel_timing) { t.e1 = timing_event(); hip_check(hipEventRecord(t.e1, st), "event"); }
             if (nks) launch_ks(key, u_buf[s], dks + plan.ks_off[gg], nks, pool->data(), st, s);
@@ -665,6 +677,11 @@ void Engine::wait_flight() {
             if (tf) std::fprintf(tf, "%d %.4f %.4f %.4f %d\n", t.nrot, a, b - a, c - b, t.wide8 ? 1 : 0);
             stats.ms_blind_rotate += b - a;
             if (t.wide8) stats.ms_blind_rotate8 += b - a;
+            if (t.em) {
+                float m = 0;
+                hip_check(hipEventElapsedTime(&m, base, t.em), "elapsed");
+                stats.ms_blind_rotate8 += b - m;
+            }
             stats.ms_keyswitch += c - b;
             if (b > a) br.emplace_back(a, b);
         }

@@ -177,7 +177,11 @@ public:
 private:
     Engine() = default;
     void *scratch(size_t idx, size_t bytes);   // grow-only device scratch buffers
-    struct Timed { hipEvent_t e0, e1, e2; bool wide8; int nrot; };
+    // em / tail: a level whose last round went to the 8-wave form as a second launch (br_tail8) -- the event between
+    // the two launches and the rotations of the second, so that each kernel's time and count stay its own
+    struct Timed { hipEvent_t e0, e1, e2; bool wide8; int nrot; hipEvent_t em = nullptr; int tail = 0; };
+    hipEvent_t tail_event_ = nullptr;                   // set by launch_br when it split a level (kernel_timing only)
+    int tail_count_ = 0;
     std::vector<Timed> flight_timed_;
     hipEvent_t flight_base_ = nullptr;
     LevelPlan flight_plan_;
@@ -196,6 +200,8 @@ private:
     unsigned long long *wg_times_dbg_ = nullptr;        // set by the workgroup-time probe only
     hipStream_t lane_stream_[2] = {nullptr, nullptr};   // lane 0 = stream_, lane 1 created on first use
     std::vector<hipEvent_t> order_events_;              // cross-lane ordering, no timing
+    size_t timing_used_ = 0;
+    hipEvent_t next_timing_event();
     std::vector<hipEvent_t> timing_events_;             // kernel_timing: 3 per (level, lane) + 1 base
     hipEvent_t ev_[3] = {nullptr, nullptr, nullptr};
     std::vector<SlotPool *> pools_;
