@@ -444,3 +444,52 @@ def test_asynchronous_flush_pipelines_circuits_with_the_same_results(p128_keys):
         results.append(words)
         assert circuits.decrypt_number(prods[0], ks, 23) == 11 * 13
     assert (results[0] == results[1]).all()
+
+
+def test_concurrent_host_threads_share_the_recorder(p128_keys):
+    """Four host threads call the library at once (ctypes releases the GIL): each encrypts its own operands, records
+    16-bit Hamming matches in default (recording) mode and decrypts -- a decrypt in one thread flushes whatever the
+    others have recorded so far.  The recorder, the slot pool and the flush are serialised by the library's lock;
+    every thread must read its own plaintext results.  (The reference is single-threaded; a server matching several
+    probes from worker threads is not.)"""
+    import threading
+    from peba1_amd import api, circuits
+    pp, ks, _ = p128_keys
+    errors, done = [], []
+    w = circuits.hamming_count_bits(16)
+
+    def worker(t):
+        try:
+            for it in range(3):
+                a, b = (0x1234 * (t + 1) + 77 * it) & 0xFFFF, (0xBEEF ^ (0x0F0F * t) ^ (it << 7)) & 0xFFFF
+                hd = bin(a ^ b).count("1")
+                A = circuits.encrypt_number(pp, a, 16, ks)
+                B = circuits.encrypt_number(pp, b, 16, ks)
+                cnt = api.CiphertextArray(pp, w)
+                circuits.hamming_distance(cnt, A, B, 16, ks)
+                outs = []
+                for bound in (hd - 1, hd):
+                    rb = api.CiphertextArray(pp, w)
+                    circuits.hamming_match(rb, A, B, 16, circuits.encrypt_number(pp, max(bound, 0), w, ks), ks)
+                    outs.append((max(bound, 0), rb))
+                got = circuits.decrypt_number(cnt, ks)                      # observes: flushes
+                assert got == hd, (t, it, got, hd)
+                for bound, rb in outs:
+                    assert rb.decrypt(ks)[0] == (1 if hd > bound else 0), (t, it, bound)
+            done.append(t)
+        except BaseException as e:      # noqa: BLE001 -- reported by the main thread
+            errors.append((t, repr(e)))
+
+    api.set_deferred(True)
+    try:
+        threads = [threading.Thread(target=worker, args=(t,)) for t in range(4)]
+        for th in threads:
+            th.start()
+        for th in threads:
+            th.join(timeout=300)
+        assert not any(th.is_alive() for th in threads), "a thread is stuck"
+        api.flush()
+    finally:
+        api.set_deferred(False)
+    assert not errors, errors
+    assert sorted(done) == [0, 1, 2, 3]
