@@ -87,6 +87,38 @@ int peba1_sharded_combine_packed(LweSample *result_b, const int32_t *packed, int
 int peba1_dist_gather_samples(Peba1Comm *comm, LweSample *all, const LweSample *mine, int count,
                               const TFheGateBootstrappingParameterSet *params);
 
+/* 1-to-N identification (BASELINE configs[3]): the loop a PEBA1 server puts around Function_f, one call per enrolled
+ * client (/root/reference/src/main.cpp:533-542), for THIS rank's share of the gallery -- with no Python in the process.
+ *   probe: nslots slot arrays of `bitsize` samples; templates: m_local * nslots slot arrays, template m at
+ *   templates[m * nslots .. (m + 1) * nslots); bound_match: 3 * bitsize samples.
+ *   mine (m_local samples, caller-allocated): mine[m] = Enc(distance(probe, template m) > bound), the reference's polarity.
+ *   all (rank 0: world * m_local samples, rank-major; NULL elsewhere): the match bits of every rank, brought over by
+ *   ONE gather at the end -- the matches themselves are independent, there is no data-path collective.
+ *   comm: NULL = single process (no gather).  Every rank passes the same m_local.
+ * `group` matches are recorded per flush (>= 1; 4 is a good value: the narrow tail levels of one match are filled by the
+ * others, and device memory is bounded by the group, not by m_local); with libtfhe-hip the flushes are pipelined
+ * (tfhe_hip_flush_async): the next group is recorded while the device runs the one before.
+ * flags: PEBA1_IDENTIFY_FAST = the depth-optimised circuit (peba1_function_f_fast; NOT the reference's gate sequence).
+ * Collective when comm has more than one rank.  Returns 0, or -1 with peba1_dist_last_error(). */
+#define PEBA1_IDENTIFY_FAST 1
+int peba1_identify(Peba1Comm *comm, LweSample *all, LweSample *mine, LweSample *const *probe,
+                   LweSample *const *templates, int m_local, int nslots, LweSample *bound_match, int bitsize,
+                   const TFheGateBootstrappingCloudKeySet *ck, int group, int flags);
+
+/* ---- failure containment (every collective of this library) ----
+ * A rank that fails locally (an allocation, the export that runs its pending gates) still ENTERS the exchange, carrying a
+ * status word, so that no rank is left inside a collective:
+ *   RCCL: the status words are all-gathered first (one int per rank, on the provider's stream); if any rank reports a
+ *     failure EVERY rank skips the data gather and returns -1, its message naming the failed rank;
+ *   host transport: the status word rides in front of each rank's payload; rank 0 returns -1 naming the failed rank, the
+ *     failed rank returns -1 with its own message (a gather cannot tell the other ranks).
+ * Every host wait of a communicator of more than one rank is bounded: PEBA1_DIST_TIMEOUT_S (default 600; 0 = unbounded)
+ * or peba1_dist_set_timeout().  When a wait expires -- a peer never arrived -- the process prints which wait, on which
+ * rank, and exits with TFHE_HIP_EXIT_DEADLINE (tfhe_hip.h): non-zero, no retry, no re-exec. */
+int peba1_dist_set_timeout(Peba1Comm *comm, double seconds);
+/* test hook: the next `count` collectives of this rank report a local failure instead of contributing */
+void peba1_dist_inject_failure(Peba1Comm *comm, int count);
+
 #ifdef __cplusplus
 }
 #endif

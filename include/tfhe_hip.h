@@ -93,6 +93,9 @@ int tfhe_hip_import_samples_device_async(LweSample *samples, int32_t count,
                                          const TFheGateBootstrappingParameterSet *params, const void *device_words);
 /* the hipStream_t every kernel and transfer of this library runs on (created non-blocking, highest priority) */
 void *tfhe_hip_stream(void);
+/* Every read of a sample by the host (bootsSymDecrypt, tfhe_hip_sync_samples, the exports) is ordered behind whatever
+ * was enqueued on that stream before it -- a flush in flight, a stream-ordered import behind a collective -- and
+ * tfhe_hip_wait() returns only when all of it has completed. */
 /* refresh the host mirror (a, b) of samples whose value lives on the device */
 int tfhe_hip_sync_samples(const LweSample *samples, int32_t count);
 
@@ -117,6 +120,19 @@ int tfhe_hip_flush(void);   /* returns the number of levels executed, <0 on erro
  * tfhe_hip_wait() waits explicitly.  tfhe_hip_flush() is the synchronous form and also completes a flush in flight. */
 int tfhe_hip_flush_async(void);
 int tfhe_hip_wait(void);
+
+/* ---- bounded host waits (multi-process runs) ----
+ * "sync_deadline_ms" (tfhe_hip_set_tuning; env TFHE_HIP_SYNC_DEADLINE_MS; default 0 = wait for ever): when > 0, no
+ * host wait on the library's stream lasts longer than this.  A wait that does -- a collective whose peer never
+ * arrived, a kernel that never ends -- prints what was waited for and the label below on stderr and ends the process
+ * with exit code TFHE_HIP_EXIT_DEADLINE (_exit: no retry, no re-exec -- the state of the device is unknown).
+ * libpeba1-dist sets it for every communicator of more than one rank (PEBA1_DIST_TIMEOUT_S, default 600 s). */
+#define TFHE_HIP_EXIT_DEADLINE 86
+/* waits (bounded as above) until everything enqueued on tfhe_hip_stream() so far -- by this library or by the caller
+ * (a collective) -- has completed; also completes a flush in flight.  Returns 0. */
+int tfhe_hip_stream_sync(void);
+/* who is waiting, for that message ("rank 3 of 8: gather of the partial sums"); copied, at most 127 characters */
+void tfhe_hip_set_diag_label(const char *label);
 
 /* result[i] = gate(a[i], b[i]) for i < count, one batched launch */
 int tfhe_hip_gate_batch(int gate, LweSample *result, const LweSample *a, const LweSample *b,
@@ -153,6 +169,7 @@ int tfhe_hip_gate_batch(int gate, LweSample *result, const LweSample *a, const L
  * observable changes; 0 = evaluate every recorded gate.
  * "balance_levels": 1 (default) = slack-aware level filling at flush, 0 = plain ASAP
  * levels.
+ * "sync_deadline_ms": see "bounded host waits" above.
  * Only in a library built with -DTFHE_HIP_EXPERIMENTAL (tfhe_hip_has_experimental() == 1; build.sh leaves it
  * off: both executors measured slower than per-level launches):
  * "dataflow": 0 (default) = one blind-rotate + one key-switch launch per level; 1 (env

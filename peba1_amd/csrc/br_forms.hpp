@@ -57,7 +57,8 @@ inline bool br_form_admissible(int form, int N, int l, int Bgbit, int tables) {
     if (!logn) return false;
     const double digit = (double)(1 << (Bgbit - 1)) / kP;              // |d| / P
     const double entry = 0.5 + (double)(1 << (Bgbit - 1)) * kQ / kP;   // |d w mod P| / P, Montgomery output
-    const bool tab_ok = tables != 0 && Bgbit <= 7 && 32 - l * Bgbit >= 2;
+    // (the lowest digit field must start at bit 3 or higher: ntt_wave.hpp DIGIT_TAB_MIN_SHIFT, 8-byte table entries)
+    const bool tab_ok = tables != 0 && Bgbit <= 7 && 32 - l * Bgbit >= 3;
     double F;                                                          // forward outputs / P
     if (form == BR_FORM_SPLIT) {
         // stage 0 on digits (x = d_lo +- W d_hi), then an (N/2)-point transform

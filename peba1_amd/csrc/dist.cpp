@@ -8,6 +8,7 @@
 #include <rccl/rccl.h>
 
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <string>
 #include <vector>
@@ -20,6 +21,13 @@ __attribute__((weak)) int tfhe_hip_export_samples_device_async(const LweSample *
 __attribute__((weak)) int tfhe_hip_import_samples_device_async(LweSample *, int32_t, const TFheGateBootstrappingParameterSet *, const void *);
 __attribute__((weak)) void *tfhe_hip_stream(void);
 __attribute__((weak)) const char *tfhe_hip_last_error(void);
+__attribute__((weak)) int tfhe_hip_stream_sync(void);
+__attribute__((weak)) int tfhe_hip_set_tuning(const char *, int64_t);
+__attribute__((weak)) void tfhe_hip_set_diag_label(const char *);
+__attribute__((weak)) int tfhe_hip_flush_async(void);
+__attribute__((weak)) int tfhe_hip_wait(void);
+__attribute__((weak)) void tfhe_hip_set_deferred(int);
+__attribute__((weak)) int tfhe_hip_get_deferred(void);
 }
 
 namespace {
@@ -36,6 +44,7 @@ struct Rccl {
     ncclResult_t (*CommInitRank)(ncclComm_t *, int, ncclUniqueId, int) = nullptr;
     ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
     ncclResult_t (*Gather)(const void *, void *, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
+    ncclResult_t (*AllGather)(const void *, void *, size_t, ncclDataType_t, ncclComm_t, hipStream_t) = nullptr;
     const char *(*GetErrorString)(ncclResult_t) = nullptr;
     bool load() {
         if (handle) return true;
@@ -48,8 +57,9 @@ struct Rccl {
         CommInitRank = reinterpret_cast<decltype(CommInitRank)>(dlsym(handle, "ncclCommInitRank"));
         CommDestroy = reinterpret_cast<decltype(CommDestroy)>(dlsym(handle, "ncclCommDestroy"));
         Gather = reinterpret_cast<decltype(Gather)>(dlsym(handle, "ncclGather"));
+        AllGather = reinterpret_cast<decltype(AllGather)>(dlsym(handle, "ncclAllGather"));
         GetErrorString = reinterpret_cast<decltype(GetErrorString)>(dlsym(handle, "ncclGetErrorString"));
-        return GetUniqueId && CommInitRank && CommDestroy && Gather && GetErrorString;
+        return GetUniqueId && CommInitRank && CommDestroy && Gather && AllGather && GetErrorString;
     }
 };
 Rccl g_rccl;
@@ -65,42 +75,116 @@ struct Peba1Comm {
     // grow-only device buffers of the RCCL path: they must outlive the stream operations that use them
     int32_t *send = nullptr, *recv = nullptr;
     size_t send_words = 0, recv_words = 0;
+    // status exchange of the RCCL path: [0] this rank's word, [1 .. world] every rank's (device, and a pinned host mirror)
+    int32_t *st_dev = nullptr, *st_host = nullptr;
+    int inject_failures = 0;             // test hook (peba1_dist_inject_failure): local failures still to report
 };
 
 namespace {
 
+// every host wait of this library goes through the provider's bounded wait (tfhe_hip.h "bounded host waits")
+void stream_sync() {
+    if (tfhe_hip_stream_sync) (void)tfhe_hip_stream_sync();
+    else if (tfhe_hip_stream) (void)hipStreamSynchronize(static_cast<hipStream_t>(tfhe_hip_stream()));
+}
+
 bool device_buffer(int32_t *&buf, size_t &have, size_t want) {
     if (have >= want) return true;
     // the stream may still be using the old buffer
-    if (buf) { (void)hipStreamSynchronize(static_cast<hipStream_t>(tfhe_hip_stream())); (void)hipFree(buf); buf = nullptr; have = 0; }
+    if (buf) { stream_sync(); (void)hipFree(buf); buf = nullptr; have = 0; }
     if (hipMalloc(reinterpret_cast<void **>(&buf), want * sizeof(int32_t)) != hipSuccess) return false;
     have = want;
     return true;
 }
 
+// A communicator of several ranks bounds every host wait of the provider (a peer that never arrives must end the job
+// with a message, not with the scheduler's time limit) and says who is waiting.
+void arm_deadline(Peba1Comm *c) {
+    if (c->world <= 1) return;
+    long long secs = 600;
+    if (const char *env = std::getenv("PEBA1_DIST_TIMEOUT_S")) secs = std::atoll(env);
+    if (tfhe_hip_set_tuning && secs > 0) (void)tfhe_hip_set_tuning("sync_deadline_ms", (int64_t)secs * 1000);
+    if (tfhe_hip_set_diag_label) {
+        const std::string label = "rank " + std::to_string(c->rank) + " of " + std::to_string(c->world) + " (libpeba1-dist)";
+        tfhe_hip_set_diag_label(label.c_str());
+    }
+}
+
+// Failure containment around a collective: a rank that failed locally -- an allocation,
+// the export that runs its pending gates -- must not leave the others inside the collective.  Every rank therefore
+// ENTERS the exchange whatever happened to it, carrying a status word:
+//   RCCL: one ncclAllGather of the status words on the provider's stream, read back by every rank (a bounded host
+//     wait); if any rank reports a failure, every rank skips the data gather and returns -1 naming that rank;
+//   host transport (gather only): the status word rides in front of the payload; rank 0 checks all of them and
+//     returns -1 naming the rank, the failed rank returns -1 with its own message.
+// Returns the first failed rank, -1 if none, -2 if the exchange itself failed (g_error set).
+int exchange_status_rccl(Peba1Comm *c, int local) {
+    hipStream_t stream = static_cast<hipStream_t>(tfhe_hip_stream());
+    if (!c->st_dev) {
+        if (hipMalloc(reinterpret_cast<void **>(&c->st_dev), (size_t)(c->world + 1) * sizeof(int32_t)) != hipSuccess ||
+            hipHostMalloc(reinterpret_cast<void **>(&c->st_host), (size_t)(c->world + 1) * sizeof(int32_t), hipHostMallocDefault) != hipSuccess) {
+            // cannot even report: the peers run into their deadline with a message of their own
+            fail("allocation of the status words failed");
+            return -2;
+        }
+    }
+    c->st_host[0] = local;
+    for (int r = 0; r < c->world; ++r) c->st_host[1 + r] = 0;
+    if (hipMemcpyAsync(c->st_dev, c->st_host, sizeof(int32_t), hipMemcpyHostToDevice, stream) != hipSuccess) { fail("upload of the status word failed"); return -2; }
+    const ncclResult_t r = g_rccl.AllGather(c->st_dev, c->st_dev + 1, 1, ncclInt32, c->nccl, stream);
+    if (r != ncclSuccess) { fail(std::string("ncclAllGather of the status words: ") + g_rccl.GetErrorString(r)); return -2; }
+    if (hipMemcpyAsync(c->st_host + 1, c->st_dev + 1, (size_t)c->world * sizeof(int32_t), hipMemcpyDeviceToHost, stream) != hipSuccess) {
+        fail("download of the status words failed");
+        return -2;
+    }
+    stream_sync();                                      // bounded: a peer that never arrives ends the process with a message
+    for (int k = 0; k < c->world; ++k)
+        if (c->st_host[1 + k] != 0) return k;
+    return -1;
+}
+
 // `count` samples of every rank -> rank 0, rank-major.  RCCL: device buffers, everything on the provider's stream;
-// host transport: through the callback.
-int gather_samples(Peba1Comm *c, LweSample *all, const LweSample *mine, int count, const TFheGateBootstrappingParameterSet *params) {
+// host transport: through the callback.  local / why: what already went wrong on this rank (0 / "" = nothing).
+int gather_samples(Peba1Comm *c, LweSample *all, const LweSample *mine, int count, const TFheGateBootstrappingParameterSet *params,
+                   int local = 0, std::string why = std::string()) {
     const size_t words = (size_t)tfhe_hip_sample_words(params) * (size_t)count;
+    auto note = [&](const std::string &msg) { if (local == 0) { local = -1; why = msg; } };
+    if (c->inject_failures > 0) { --c->inject_failures; note("injected failure (peba1_dist_inject_failure)"); }
+    if (c->rank == 0 && !all) note("no destination array on rank 0");
     if (c->rccl) {
         if (!tfhe_hip_export_samples_device_async || !tfhe_hip_import_samples_device_async || !tfhe_hip_stream)
             return fail("the RCCL transport needs libtfhe-hip as the gate provider");
-        if (!device_buffer(c->send, c->send_words, words)) return fail("hipMalloc of the send buffer failed");
-        if (c->rank == 0 && !device_buffer(c->recv, c->recv_words, words * (size_t)c->world)) return fail("hipMalloc of the receive buffer failed");
+        if (local == 0 && !device_buffer(c->send, c->send_words, words)) note("hipMalloc of the send buffer failed");
+        if (local == 0 && c->rank == 0 && !device_buffer(c->recv, c->recv_words, words * (size_t)c->world)) note("hipMalloc of the receive buffer failed");
         hipStream_t stream = static_cast<hipStream_t>(tfhe_hip_stream());
         // runs the pending gates, then gathers the slots into the buffer -- enqueued, not waited for
-        if (tfhe_hip_export_samples_device_async(mine, count, params, c->send) != 0) return fail("export of the samples: " + provider_error());
+        if (local == 0 && tfhe_hip_export_samples_device_async(mine, count, params, c->send) != 0) note("export of the samples: " + provider_error());
+        const int bad = exchange_status_rccl(c, local);
+        if (bad == -2) return -1;
+        if (bad >= 0)
+            return fail(bad == c->rank ? "rank " + std::to_string(bad) + " (this rank) failed before the gather: " + why
+                                       : "rank " + std::to_string(bad) + " reported a failure before the gather; no rank entered it");
         const ncclResult_t r = g_rccl.Gather(c->send, c->rank == 0 ? c->recv : nullptr, words, ncclInt32, 0, c->nccl, stream);
         if (r != ncclSuccess) return fail(std::string("ncclGather: ") + g_rccl.GetErrorString(r));
         if (c->rank == 0 && tfhe_hip_import_samples_device_async(all, count * c->world, params, c->recv) != 0)
             return fail("import of the gathered samples: " + provider_error());
         return 0;
     }
-    std::vector<int32_t> send(words), recv(c->rank == 0 ? words * (size_t)c->world : 0);
-    if (tfhe_hip_export_samples(mine, count, params, send.data()) != 0) return fail("export of the samples: " + provider_error());
-    if (c->gather(c->ctx, send.data(), c->rank == 0 ? recv.data() : nullptr, words * sizeof(int32_t), 0) != 0)
+    // host transport: [status word][payload] per rank
+    std::vector<int32_t> send(1 + words, 0), recv(c->rank == 0 ? (1 + words) * (size_t)c->world : 0);
+    if (local == 0 && tfhe_hip_export_samples(mine, count, params, send.data() + 1) != 0) note("export of the samples: " + provider_error());
+    send[0] = local;
+    if (c->gather(c->ctx, send.data(), c->rank == 0 ? recv.data() : nullptr, (1 + words) * sizeof(int32_t), 0) != 0)
         return fail("the host gather callback failed");
-    if (c->rank == 0 && tfhe_hip_import_samples(all, count * c->world, params, recv.data()) != 0)
+    if (local != 0) return fail("rank " + std::to_string(c->rank) + " (this rank) failed before the gather: " + why);
+    if (c->rank != 0) return 0;
+    for (int k = 0; k < c->world; ++k)
+        if (recv[(size_t)k * (1 + words)] != 0)
+            return fail("rank " + std::to_string(k) + " reported a failure before the gather; its contribution is void");
+    std::vector<int32_t> packed(words * (size_t)c->world);
+    for (int k = 0; k < c->world; ++k)
+        std::memcpy(packed.data() + (size_t)k * words, recv.data() + (size_t)k * (1 + words) + 1, words * sizeof(int32_t));
+    if (tfhe_hip_import_samples(all, count * c->world, params, packed.data()) != 0)
         return fail("import of the gathered samples: " + provider_error());
     return 0;
 }
@@ -141,6 +225,7 @@ Peba1Comm *peba1_dist_init_rccl(const void *id128, int world, int rank) {
     c->world = world; c->rank = rank; c->rccl = true; c->own = true;
     const ncclResult_t r = g_rccl.CommInitRank(&c->nccl, world, id, rank);
     if (r != ncclSuccess) { fail(std::string("ncclCommInitRank: ") + g_rccl.GetErrorString(r)); delete c; return nullptr; }
+    arm_deadline(c);
     return c;
 }
 
@@ -150,6 +235,7 @@ Peba1Comm *peba1_dist_adopt_rccl(void *nccl_comm, int world, int rank) {
     auto *c = new Peba1Comm();
     c->world = world; c->rank = rank; c->rccl = true; c->own = false;
     c->nccl = static_cast<ncclComm_t>(nccl_comm);
+    arm_deadline(c);
     return c;
 }
 
@@ -157,15 +243,18 @@ Peba1Comm *peba1_dist_init_host(peba1_gather_fn gather, void *ctx, int world, in
     if (!gather || world < 1 || rank < 0 || rank >= world) { fail("peba1_dist_init_host: bad arguments"); return nullptr; }
     auto *c = new Peba1Comm();
     c->world = world; c->rank = rank; c->gather = gather; c->ctx = ctx;
+    arm_deadline(c);
     return c;
 }
 
 void peba1_dist_destroy(Peba1Comm *c) {
     if (!c) return;
     if (c->rccl) {
-        if (tfhe_hip_stream) (void)hipStreamSynchronize(static_cast<hipStream_t>(tfhe_hip_stream()));
+        stream_sync();
         if (c->send) (void)hipFree(c->send);
         if (c->recv) (void)hipFree(c->recv);
+        if (c->st_dev) (void)hipFree(c->st_dev);
+        if (c->st_host) (void)hipHostFree(c->st_host);
         if (c->own && c->nccl) (void)g_rccl.CommDestroy(c->nccl);
     }
     delete c;
@@ -215,7 +304,8 @@ int peba1_sharded_combine_packed(LweSample *result_b, const int32_t *packed, int
 
 int peba1_dist_gather_samples(Peba1Comm *c, LweSample *all, const LweSample *mine, int count,
                               const TFheGateBootstrappingParameterSet *params) {
-    if (!c || !mine || count < 1 || !params || (c->rank == 0 && !all)) return fail("peba1_dist_gather_samples: bad arguments");
+    // (a missing destination on rank 0 is reported THROUGH the exchange, so that the other ranks are not left in it)
+    if (!c || !mine || count < 1 || !params) return fail("peba1_dist_gather_samples: bad arguments");
     return gather_samples(c, all, mine, count, params);
 }
 
@@ -226,18 +316,73 @@ int peba1_sharded_function_f(Peba1Comm *c, LweSample *result_b, LweSample *const
         return fail("peba1_sharded_function_f: bad arguments");
     if ((flags & PEBA1_DIST_FAST_PARTIAL) && 3 * bitsize != PARTIAL_BITS)
         return fail("peba1_sharded_function_f: PEBA1_DIST_FAST_PARTIAL needs bitsize 8 (a 24-sample partial sum)");
-    // phase 1, every rank: the reference's slot loop over this rank's slots (recorded; the export runs it)
+    // phase 1, every rank: the reference's slot loop over this rank's slots (recorded; the export runs it).  From here
+    // on nothing returns before the exchange: a local failure travels through it (gather_samples)
+    int local = 0;
+    std::string why;
     LweSample *partial = new_gate_bootstrapping_ciphertext_array(PARTIAL_BITS, ck->params);
-    if (!partial) return fail("allocation of the partial sum: " + provider_error());
-    partial_phase(partial, a, b, nslots_local, bitsize, ck, flags);
+    if (!partial) { local = -1; why = "allocation of the partial sum: " + provider_error(); }
+    else partial_phase(partial, a, b, nslots_local, bitsize, ck, flags);
     // phase 2: ONE exchange, 24 ciphertexts per rank
     LweSample *parts = c->rank == 0 ? new_gate_bootstrapping_ciphertext_array(PARTIAL_BITS * c->world, ck->params) : nullptr;
-    int rc = gather_samples(c, parts, partial, PARTIAL_BITS, ck->params);
-    delete_gate_bootstrapping_ciphertext_array(PARTIAL_BITS, partial);
+    if (c->rank == 0 && !parts && local == 0) { local = -1; why = "allocation of the gathered partial sums: " + provider_error(); }
+    int rc = gather_samples(c, parts, partial, PARTIAL_BITS, ck->params, local, why);
+    // (the exported slots may be released at once: a later host write of a recycled slot waits for the stream-ordered
+    // export first -- engine.cpp write_slot)
+    if (partial) delete_gate_bootstrapping_ciphertext_array(PARTIAL_BITS, partial);
     // phase 3, rank 0: add the partial sums, compare with the bound (recorded; runs at the caller's next decrypt /
     // export / flush, ordered behind the import on the provider's stream)
     if (rc == 0 && c->rank == 0) rc = combine(result_b, parts, c->world, bound_match, ck, flags);
     if (parts) delete_gate_bootstrapping_ciphertext_array(PARTIAL_BITS * c->world, parts);
+    return rc;
+}
+
+void peba1_dist_inject_failure(Peba1Comm *c, int count) { if (c) c->inject_failures = count > 0 ? count : 0; }
+
+int peba1_dist_set_timeout(Peba1Comm *c, double seconds) {
+    if (!c || seconds < 0) return fail("peba1_dist_set_timeout: bad arguments");
+    if (!tfhe_hip_set_tuning) return fail("the gate provider has no bounded waits (not libtfhe-hip)");
+    return tfhe_hip_set_tuning("sync_deadline_ms", (int64_t)(seconds * 1000.0)) == 0 ? 0 : fail("sync_deadline_ms refused");
+}
+
+// 1-to-N identification (BASELINE configs[3]; the loop a server puts around /root/reference/src/main.cpp:533-542, one
+// Function_f per enrolled client): this rank's m_local matches, recorded `group` at a time -- a flush runs the pending
+// gates of the whole group level by level, so the narrow tail levels of one match are filled by the others, and
+// releases their slots: device memory is bounded by `group`, not by m_local.  Pipelined: a group's launches are
+// enqueued and the next group is recorded while the device works.  Only the match-bit ciphertexts are kept; one gather
+// brings them to rank 0.
+int peba1_identify(Peba1Comm *c, LweSample *all, LweSample *mine, LweSample *const *probe, LweSample *const *templates,
+                   int m_local, int nslots, LweSample *bound_match, int bitsize, const TFheGateBootstrappingCloudKeySet *ck,
+                   int group, int flags) {
+    if (!mine || !probe || !templates || m_local < 1 || nslots < 1 || !bound_match || bitsize < 1 || !ck || group < 1)
+        return fail("peba1_identify: bad arguments");
+    const int was_deferred = tfhe_hip_get_deferred ? tfhe_hip_get_deferred() : -1;
+    if (tfhe_hip_set_deferred) tfhe_hip_set_deferred(1);            // record; the flushes below run the batches
+    int local = 0;
+    std::string why;
+    for (int first = 0; first < m_local && local == 0; first += group) {
+        const int cnt = m_local - first < group ? m_local - first : group;
+        for (int m = first; m < first + cnt; ++m) {
+            LweSample *rb = new_gate_bootstrapping_ciphertext_array(3 * bitsize, ck->params);
+            if (!rb) { local = -1; why = "allocation of a result array: " + provider_error(); break; }
+            LweSample *const *tmpl = templates + (size_t)m * (size_t)nslots;
+            if (flags & PEBA1_IDENTIFY_FAST) peba1_function_f_fast(rb, probe, tmpl, nslots, bound_match, bitsize, ck);
+            else peba1_function_f(rb, probe, tmpl, nslots, bound_match, bitsize, ck);
+            bootsCOPY(mine + m, rb, ck);                            // re-points a handle: no data moves
+            delete_gate_bootstrapping_ciphertext_array(3 * bitsize, rb);
+        }
+        // the launches of this group are enqueued and the host goes on recording the next group; the next flush (or the
+        // final wait / export) completes this one
+        if (local == 0 && tfhe_hip_flush_async && tfhe_hip_flush_async() < 0) { local = -1; why = "flush: " + provider_error(); }
+    }
+    int rc = 0;
+    if (c && (c->world > 1 || all)) {
+        rc = gather_samples(c, all, mine, m_local, ck->params, local, why);
+    } else {
+        if (tfhe_hip_wait) (void)tfhe_hip_wait();
+        if (local != 0) rc = fail(why);
+    }
+    if (tfhe_hip_set_deferred && was_deferred == 0) tfhe_hip_set_deferred(0);
     return rc;
 }
 

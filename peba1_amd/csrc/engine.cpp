@@ -57,6 +57,7 @@ void SlotPool::grow(size_t new_cap) {
         // growth happens while recording (host side).  A pipelined flush may still be in flight -- its launches carry
         // the old pointer -- and a caller's own stream may still read an exported buffer: wait for the whole device
         // once (every launch enqueued so far has then finished with the old buffer), copy, release
+        Engine::get().sync_stream("sync before pool growth");      // bounded when a deadline is set (a collective may sit there)
         hip_check(hipDeviceSynchronize(), "sync before pool growth");
         hip_check(hipMemcpy(fresh, data_, cap_ * (size_t)stride_ * sizeof(int32_t), hipMemcpyDeviceToDevice), "copy slot pool");
         (void)hipFree(data_);
@@ -126,14 +127,68 @@ void Engine::ensure_init() {
     if (const char *env = std::getenv("TFHE_HIP_BR_TAIL8")) br_tail8 = std::atoi(env);
     if (const char *env = std::getenv("TFHE_HIP_BR_VARIANT")) br_variant = std::atoi(env);
     if (const char *env = std::getenv("TFHE_HIP_BR_TABLE")) br_digit_table = std::atoi(env);
+    if (const char *env = std::getenv("TFHE_HIP_SYNC_DEADLINE_MS")) sync_deadline_ms = std::atoll(env);
     for (auto &e : ev_) hip_check(hipEventCreate(&e), "hipEventCreate");
     inited_ = true;
+}
+
+// ---- host waits ----------------------------------------------------------------
+// Every host wait on the engine's stream goes through here.  Without a deadline it is hipStreamSynchronize.  With one
+// (tuning "sync_deadline_ms" / TFHE_HIP_SYNC_DEADLINE_MS; libpeba1-dist sets it for communicators of more than one
+// rank) the stream is polled, and a wait that outlasts the deadline -- a collective whose peer never arrived, a kernel
+// that never ends -- prints what was waited for, by whom, and ends the process with TFHE_HIP_EXIT_DEADLINE: the job fails
+// with a message instead of sitting in its scheduler's time limit.  No retry, no re-exec: the device state is unknown.
+[[noreturn]] static void deadline_expired(const char *what, long long ms, const std::string &label) {
+    std::fprintf(stderr, "libtfhe-hip: fatal: '%s' did not complete within %lld ms%s%s; the engine's stream is stuck behind a "
+                         "collective or a kernel that does not finish -- exiting with code %d\n",
+                 what, ms, label.empty() ? "" : " on ", label.c_str(), TFHE_HIP_EXIT_DEADLINE);
+    std::fflush(stderr);
+    _exit(TFHE_HIP_EXIT_DEADLINE);       // not exit(): runtime destructors would wait for the same stream
+}
+
+template <typename Query>
+static void bounded_wait(Query &&query, const char *what, long long deadline_ms, const std::string &label) {
+    const auto t0 = std::chrono::steady_clock::now();
+    for (unsigned spins = 0;; ++spins) {
+        const hipError_t e = query();
+        if (e == hipSuccess) return;
+        if (e != hipErrorNotReady) hip_check(e, what);
+        if ((spins & 63u) == 63u || spins > 4096u) {
+            const long long ms = std::chrono::duration_cast<std::chrono::milliseconds>(std::chrono::steady_clock::now() - t0).count();
+            if (ms >= deadline_ms) deadline_expired(what, deadline_ms, label);
+        }
+        if (spins > 4096u) {                 // a long wait: stop burning the core the recorder may want
+            struct timespec ts = {0, 50 * 1000};
+            nanosleep(&ts, nullptr);
+        }
+    }
+}
+
+void Engine::sync_stream(const char *what) {
+    if (sync_deadline_ms <= 0) hip_check(hipStreamSynchronize(stream_), what);
+    else bounded_wait([&] { return hipStreamQuery(stream_); }, what, sync_deadline_ms, diag_label);
+    io_pending_ = false;                     // whatever was enqueued without a host wait has completed too
+}
+
+// Stream-ordered transfers that returned without a host wait (write_/read_slots_packed with wait = false) leave an
+// event behind; host accesses of slot memory that do not go through the stream wait for it first (a
+// decrypt of a sample imported behind an ncclGather read the slot before the scatter had written it).
+void Engine::note_async_io() {
+    if (!io_event_) hip_check(hipEventCreateWithFlags(&io_event_, hipEventDisableTiming), "io event");
+    hip_check(hipEventRecord(io_event_, stream_), "io event record");
+    io_pending_ = true;
+}
+void Engine::sync_io() {
+    if (!io_pending_) return;
+    if (sync_deadline_ms <= 0) hip_check(hipEventSynchronize(io_event_), "stream-ordered transfer");
+    else bounded_wait([&] { return hipEventQuery(io_event_); }, "stream-ordered transfer", sync_deadline_ms, diag_label);
+    io_pending_ = false;
 }
 
 void *Engine::scratch(size_t idx, size_t bytes) {
     if (scratch_ptr_.size() <= idx) { scratch_ptr_.resize(idx + 1, nullptr); scratch_size_.resize(idx + 1, 0); }
     if (scratch_size_[idx] < bytes) {
-        hip_check(hipStreamSynchronize(stream_), "sync before scratch realloc");
+        sync_stream("sync before scratch realloc");
         if (scratch_ptr_[idx]) (void)hipFree(scratch_ptr_[idx]);
         size_t cap = bytes + bytes / 2 + 4096;
         hip_check(hipMalloc(&scratch_ptr_[idx], cap), "hipMalloc(scratch)");
@@ -272,7 +327,7 @@ DeviceKeyImage *Engine::upload_key(const TfheHipCloudKey &ck) {
     hip_check(hipMalloc(reinterpret_cast<void **>(&img->bk_img), bk_words * 2 * 4), "hipMalloc(bk image)");
     launch_bk_transform(stream_, img->dp, raw, img->bk_img, img->tw, p.n * p.kpl(), p.k + 1, scale);
     hip_check(hipGetLastError(), "bk_transform launch");
-    hip_check(hipStreamSynchronize(stream_), "bk_transform");
+    sync_stream("bk_transform");
     (void)hipFree(raw);
 
     // KSK: drop the all-zero digit-0 rows, pad rows to ct_stride
@@ -295,7 +350,7 @@ DeviceKeyImage *Engine::upload_key(const TfheHipCloudKey &ck) {
 
 void Engine::free_key(DeviceKeyImage *img) {
     if (!img) return;
-    if (inited_) hip_check(hipStreamSynchronize(stream_), "sync before key free");
+    if (inited_) sync_stream("sync before key free");
     if (img->bk_img) (void)hipFree(img->bk_img);
     if (img->ksk) (void)hipFree(img->ksk);
     if (img->tw) (void)hipFree(img->tw);
@@ -330,6 +385,11 @@ SlotPool *Engine::pool_for(const Params &p) {
 }
 
 void Engine::write_slot(SlotPool *pool, int32_t slot, const Torus32 *a, Torus32 b) {
+    // A blocking copy on the null stream is not ordered against the engine's non-blocking stream.  Slots a flush in
+    // flight touches stay pinned, so a fresh slot is never one of those; but a slot freed right after a stream-ordered
+    // export may still be waiting for its gather kernel: wait for such transfers, not for the whole stream
+    // (a pipelined flush keeps running under the recording that calls this).
+    sync_io();
     std::vector<int32_t> tmp(pool->ct_stride(), 0);
     std::memcpy(tmp.data(), a, (size_t)(pool->ct_words() - 1) * 4);
     tmp[pool->ct_words() - 1] = b;
@@ -338,10 +398,13 @@ void Engine::write_slot(SlotPool *pool, int32_t slot, const Torus32 *a, Torus32 
 }
 
 void Engine::read_slot(SlotPool *pool, int32_t slot, Torus32 *a, Torus32 *b) {
-    wait_flight();          // a blocking copy on the null stream does not wait for the engine's non-blocking stream
+    wait_flight();
+    // on the engine's stream, then waited for: ordered behind everything enqueued there -- a flush, and a stream-ordered
+    // import that nobody waited for (the scatter behind an ncclGather of tfhe_hip_import_samples_device_async)
     std::vector<int32_t> tmp(pool->ct_stride());
-    hip_check(hipMemcpy(tmp.data(), pool->data() + (size_t)slot * pool->ct_stride(), tmp.size() * 4, hipMemcpyDeviceToHost),
+    hip_check(hipMemcpyAsync(tmp.data(), pool->data() + (size_t)slot * pool->ct_stride(), tmp.size() * 4, hipMemcpyDeviceToHost, stream_),
               "read_slot");
+    sync_stream("read_slot");
     std::memcpy(a, tmp.data(), (size_t)(pool->ct_words() - 1) * 4);
     *b = tmp[pool->ct_words() - 1];
 }
@@ -352,12 +415,12 @@ int32_t *Engine::stage_slots(const int32_t *slots, int count) {
     constexpr size_t RING = 1 << 16;                         // words; one transfer may use at most a quarter
     if (!slot_ring_) hip_check(hipHostMalloc(reinterpret_cast<void **>(&slot_ring_), RING * 4, hipHostMallocDefault), "pinned slot ring");
     if ((size_t)count > RING / 4) {                          // large lists: synchronous staging through the stream
-        hip_check(hipStreamSynchronize(stream_), "sync before large slot list");
+        sync_stream("sync before large slot list");
         slot_ring_pos_ = 0;
         if ((size_t)count > RING) api_fail("too many samples in one packed transfer");
     }
     if (slot_ring_pos_ + (size_t)count > RING) {             // wrap: everything queued so far must have read its list
-        hip_check(hipStreamSynchronize(stream_), "sync at slot ring wrap");
+        sync_stream("sync at slot ring wrap");
         slot_ring_pos_ = 0;
     }
     int32_t *h = slot_ring_ + slot_ring_pos_;
@@ -378,7 +441,8 @@ void Engine::write_slots_packed(SlotPool *pool, const int32_t *slots, int count,
         src = dw;
     }
     launch_scatter_slots(stream_, pool->data(), pool->ct_stride(), pool->ct_words(), dslots, count, src);
-    if (wait || !on_device) hip_check(hipStreamSynchronize(stream_), "scatter slots");
+    if (wait || !on_device) sync_stream("scatter slots");
+    else note_async_io();
 }
 
 void Engine::read_slots_packed(SlotPool *pool, const int32_t *slots, int count, Torus32 *words, bool on_device, bool wait) {
@@ -390,7 +454,8 @@ void Engine::read_slots_packed(SlotPool *pool, const int32_t *slots, int count, 
     int32_t *dst = on_device ? words : static_cast<int32_t *>(scratch(4, wbytes));
     launch_gather_slots(stream_, pool->data(), pool->ct_stride(), pool->ct_words(), dslots, count, dst);
     if (!on_device) hip_check(hipMemcpyAsync(words, dst, wbytes, hipMemcpyDeviceToHost, stream_), "download packed words");
-    if (wait || !on_device) hip_check(hipStreamSynchronize(stream_), "gather slots");
+    if (wait || !on_device) sync_stream("gather slots");
+    else note_async_io();
 }
 
 hipEvent_t Engine::next_timing_event() {
@@ -405,6 +470,8 @@ hipEvent_t Engine::next_timing_event() {
 bool Engine::launch_br(const DeviceKeyImage *key, const int32_t *pool, const RotDesc *rots, int count, int32_t *u_buf,
                        int32_t *acc_dbg, hipStream_t stream, int wave_prio) {
     if (!stream) stream = stream_;
+    tail_event_ = nullptr;                   // what an earlier launch left is not this one's
+    tail_count_ = 0;
     DevParams dp = key->dp;
     // the form the tunings ask for ...
     int form;
@@ -471,7 +538,9 @@ bool Engine::launch_br(const DeviceKeyImage *key, const int32_t *pool, const Rot
         !acc_dbg && !wg_times_dbg_ && key->form_ok[BR_FORM_WAVE8][tables]) {
         launch_blind_rotate4(stream, dp, key->key, pool, rots, count - tail, u_buf, nullptr);
         tail_count_ = tail;
-        if (kernel_timing) { tail_event_ = next_timing_event(); hip_check(hipEventRecord(tail_event_, stream), "event"); }
+        // the event between the two launches belongs to execute()'s per-flush set (reset there); the raw test paths and
+        // probes have no reader for it and must not grow the set
+        if (kernel_timing && in_execute_) { tail_event_ = next_timing_event(); hip_check(hipEventRecord(tail_event_, stream), "event"); }
         DevParams dp8 = dp;                                   // as a narrow launch gets them: no turn-taking
         dp8.fair_shift = 0;
         dp8.cu_arrivals = nullptr;
@@ -609,9 +678,9 @@ void Engine::execute(const DeviceKeyImage *key, SlotPool *pool, LevelPlan &&plan
             Timed t{nullptr, nullptr, nullptr, false, nrot};
             if (kernel_timing) { t.e0 = timing_event(); hip_check(hipEventRecord(t.e0, st), "event"); }
             if (nrot) {
-                tail_event_ = nullptr;
-                tail_count_ = 0;
+                in_execute_ = true;
                 t.wide8 = launch_br(key, pool->data(), drots + plan.rot_off[gg], nrot, u_buf[s], nullptr, st, K > 1 && s == 0 ? lane_prio : 0);
+                in_execute_ = false;
                 if (t.wide8) { ++stats.br8_launches; stats.br8_rotations += (uint64_t)nrot; }
                 if (tail_count_) {                       // a second launch, of the 8-wave kernel
                     t.em = tail_event_;
@@ -660,7 +729,7 @@ void Engine::wait_flight() {
     const int levels = flight_levels_;
     std::vector<Timed> &timed = flight_timed_;
     hipEvent_t base = flight_base_;
-    hip_check(hipStreamSynchronize(stream_), "level execution");
+    sync_stream("level execution");
     if (kernel_timing && base) {
         // durations per launch, and the union of the blind-rotate intervals (two lanes overlap)
         std::vector<std::pair<float, float>> br;
@@ -749,7 +818,7 @@ void Engine::execute_dataflow(const DeviceKeyImage *key, SlotPool *pool, const s
     }
     int32_t ctrl[2] = {0, 0};
     hip_check(hipMemcpyAsync(ctrl, dflags + ntasks, sizeof ctrl, hipMemcpyDeviceToHost, stream_), "read ctrl");
-    hip_check(hipStreamSynchronize(stream_), "dataflow execution");
+    sync_stream("dataflow execution");
     if (ctrl[1] != 0) fatal("dataflow executor: a workgroup timed out waiting for a producer (results are invalid)");
     if (kernel_timing) {
         float ms = 0;
@@ -787,7 +856,7 @@ void Engine::run_bootstrap_woks(const DeviceKeyImage *key, const Torus32 *lin, i
     std::vector<int32_t> ubuf((size_t)count * dp.u_stride);
     hip_check(hipMemcpyAsync(ubuf.data(), u_buf, ubuf.size() * 4, hipMemcpyDeviceToHost, stream_), "download u");
     if (acc_out) hip_check(hipMemcpyAsync(acc_out, dacc, (size_t)count * 2 * dp.N * 4, hipMemcpyDeviceToHost, stream_), "download acc");
-    hip_check(hipStreamSynchronize(stream_), "bootstrap_woks");
+    sync_stream("bootstrap_woks");
     for (int c = 0; c < count; ++c)
         std::memcpy(u_out + (size_t)c * (dp.k * dp.N + 1), &ubuf[(size_t)c * dp.u_stride], (size_t)(dp.k * dp.N + 1) * 4);
     stats.blind_rotates += (uint64_t)count;
@@ -810,7 +879,7 @@ void Engine::run_keyswitch(const DeviceKeyImage *key, const Torus32 *u, int coun
     hip_check(hipGetLastError(), "keyswitch launch");
     std::vector<int32_t> res((size_t)count * dp.ct_stride);
     hip_check(hipMemcpyAsync(res.data(), dpool, res.size() * 4, hipMemcpyDeviceToHost, stream_), "download ks");
-    hip_check(hipStreamSynchronize(stream_), "keyswitch");
+    sync_stream("keyswitch");
     for (int c = 0; c < count; ++c) std::memcpy(out + (size_t)c * (dp.n + 1), &res[(size_t)c * dp.ct_stride], (size_t)(dp.n + 1) * 4);
     stats.keyswitches += (uint64_t)count;
 }
@@ -912,7 +981,7 @@ void Engine::run_negacyclic(const DeviceKeyImage *key, const int32_t *ip, const 
     launch_negacyclic(stream_, dp, key->tw, dip, dimg, dres, count);
     hip_check(hipGetLastError(), "negacyclic launch");
     hip_check(hipMemcpyAsync(res, dres, words * 4, hipMemcpyDeviceToHost, stream_), "download res");
-    hip_check(hipStreamSynchronize(stream_), "negacyclic");
+    sync_stream("negacyclic");
 }
 
 }  // namespace tfhe_hip

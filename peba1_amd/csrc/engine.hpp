@@ -112,6 +112,14 @@ public:
     // enqueued ("in flight") -- see engine.cpp
     void execute(const DeviceKeyImage *key, SlotPool *pool, LevelPlan &&plan, bool wait = true);
     void wait_flight();                 // completes an asynchronous execute(): waits, then reads the timing events
+    // host waits (engine.cpp "host waits"): bounded by sync_deadline_ms when that is set
+    void sync_stream(const char *what); // everything enqueued on the engine's stream has completed
+    void sync_io();                     // the stream-ordered transfers nobody waited for have completed
+    void wait_all() { wait_flight(); sync_io(); }
+    // > 0: no host wait on the engine's stream lasts longer -- on expiry the process prints what it waited for and ends
+    // with TFHE_HIP_EXIT_DEADLINE (tuning "sync_deadline_ms", env TFHE_HIP_SYNC_DEADLINE_MS); 0 = wait for ever
+    long long sync_deadline_ms = 0;
+    std::string diag_label;             // who waits, for the deadline message (tfhe_hip_set_diag_label: "rank 3 of 8")
     bool in_flight() const { return in_flight_; }
 #ifdef TFHE_HIP_EXPERIMENTAL
     // run a whole DAG (tasks in topological priority order) as one dataflow launch
@@ -180,6 +188,10 @@ private:
     // em / tail: a level whose last round went to the 8-wave form as a second launch (br_tail8) -- the event between
     // the two launches and the rotations of the second, so that each kernel's time and count stay its own
     struct Timed { hipEvent_t e0, e1, e2; bool wide8; int nrot; hipEvent_t em = nullptr; int tail = 0; };
+    void note_async_io();
+    hipEvent_t io_event_ = nullptr;                     // behind the last stream-ordered transfer that returned without a wait
+    bool io_pending_ = false;
+    bool in_execute_ = false;                           // launch_br called for a level of execute(): the tail event has a reader
     hipEvent_t tail_event_ = nullptr;                   // set by launch_br when it split a level (kernel_timing only)
     int tail_count_ = 0;
     std::vector<Timed> flight_timed_;

@@ -14,8 +14,11 @@
 #include <cstdlib>
 #include <cstring>
 #include <ctime>
+#include <pthread.h>
 #include <sys/random.h>
 #include <unistd.h>
+
+#include <atomic>
 
 namespace tfhe_hip {
 
@@ -100,19 +103,37 @@ void Rng::reseed(uint64_t seed) {
     }
 }
 
-Rng Rng::secure() {
-    Rng r(0);
+// Fork safety of the secure streams: a child of fork() inherits the ChaCha20 key, nonce, counter and the
+// unread words of the current block -- parent and child would then draw identical noise and masks, and two encryptions
+// under one mask and noise leak the difference of their messages.  A pthread_atfork child handler bumps a generation
+// counter; a secure generator that sees another generation than the one it was keyed in re-keys itself from the OS
+// before it yields another word.
+static std::atomic<uint32_t> g_fork_generation{0};
+static void note_fork_in_child() { g_fork_generation.fetch_add(1, std::memory_order_relaxed); }
+static void register_fork_handler() {
+    static const bool once = [] { return pthread_atfork(nullptr, nullptr, note_fork_in_child) == 0; }();
+    (void)once;
+}
+
+void Rng::rekey_secure() {
     uint32_t seed[10];
     if (!os_random(seed, sizeof seed)) {
         // a keyset or an encryption without entropy would be worthless: stop, like upstream's fatal paths
         std::fprintf(stderr, "libtfhe-hip: fatal: the operating system offers no entropy (getrandom, /dev/urandom)\n");
         std::abort();
     }
-    std::memcpy(r.key_, seed, sizeof r.key_);
-    r.nonce_[0] = seed[8]; r.nonce_[1] = seed[9];
-    r.counter_ = 0;
-    r.pos_ = 16;
-    r.chacha_ = true;
+    std::memcpy(key_, seed, sizeof key_);
+    nonce_[0] = seed[8]; nonce_[1] = seed[9];
+    counter_ = 0;
+    pos_ = 16;
+    chacha_ = true;
+    fork_gen_ = g_fork_generation.load(std::memory_order_relaxed);
+}
+
+Rng Rng::secure() {
+    register_fork_handler();
+    Rng r(0);
+    r.rekey_secure();
     return r;
 }
 
@@ -152,6 +173,7 @@ void Rng::chacha_block(const uint32_t key[8], uint64_t counter, const uint32_t n
 
 uint64_t Rng::next() {
     if (chacha_) {
+        if (fork_gen_ != g_fork_generation.load(std::memory_order_relaxed)) rekey_secure();    // this process is a fork() child
         if (pos_ >= 16) refill();
         const uint64_t v = (uint64_t)block_[pos_] | ((uint64_t)block_[pos_ + 1] << 32);
         pos_ += 2;

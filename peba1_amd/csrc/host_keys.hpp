@@ -59,6 +59,8 @@ public:
     static void chacha_block(const uint32_t key[8], uint64_t counter, const uint32_t nonce[2], uint32_t out[16]);
 private:
     void refill();
+    void rekey_secure();             // key, nonce from the OS; counter 0 (also after fork(): host_keys.cpp)
+    uint32_t fork_gen_ = 0;          // the fork generation the secure stream was keyed in
     bool chacha_ = false;
     uint64_t s_[4];                  // xoshiro state
     uint32_t key_[8], nonce_[2];     // ChaCha20 key and nonce

@@ -499,16 +499,17 @@ struct Br4Lds {
     static constexpr bool MERGED = BrTraits<LOGN, V>::MERGED_BUFFERS;
     static constexpr bool LTW = BrTraits<LOGN, V>::LDS_TWIDDLES;
     AccLds<LOGN> acc;                              // the accumulator (signed runs), resident for all n steps
-    uint32_t buf[MERGED ? 1 : 2][4][NTT::SCRATCH_WORDS];
+    uint32_t buf0[4][NTT::SCRATCH_WORDS];          // per wave: transpose scratch (layouts R and H of ntt_wave.hpp), then residues
+    uint32_t buf1[MERGED ? 1 : 4][MERGED ? 4 : NTT::ROW_WORDS];   // per wave: the partial sums sent (rows only: layout R)
     uint16_t bar[1024 + 8];                        // modulus-switched mask and body
-    uint32_t dtab[2][5 * DIGIT_TAB];               // per prime: first-step products of the gadget digits (ntt_wave.hpp)
+    alignas(8) uint32_t dtab[2][5 * DIGIT_TAB];    // per prime: first-step products of the gadget digits (ntt_wave.hpp)
     // per prime: the forward transforms' second-pass twiddles (one image per group of 2^LC lanes) and third-pass
     // twiddles (one per lane)
     uint4 ft1[LTW ? 2 : 1][LTW ? (64 >> NTT::LC) : 1][NTT::FwdTw1::IMAGE16];
     uint4 ft2[LTW ? 2 : 1][LTW ? 64 : 1][NTT::FwdTw2::IMAGE16];
-    __device__ __forceinline__ uint32_t *scr(int wv) { return buf[0][wv]; }
-    __device__ __forceinline__ uint32_t *x1(int wv) { return buf[MERGED ? 0 : 1][wv]; }
-    __device__ __forceinline__ uint32_t *x2(int wv) { return buf[0][wv]; }
+    __device__ __forceinline__ uint32_t *scr(int wv) { return buf0[wv]; }
+    __device__ __forceinline__ uint32_t *x1(int wv) { return MERGED ? buf0[wv] : buf1[wv]; }
+    __device__ __forceinline__ uint32_t *x2(int wv) { return buf0[wv]; }
 };
 static_assert(sizeof(Br4Lds<10, 0>) <= 80 * 1024, "two workgroups of the default form must fit the 160 KB of a CU");
 
@@ -715,13 +716,15 @@ template <int LOGN>
 struct Br8Lds {
     using NTT = WaveNtt<LOGN>;
     AccLds<LOGN> acc;
-    uint32_t scr[8][NTT::SCRATCH_WORDS];           // wave-private NTT transposes
-    uint32_t pa0[4][NTT::SCRATCH_WORDS];           // A's sum for its own output polynomial (read by its B)
-    uint32_t pa1[4][NTT::SCRATCH_WORDS];           // A's sum for the other output polynomial (read by the other B)
-    uint32_t pb0[4][NTT::SCRATCH_WORDS];           // B's sum for its own output polynomial
-    uint32_t pb[4][NTT::SCRATCH_WORDS];            // B's sum for the other output polynomial
+    // wave-private NTT transposes: full-size forward transforms (layout R), half-size inverse (layout H: smaller)
+    static_assert(WaveNtt<LOGN - 1>::SCRATCH_WORDS <= NTT::ROW_WORDS, "the half transform's scratch fits the full-size rows");
+    uint32_t scr[8][NTT::ROW_WORDS];
+    uint32_t pa0[4][NTT::ROW_WORDS];               // A's sum for its own output polynomial (read by its B)
+    uint32_t pa1[4][NTT::ROW_WORDS];               // A's sum for the other output polynomial (read by the other B)
+    uint32_t pb0[4][NTT::ROW_WORDS];               // B's sum for its own output polynomial
+    uint32_t pb[4][NTT::ROW_WORDS];                // B's sum for the other output polynomial
     uint16_t bar[1024 + 8];
-    uint32_t dtab[2][5 * DIGIT_TAB];
+    alignas(8) uint32_t dtab[2][5 * DIGIT_TAB];
     // per prime: LDS copies of the forward transforms' second- and third-pass twiddles (as in Br4Lds)
     uint4 ft1[2][64 >> NTT::LC][NTT::FwdTw1::IMAGE16];
     uint4 ft2[2][64][NTT::FwdTw2::IMAGE16];
@@ -879,9 +882,9 @@ struct BrSplitLds {
     AccLds<LOGN, 3> acc;
     uint32_t scr[8][SUB::SCRATCH_WORDS];           // wave-private NTT transposes; from the end of the inverse to the
                                                    // step's last barrier: its outputs (natural order), read by 3 waves
-    uint32_t x1[8][SUB::SCRATCH_WORDS];            // partial sums sent to the wave of the other input polynomial
+    uint32_t x1[8][SUB::ROW_WORDS];                // partial sums sent to the wave of the other input polynomial
     uint16_t bar[1024 + 8];
-    uint32_t tab[2][2][TM == 2 ? 11 << SPLIT_TAB2_BITS : DIGIT_TAB];     // [prime][h][table][digit field]
+    alignas(8) uint32_t tab[2][2][TM == 2 ? 11 << SPLIT_TAB2_BITS : DIGIT_TAB];     // [prime][h][table][digit field]
     // N = 2048 (one workgroup per CU, 30 KB of LDS to spare): per prime and half, LDS copies of the half transforms'
     // second- and third-pass forward twiddles (ntt_wave.hpp forward_digits LDSTW)
     static constexpr bool LTW = LOGN == 11;
@@ -950,7 +953,14 @@ __global__ __launch_bounds__(512, (LOGN == 10 ? 4 : 2)) void blind_rotate_split_
             const int32_t half = (int32_t)(c.P >> 1);
             if (v > half) v -= (int32_t)c.P;
             if (v < -half) v += (int32_t)c.P;
-            sh.tab[q][h][(k << SPLIT_TAB2_BITS) + f] = (uint32_t)v;
+#if BR_TAB_PAIRS
+            // tables read by one digit sit side by side (ntt_wave.hpp BR_TAB_PAIRS): (3,7) lo1, (4,8) hi1, (5,9) lo3, (6,10) hi3
+            const int pos = k < 3 ? (k << SPLIT_TAB2_BITS) + f
+                                  : ((3 + 2 * ((k - 3) & 3)) << SPLIT_TAB2_BITS) + 2 * f + (k >= 7 ? 1 : 0);
+#else
+            const int pos = (k << SPLIT_TAB2_BITS) + f;
+#endif
+            sh.tab[q][h][pos] = (uint32_t)v;
         }
     }
     __syncthreads();
@@ -997,6 +1007,27 @@ __global__ __launch_bounds__(512, (LOGN == 10 ? 4 : 2)) void blind_rotate_split_
                     return (int32_t)*reinterpret_cast<const uint32_t *>(tab + (k << (SPLIT_TAB2_BITS + 2)) + off);
                 };
                 auto field = [&](int i) { return (D[i] >> sh2) & mask4; };
+#if BR_TAB_PAIRS
+                const uint32_t mask8 = mask4 << 1;
+                const int sh3 = shift - 3;
+                auto pair = [&](int k, uint32_t off) {       // tables (k, k + 4) of one digit: an 8-byte entry
+                    return *reinterpret_cast<const uint2 *>(tab + ((3 + 2 * (k - 3)) << (SPLIT_TAB2_BITS + 2)) + off);
+                };
+                auto field8 = [&](int i) { return (D[i] >> sh3) & mask8; };
+#pragma unroll
+                for (int r = 0; r < RS; ++r)
+                    if (!(r & (hb | lb))) {
+                        const uint32_t l2 = field(r | hb), h0 = field(RS + r), h2 = field(RS + (r | hb));
+                        const uint2 pl1 = pair(3, field8(r | lb)), ph1 = pair(4, field8(RS + (r | lb)));
+                        const uint2 pl3 = pair(5, field8(r | hb | lb)), ph3 = pair(6, field8(RS + (r | hb | lb)));
+                        const int32_t x0 = __builtin_amdgcn_sbfe((int32_t)D[r], shift, width) + entry(0, h0);
+                        const int32_t A = entry(1, l2) + entry(2, h2);
+                        const int32_t S = ((int32_t)pl1.x + (int32_t)ph1.x) + ((int32_t)pl3.x + (int32_t)ph3.x);
+                        const int32_t T = ((int32_t)pl1.y + (int32_t)ph1.y) + ((int32_t)pl3.y + (int32_t)ph3.y);
+                        const int32_t uu = x0 + A, vv = x0 - A;
+                        x[r] = uu + S; x[r | lb] = uu - S; x[r | hb] = vv + T; x[r | hb | lb] = vv - T;
+                    }
+#else
 #pragma unroll
                 for (int r = 0; r < RS; ++r)
                     if (!(r & (hb | lb))) {
@@ -1010,6 +1041,7 @@ __global__ __launch_bounds__(512, (LOGN == 10 ? 4 : 2)) void blind_rotate_split_
                         const int32_t uu = x0 + A, vv = x0 - A;
                         x[r] = uu + S; x[r | lb] = uu - S; x[r | hb] = vv + T; x[r | hb | lb] = vv - T;
                     }
+#endif
             } else if constexpr (TAB) {
                 const uint32_t mask4 = ((1u << width) - 1u) << 2;
                 const int sh2 = shift - 2;
@@ -1615,10 +1647,10 @@ void launch_blind_rotate(hipStream_t s, const DevParams &p, const DevKey &key, c
         hipLaunchKernelGGL(blind_rotate_kernel<10>, dim3(count), dim3(128), 0, s, p, key, pool, rots, u_buf, acc_dbg);
 }
 
-// the LDS digit tables index by (D >> (shift - 2)) & mask: digits of at most DIGIT_TAB_BITS bits whose
-// lowest field starts at bit 2 or higher
+// the LDS digit tables index by (D >> (shift - 3)) & mask (8-byte entries): digits of at most DIGIT_TAB_BITS bits whose
+// lowest field starts at bit DIGIT_TAB_MIN_SHIFT or higher
 static bool digit_table_usable(const DevParams &p) {
-    return p.Bgbit <= DIGIT_TAB_BITS && p.digit_table != 0 && 32 - p.l * p.Bgbit >= 2;
+    return p.Bgbit <= DIGIT_TAB_BITS && p.digit_table != 0 && 32 - p.l * p.Bgbit >= DIGIT_TAB_MIN_SHIFT;
 }
 
 void launch_blind_rotate8(hipStream_t s, const DevParams &p, const DevKey &key, const int32_t *pool,

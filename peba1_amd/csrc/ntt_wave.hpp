@@ -66,6 +66,20 @@ struct PrimeCtx {
 // multiplier-class instructions of a group become five LDS reads of d * w mod P, indexed by the
 // digit's two's-complement bit field.  Rows: w1, w2, w1 w2, w3, P - w1 w3.
 constexpr int DIGIT_TAB_BITS = 7, DIGIT_TAB = 1 << DIGIT_TAB_BITS;
+// Round 4: S and S' both take the products of x1 (rows w2, w3) and of x3 (rows w1 w2, P - w1 w3),
+// so the two rows a digit indexes together are stored as ONE 8-byte entry: per group of four coefficients one
+// ds_read_b32 (row w1 by x2's digit) and two ds_read_b64 instead of five dword accesses -- the LDS array serves a
+// ds_read_b64 in the cycles of one ds_read_b32, and a data-dependent address pays its bank conflicts once, not twice
+// (SQ counters: profiles/r04_lds_conflict_attribution*.txt).  Layout of a table, in words:
+//   [0, DIGIT_TAB)                 w1 d
+//   [DIGIT_TAB, 3 DIGIT_TAB)       {w2 d, w3 d} per digit field
+//   [3 DIGIT_TAB, 5 DIGIT_TAB)     {w1 w2 d, (P - w1 w3) d} per digit field
+// BR_TAB_PAIRS=0 builds the round-3 layout (five rows of words) for A/B measurements.
+#ifndef BR_TAB_PAIRS
+#define BR_TAB_PAIRS 1
+#endif
+// the lowest digit field must start at this bit or higher for the table index to be a plain shift + mask
+constexpr int DIGIT_TAB_MIN_SHIFT = BR_TAB_PAIRS ? 3 : 2;
 
 // signed Montgomery reduction: T*R^-1 mod P, |result| <= |T|/2^32 + P/2
 __device__ __forceinline__ int32_t mont_redc(int64_t T, uint32_t P, uint32_t pinv) {
@@ -170,7 +184,26 @@ struct WaveNtt {
     static constexpr int RB = LOGN - 6;              // register bits
     static constexpr int REGS = 1 << RB;             // coefficients per lane
     static constexpr int LC = LOGN - 2 * RB;         // stages of the last pass
-    static constexpr int SCRATCH_WORDS = N + 4 * (64 >> LC);   // rows of REGS words, padded
+    static constexpr int ROW_WORDS = N + 4 * (64 >> LC);       // layout R: 64 rows of REGS words, a 16-byte pad every 2^LC rows
+    // Layout H, the inverse transform's transposes (round 4).  The inverse writes rows with ds_write_b128 and reads
+    // them back word by word, scattered -- it never reads a row with ds_read_b128, whose odd lane groups are what
+    // forces layout R's shape.  In layout R the row stores (8 contiguous lanes, banks mod 32, rows 16 words apart) and
+    // the L0 gather (four rows 16 words apart) are both two-way bank conflicts: at N = 1024, 96 of the LDS array's
+    // ~1,320 cycles per wave and blind-rotate step.  Layout H cuts a row into pieces of 8 words; piece c of all 64 rows
+    // is an array of its own with a 16-byte pad every 4 rows:
+    //     word (row, col)  ->  (col / 8) * HPIECE + 8 * row + 4 * (row / 4) + col % 8.
+    // Rows 8 words apart put the eight lanes of a b128 store group on eight different 16-byte slots and the four rows
+    // of a gather on four different 8-bank windows; the pads keep the second gather (rows 4 apart) conflict-free too
+    // (tools/lds_bank_model.py checks all of it against the bank rules of MI355X_MICROARCH.md).
+#ifndef BR_INV_LAYOUT_H
+#define BR_INV_LAYOUT_H 1
+#endif
+    static constexpr int HROW = REGS < 8 ? REGS : 8;
+    static constexpr int HPIECES = REGS / HROW;
+    // piece arrays 16 words off a multiple of 32 where a gather spans two pieces (N = 2048: 16 columns per half wave)
+    static constexpr int HPIECE = 64 * HROW + 4 * 16 + (HPIECES > 2 ? 16 : 0);
+    static constexpr int INV_WORDS = BR_INV_LAYOUT_H ? HPIECES * HPIECE : ROW_WORDS;
+    static constexpr int SCRATCH_WORDS = INV_WORDS > ROW_WORDS ? INV_WORDS : ROW_WORDS;   // a wave's transpose scratch
     static_assert(LOGN >= 9 && LOGN <= 11, "wave NTT is laid out for N = 512 (half of a split 1024-point transform), 1024 or 2048");
 
     // ---- transposes through wave-private LDS scratch ---------------------------
@@ -194,6 +227,25 @@ struct WaveNtt {
             const uint4 v = p[g];
             x[4 * g] = (T)v.x; x[4 * g + 1] = (T)v.y; x[4 * g + 2] = (T)v.z; x[4 * g + 3] = (T)v.w;
         }
+    }
+    // layout H (inverse transform only)
+    static __device__ __forceinline__ int h_addr(int row, int col) {
+        return (col / HROW) * HPIECE + HROW * row + 4 * (row >> 2) + (col % HROW);
+    }
+    static __device__ __forceinline__ void write_row_h(const int32_t (&x)[REGS], uint32_t *scr, int lane) {
+        uint32_t *base = scr + HROW * lane + 4 * (lane >> 2);
+#pragma unroll
+        for (int g = 0; g < REGS / 4; ++g)
+            *reinterpret_cast<uint4 *>(base + ((4 * g) / HROW) * HPIECE + (4 * g) % HROW) =
+                make_uint4((uint32_t)x[4 * g], (uint32_t)x[4 * g + 1], (uint32_t)x[4 * g + 2], (uint32_t)x[4 * g + 3]);
+    }
+    // (lane, reg) of the layout being entered -> where that word sits in layout H
+    static __device__ __forceinline__ int h_t2_addr(int lane, int reg) {      // L2 rows -> L1
+        const int j = ((lane >> LC) << (LOGN - RB)) | (reg << LC) | (lane & ((1 << LC) - 1));
+        return h_addr(j >> RB, j & (REGS - 1));
+    }
+    static __device__ __forceinline__ int h_t1_addr(int lane, int reg) {      // L1 rows -> L0
+        return h_addr((reg << LC) | (lane & ((1 << LC) - 1)), lane >> LC);
     }
     template <typename T>
     static __device__ __forceinline__ void write_row(const T (&x)[REGS], uint32_t *scr, int lane) {
@@ -448,6 +500,23 @@ struct WaveNtt {
             const uint32_t mask4 = ((1u << width) - 1u) << 2;            // byte offset of a table word
             const int sh = shift - 2;
             const char *tab = reinterpret_cast<const char *>(c.dtab);
+#if BR_TAB_PAIRS
+            const uint32_t mask8 = mask4 << 1;                           // byte offset of a pair
+            const int sh8 = shift - 3;
+            const char *tab1 = tab + DIGIT_TAB * 4, *tab3 = tab + 3 * DIGIT_TAB * 4;
+#pragma unroll
+            for (int r = 0; r < REGS; ++r)
+                if (!(r & (h | l))) {
+                    const int32_t x0 = __builtin_amdgcn_sbfe((int32_t)D[r], shift, width);
+                    const uint32_t i1 = (D[r | l] >> sh8) & mask8, i2 = (D[r | h] >> sh) & mask4, i3 = (D[r | h | l] >> sh8) & mask8;
+                    const int32_t A = (int32_t)*reinterpret_cast<const uint32_t *>(tab + i2);
+                    const uint2 p1 = *reinterpret_cast<const uint2 *>(tab1 + i1), p3 = *reinterpret_cast<const uint2 *>(tab3 + i3);
+                    const int32_t S = (int32_t)p1.x + (int32_t)p3.x;
+                    const int32_t T = (int32_t)p1.y + (int32_t)p3.y;
+                    const int32_t u = x0 + A, v = x0 - A;
+                    x[r] = u + S; x[r | l] = u - S; x[r | h] = v + T; x[r | h | l] = v - T;
+                }
+#else
             auto entry = [&](int k, uint32_t off) { return (int32_t)*reinterpret_cast<const uint32_t *>(tab + k * (DIGIT_TAB * 4) + off); };
 #pragma unroll
             for (int r = 0; r < REGS; ++r)
@@ -460,6 +529,7 @@ struct WaveNtt {
                     const int32_t u = x0 + A, v = x0 - A;
                     x[r] = u + S; x[r | l] = u - S; x[r | h] = v + T; x[r | h | l] = v - T;
                 }
+#endif
             forward_rest<EARLY, LDSTW>(x, c, scr, lane, t0);
         }
     }
@@ -505,7 +575,13 @@ struct WaveNtt {
         for (int e = tid; e < 5 * fields; e += nthreads) {
             const int k = e >> width, f = e & (fields - 1);
             const int32_t d = f < fields / 2 ? f : f - fields;
-            tab[k * DIGIT_TAB + f] = (uint32_t)mont_mul(d, w[k], c.P, c.pinv);
+#if BR_TAB_PAIRS
+            // k = 0: the word row; k = 1, 3 (w2, w3): halves of the pair x1's digit reads; k = 2, 4: of x3's
+            const int pos = k == 0 ? f : (k & 1 ? DIGIT_TAB : 3 * DIGIT_TAB) + 2 * f + (k > 2 ? 1 : 0);
+#else
+            const int pos = k * DIGIT_TAB + f;
+#endif
+            tab[pos] = (uint32_t)mont_mul(d, w[k], c.P, c.pinv);
         }
     }
 
@@ -517,19 +593,19 @@ struct WaveNtt {
         inv_pass<0>(x, c, t2);
         InvTw1 t1;
         if constexpr (EARLY) t1.load(c, lane);
-        write_row(x, scr, lane);
+        if constexpr (BR_INV_LAYOUT_H) write_row_h(x, scr, lane); else write_row(x, scr, lane);
         wave_lds_fence();
 #pragma unroll
-        for (int r = 0; r < REGS; ++r) x[r] = (int32_t)scr[t2_l1_addr(lane, r)];
+        for (int r = 0; r < REGS; ++r) x[r] = (int32_t)scr[BR_INV_LAYOUT_H ? h_t2_addr(lane, r) : t2_l1_addr(lane, r)];
         wave_lds_fence();
         if constexpr (!EARLY) t1.load(c, lane);
         inv_pass<steps_in(LC)>(x, c, t1);
         InvTw0 t0;
         if constexpr (EARLY) t0.load(c, lane);
-        write_row(x, scr, lane);
+        if constexpr (BR_INV_LAYOUT_H) write_row_h(x, scr, lane); else write_row(x, scr, lane);
         wave_lds_fence();
 #pragma unroll
-        for (int r = 0; r < REGS; ++r) x[r] = (int32_t)scr[t1_l0_addr(lane, r)];
+        for (int r = 0; r < REGS; ++r) x[r] = (int32_t)scr[BR_INV_LAYOUT_H ? h_t1_addr(lane, r) : t1_l0_addr(lane, r)];
         wave_lds_fence();
         if constexpr (!EARLY) t0.load(c, lane);
         inv_pass<steps_in(LC) + steps_in(RB)>(x, c, t0);

@@ -993,7 +993,22 @@ int tfhe_hip_flush_async(void) {
 int tfhe_hip_wait(void) {
     Recorder &r = rec();
     std::lock_guard<std::recursive_mutex> g(r.mtx);
-    return guarded_rc([&] { finish_flight_locked(); return 0; });
+    // the flush in flight, and the stream-ordered transfers nobody has waited for (an import behind a collective)
+    return guarded_rc([&] { finish_flight_locked(); Engine::get().sync_io(); return 0; });
+}
+int tfhe_hip_stream_sync(void) {
+    Recorder &r = rec();
+    std::lock_guard<std::recursive_mutex> g(r.mtx);
+    return guarded_rc([&] {
+        Engine::get().ensure_init();
+        finish_flight_locked();
+        Engine::get().sync_stream("tfhe_hip_stream_sync");
+        return 0;
+    });
+}
+void tfhe_hip_set_diag_label(const char *label) {
+    std::lock_guard<std::recursive_mutex> g(rec().mtx);
+    Engine::get().diag_label = label ? std::string(label).substr(0, 127) : std::string();
 }
 
 int tfhe_hip_gate_batch(int gate, LweSample *result, const LweSample *a, const LweSample *b, int32_t count,
@@ -1041,6 +1056,7 @@ int tfhe_hip_set_tuning(const char *name, int64_t value) {
     if (name && std::strcmp(name, "reuse_gates") == 0) { rec().reuse_gates = value != 0; return 0; }
     if (name && std::strcmp(name, "eliminate_dead") == 0) { rec().eliminate_dead = value != 0; return 0; }
     if (name && std::strcmp(name, "balance_levels") == 0) { rec().balance_levels = value != 0; return 0; }
+    if (name && std::strcmp(name, "sync_deadline_ms") == 0) { Engine::get().sync_deadline_ms = value > 0 ? (long long)value : 0; return 0; }
 #ifdef TFHE_HIP_EXPERIMENTAL
     if (name && std::strcmp(name, "lanes") == 0) { rec().lanes = value > 1 ? 2 : 1; return 0; }
     if (name && std::strcmp(name, "tight_slack") == 0) { rec().tight_slack = (int)value; return 0; }

@@ -8,7 +8,9 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libtfhe-hip.so")
+# PEBA1_TFHE_HIP_LIB: another build of the same library (tools/diag/build_variants.sh: A/B runs of kernel variants on one
+# box); it must exist like the default one -- there is no fallback either way
+LIB_PATH = os.environ.get("PEBA1_TFHE_HIP_LIB") or os.path.join(_HERE, "libtfhe-hip.so")
 CIRCUITS_PATH = os.path.join(_HERE, "libpeba1-circuits.so")
 
 

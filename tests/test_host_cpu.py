@@ -230,6 +230,31 @@ def test_default_randomness_is_chacha20_keyed_by_the_os():
     assert runs[0].stdout != runs[1].stdout                  # two processes, two key streams
 
 
+def test_secure_randomness_is_rekeyed_in_a_fork_child():
+    """a fork() child inherits the ChaCha20 state; without a re-key parent and child encrypt under identical
+    masks and noise.  The child handler of pthread_atfork makes the stream re-key itself: after a fork, the next
+    encryption of parent and child must differ in the mask words (host-only keyset: no GPU in the process)."""
+    code = ("import os, sys; sys.path.insert(0, %r)\n"
+            "from peba1_amd import api, lib\n"
+            "L = lib.load()\n"
+            "pp = api.ParameterSet(custom=(16, 64, 1, 3, 7, 8, 2, 1e-5, 1e-8, 0.01))\n"
+            "ks = api.SecretKeySet(pp, 5, device=False)\n"
+            "api.CiphertextArray(pp, 1).encrypt([1], ks)          # the secure streams exist and are mid-block\n"
+            "r, w = os.pipe()\n"
+            "pid = os.fork()\n"
+            "a = api.CiphertextArray(pp, 1).encrypt([1], ks)\n"
+            "words = a.words()[0].tolist(); assert list(a.decrypt(ks)) == [1]\n"
+            "if pid == 0:\n"
+            "    os.write(w, repr(words).encode()); os._exit(0)\n"
+            "os.waitpid(pid, 0)\n"
+            "child = eval(os.read(r, 1 << 16).decode())\n"
+            "assert child[:16] != words[:16], 'parent and child drew the same mask'\n"
+            "print('ok')\n" % ROOT)
+    import sys
+    run = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=120)
+    assert run.returncode == 0 and "ok" in run.stdout, run.stdout + run.stderr
+
+
 def test_parity_kit_files_are_what_the_oracle_produces():
     """tests/golden/parity_kit: the committed raw-word fixtures are exactly what make_kit.py
     regenerates from the oracle (schoolbook and two-prime evaluators agree inside it), and the product's seeded key

@@ -1,0 +1,20 @@
+#!/bin/bash
+# Builds libtfhe-hip variants that differ in compile-time switches of the kernels, for A/B runs on one box:
+#   tools/diag/build_variants.sh name1="-DBR_TAB_PAIRS=0" name2="-DBR_INV_LAYOUT_H=0" ...
+# -> tools/diag/_ab/libtfhe-hip-<name>.so (git-ignored; travels to the GPU box).  Select with PEBA1_TFHE_HIP_LIB.
+# Host objects come from the default build (run peba1_amd/csrc/build.sh first).
+set -euo pipefail
+ROOT=$(cd "$(dirname "$0")/../.." && pwd)
+S=$ROOT/peba1_amd/csrc; O=$ROOT/tools/diag/_ab; mkdir -p $O
+ROCM=${ROCM_PATH:-/opt/rocm}
+F="-O3 -std=c++17 -fPIC -ffp-contract=off -Wall -Wno-unused-result -mllvm -amdgpu-sched-strategy=max-ilp"
+for spec in "$@"; do
+  name=${spec%%=*}; defs=${spec#*=}
+  $ROCM/bin/hipcc $F $defs --offload-arch=gfx950 -c $S/kernels.hip -o $O/kernels-$name.o &
+done
+wait
+for spec in "$@"; do
+  name=${spec%%=*}
+  $ROCM/bin/hipcc -shared -Wl,-Bsymbolic-functions -o $O/libtfhe-hip-$name.so $O/kernels-$name.o $S/host_keys.o $S/engine.o $S/shim.o $S/scheduler.o $S/io.o
+  echo "built $O/libtfhe-hip-$name.so"
+done
