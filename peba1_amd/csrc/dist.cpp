@@ -378,9 +378,10 @@ int peba1_identify(Peba1Comm *c, LweSample *all, LweSample *mine, LweSample *con
     int rc = 0;
     if (c && (c->world > 1 || all)) {
         rc = gather_samples(c, all, mine, m_local, ck->params, local, why);
-    } else {
-        if (tfhe_hip_wait) (void)tfhe_hip_wait();
-        if (local != 0) rc = fail(why);
+    } else if (local != 0) {
+        // (no wait here: the last group stays in flight like the others -- a decrypt / export of the match bits, or the next
+        // call's first flush, completes it; a server streaming probe after probe keeps the device busy across calls)
+        rc = fail(why);
     }
     if (tfhe_hip_set_deferred && was_deferred == 0) tfhe_hip_set_deferred(0);
     return rc;

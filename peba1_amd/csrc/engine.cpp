@@ -366,7 +366,9 @@ SlotPool *Engine::find_pool(const Params &p) const {
 SlotPool *Engine::pool_for(const Params &p) {
     ensure_init();
     if (SlotPool *pl = find_pool(p)) return pl;
-    size_t cap = 1u << 21;   // 2,097,152 slots = 5.3 GB at n = 630 (HBM is 288 GB): ~9 matches in flight
+    // what the pool may GROW to (it starts at 65,536 slots and doubles on demand): 4,194,304 slots = 10.6 GB at n = 630 of
+    // 288 GB of HBM -- eight 128-slot matches recorded while the eight of the flush in flight are still pinned
+    size_t cap = 1u << 22;
     if (const char *env = std::getenv("TFHE_HIP_POOL_SLOTS")) cap = (size_t)std::atoll(env);
     // slot ids are packed into 29-bit fields by the recorder's table of pending gates (shim.cpp gate_key)
     if (cap < 8 || cap > MAX_POOL_SLOTS) {

@@ -564,6 +564,13 @@ __device__ __forceinline__ void blind_rotate4_body(const DevParams &p, const Dev
     STAMP_DECL;
     typename NTT::FwdTw0 t0;                 // first-pass twiddles of every forward transform: loaded once (forward_poly)
     t0.load(c, lane);
+#ifndef BR4_INV_TW0_HOIST
+#define BR4_INV_TW0_HOIST 0
+#endif
+#if BR4_INV_TW0_HOIST
+    typename NTT::InvTw0 it0;                // likewise the last pass of the inverse transform
+    it0.load(c, lane);
+#endif
 
     for (int i = 0; i < n; ++i) {
         if (p.fair_shift > 0) {
@@ -611,7 +618,11 @@ __device__ __forceinline__ void blind_rotate4_body(const DevParams &p, const Dev
             for (int r = 0; r < REGS; ++r) t[r] += other[r];       // |.| < 3.4P (the inverse takes < 4P)
         }
         if constexpr (TR::MERGED_BUFFERS) lds_barrier();          // partner has read my sums: the buffer is scratch again
+#if BR4_INV_TW0_HOIST
+        NTT::template inverse<TR::EARLY_TW>(t, c, scr, lane, t2, &it0);
+#else
         NTT::template inverse<TR::EARLY_TW>(t, c, scr, lane, t2);  // signed residues, |t| < P: recombined as they are
+#endif
         STAMP(4);
 
         // CRT of output poly u is split with wave (1-q,u): wave q recombines registers [q*HALF, (q+1)*HALF)
@@ -712,6 +723,9 @@ __device__ __forceinline__ uint32_t split_finish(int h, int32_t a0, int32_t a1, 
     return crt_signed_to_torus(mont_mul(a0 - a1, iw1_0, NTT_P0, NTT_PINV0), mont_mul(b0 - b1, iw1_1, NTT_P1, NTT_PINV1));
 }
 
+#ifndef BR8_INV_LAYOUT_H
+#define BR8_INV_LAYOUT_H false
+#endif
 template <int LOGN>
 struct Br8Lds {
     using NTT = WaveNtt<LOGN>;
@@ -821,7 +835,9 @@ __global__ __launch_bounds__(512, 2) void blind_rotate8_kernel(
                     else { t[4 * g] += (int32_t)v.x; t[4 * g + 1] += (int32_t)v.y; t[4 * g + 2] += (int32_t)v.z; t[4 * g + 3] += (int32_t)v.w; }
                 }
             }                                                           // |.| < 3.3P (the inverse takes < 4P)
-            SUB::template inverse<true>(t, ch, scr, lane, t2);          // half-transform outputs, natural order, |t| < P
+            // (layout R for this inverse: measured, round 4 -- with layout H the compiler's schedule of this kernel came out
+            // 0.13 ms per rotation slower, 2.87 against 2.74 ms, although H saves LDS cycles here too; profiles/r04_ab_*.txt)
+            SUB::template inverse<true, BR8_INV_LAYOUT_H>(t, ch, scr, lane, t2);   // half-transform outputs, natural order, |t| < P
 #pragma unroll
             for (int r = 0; r < RS; ++r) scr[r * 64 + lane] = (uint32_t)t[r];
         }

@@ -33,6 +33,7 @@ import numpy as np
 PARTIAL_BITS = 24
 FAST_COMBINE = 1
 FAST_PARTIAL = 2          # include/peba1_dist.h PEBA1_DIST_FAST_PARTIAL
+IDENTIFY_FAST = 1         # PEBA1_IDENTIFY_FAST
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 DIST_PATH = os.path.join(_HERE, "libpeba1-dist.so")
@@ -66,6 +67,10 @@ def load():
         D.peba1_sharded_partial_packed.argtypes = [V, V, I, I, V, V, I]
         D.peba1_sharded_combine_packed.argtypes = [V, V, I, V, V, I]
         D.peba1_dist_gather_samples.argtypes = [V, V, V, I, V]
+        D.peba1_identify.argtypes = [V, V, V, V, V, I, I, V, I, V, I, I]
+        D.peba1_dist_set_timeout.argtypes = [V, C.c_double]
+        D.peba1_dist_inject_failure.restype = None
+        D.peba1_dist_inject_failure.argtypes = [V, I]
         _dlib = D
     return _dlib
 
@@ -149,6 +154,14 @@ class Comm:
             load().peba1_dist_destroy(self.ptr)
             self.ptr = None
 
+    def set_timeout(self, seconds):
+        """Bound of every host wait behind a collective (peba1_dist_set_timeout; default PEBA1_DIST_TIMEOUT_S or 600 s)."""
+        _check(load().peba1_dist_set_timeout(self.ptr, float(seconds)), "peba1_dist_set_timeout")
+
+    def inject_failure(self, count=1):
+        """Test hook: this rank's next `count` collectives report a local failure (peba1_dist_inject_failure)."""
+        load().peba1_dist_inject_failure(self.ptr, int(count))
+
 
 def _flags(fast_combine, fast_partial):
     return (FAST_COMBINE if fast_combine else 0) | (FAST_PARTIAL if fast_partial else 0)
@@ -222,3 +235,14 @@ def sharded_match_logical(torch, gate_lib, circ_lib, params_ptr, cloud_ptr, word
 def gather_samples(comm, all_ptr, mine_ptr, count, params_ptr):
     """`count` ciphertexts of every rank -> rank 0, rank-major (identification: the match bits)."""
     _check(load().peba1_dist_gather_samples(comm.ptr, all_ptr, mine_ptr, count, params_ptr), "peba1_dist_gather_samples")
+
+
+def identify(comm, all_ptr, mine_ptr, probe_slots, template_slots, nslots, bound_ptr, bitsize, cloud_ptr, group=4, fast=False):
+    """1-to-N identification through the C ABI (peba1_identify): this rank's len(template_slots) / nslots matches of the
+    probe, `group` recorded per (pipelined) flush, the match bits left in `mine_ptr` and -- with a communicator --
+    gathered into `all_ptr` on rank 0.  `template_slots`: the slot arrays of all local templates, template-major."""
+    m_local = len(template_slots) // nslots
+    assert m_local * nslots == len(template_slots) and len(probe_slots) == nslots
+    _check(load().peba1_identify(comm.ptr if comm is not None else None, all_ptr, mine_ptr, _ptr_array(probe_slots),
+                                 _ptr_array(template_slots), m_local, nslots, bound_ptr, bitsize, cloud_ptr, group,
+                                 IDENTIFY_FAST if fast else 0), "peba1_identify")

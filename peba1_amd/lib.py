@@ -122,6 +122,8 @@ SIGNATURES = {
     "tfhe_hip_flush": (C.c_int, []),
     "tfhe_hip_flush_async": (C.c_int, []),
     "tfhe_hip_wait": (C.c_int, []),
+    "tfhe_hip_stream_sync": (C.c_int, []),
+    "tfhe_hip_set_diag_label": (None, [C.c_char_p]),
     "tfhe_hip_gate_batch": (C.c_int, [C.c_int, LS, LS, LS, C.c_int32, CK]),
     "tfhe_hip_set_tuning": (C.c_int, [C.c_char_p, C.c_int64]),
     "tfhe_hip_has_experimental": (C.c_int, []),

@@ -7,6 +7,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <string>
 #include <vector>
 
 #include "peba1_dist.h"
@@ -74,6 +75,88 @@ int main(int argc, char **argv) {
         if (bit != (d > bound ? 1 : 0)) { std::printf("pass %d: bit %d, distance %ld, bound %ld\n", pass, bit, d, bound); return 1; }
         delete_gate_bootstrapping_ciphertext_array(24, result_b);
         delete_gate_bootstrapping_ciphertext_array(24, enc_bound);
+    }
+    // ---- failure containment: rank 1 fails locally -- it must still enter the exchange, so that
+    // nobody is left inside it; it returns -1 with its own message and rank 0 returns -1 naming it
+    if (world >= 2) {
+        g_mail.assign((size_t)world, {});
+        LweSample *result_b = new_gate_bootstrapping_ciphertext_array(24, pp);
+        LweSample *enc_bound = encrypt_number(1u, 24, pp, key);
+        std::vector<int> ranks;
+        for (int r = 1; r < world; ++r) ranks.push_back(r);
+        ranks.push_back(0);
+        for (int rank : ranks) {
+            int lo, hi;
+            peba1_dist_shard_slots(nslots, world, rank, &lo, &hi);
+            std::vector<LweSample *> S, T;
+            for (int i = lo; i < hi; ++i) { S.push_back(encrypt_number(probe[i], bitsize, pp, key)); T.push_back(encrypt_number(tmpl[i], bitsize, pp, key)); }
+            Peba1Comm *comm = peba1_dist_init_host(gather_cb, &rank, world, rank);
+            if (rank == 1) peba1_dist_inject_failure(comm, 1);
+            const int rc = peba1_sharded_function_f(comm, rank == 0 ? result_b : nullptr, S.data(), T.data(), hi - lo,
+                                                    rank == 0 ? enc_bound : nullptr, bitsize, ck, 0);
+            const std::string msg = peba1_dist_last_error();
+            const bool expect_fail = rank == 0 || rank == 1;
+            if ((rc != 0) != expect_fail) { std::printf("containment: rank %d returned %d (%s)\n", rank, rc, msg.c_str()); return 1; }
+            if (rank == 1 && msg.find("injected failure") == std::string::npos) { std::printf("containment: rank 1 says '%s'\n", msg.c_str()); return 1; }
+            if (rank == 0 && msg.find("rank 1 reported a failure") == std::string::npos) { std::printf("containment: rank 0 says '%s'\n", msg.c_str()); return 1; }
+            if (g_mail[(size_t)rank].empty()) { std::printf("containment: rank %d never entered the exchange\n", rank); return 1; }
+            peba1_dist_destroy(comm);
+            for (LweSample *p : S) delete_gate_bootstrapping_ciphertext_array(bitsize, p);
+            for (LweSample *p : T) delete_gate_bootstrapping_ciphertext_array(bitsize, p);
+        }
+        delete_gate_bootstrapping_ciphertext_array(24, result_b);
+        delete_gate_bootstrapping_ciphertext_array(24, enc_bound);
+    }
+    // ---- 1-to-N identification from the C++ host (BASELINE configs[3]): every rank matches the probe
+    // against its 3 templates, 2 recorded per flush; the match bits of all ranks arrive on rank 0
+    {
+        const int m_local = 3, ns = 4;
+        std::vector<unsigned> pr(ns);
+        for (int i = 0; i < ns; ++i) pr[i] = (91u * i + 5) % 256;
+        const unsigned bound = 300;
+        g_mail.assign((size_t)world, {});
+        std::vector<int> expect((size_t)world * m_local);
+        LweSample *all = new_gate_bootstrapping_ciphertext_array(world * m_local, pp);
+        std::vector<int> ranks;
+        for (int r = 1; r < world; ++r) ranks.push_back(r);
+        ranks.push_back(0);
+        for (int rank : ranks) {
+            std::vector<LweSample *> P, T;
+            for (int i = 0; i < ns; ++i) P.push_back(encrypt_number(pr[i], bitsize, pp, key));
+            for (int m = 0; m < m_local; ++m) {
+                long dd = 0;
+                for (int i = 0; i < ns; ++i) {
+                    // template (rank, m): the probe itself for (0, 1) -- the genuine match -- else shifted values
+                    const unsigned v = (rank == 0 && m == 1) ? pr[i] : (pr[i] + 7u * (unsigned)(rank * m_local + m + 1) + 3u * (unsigned)i) % 256;
+                    T.push_back(encrypt_number(v, bitsize, pp, key));
+                    dd += ((long)pr[i] - (long)v) * ((long)pr[i] - (long)v);
+                }
+                expect[(size_t)rank * m_local + m] = dd > (long)bound ? 1 : 0;
+            }
+            LweSample *enc_bound = encrypt_number(bound, 24, pp, key);
+            LweSample *mine = new_gate_bootstrapping_ciphertext_array(m_local, pp);
+            Peba1Comm *comm = peba1_dist_init_host(gather_cb, &rank, world, rank);
+            if (peba1_identify(comm, rank == 0 ? all : nullptr, mine, P.data(), T.data(), m_local, ns, enc_bound, bitsize, ck,
+                               2, rank & 1 ? PEBA1_IDENTIFY_FAST : 0) != 0) {
+                std::printf("identify rank %d: %s\n", rank, peba1_dist_last_error());
+                return 1;
+            }
+            for (int m = 0; m < m_local; ++m)
+                if (bootsSymDecrypt(mine + m, key) != expect[(size_t)rank * m_local + m]) { std::printf("identify: rank %d match %d\n", rank, m); return 1; }
+            peba1_dist_destroy(comm);
+            delete_gate_bootstrapping_ciphertext_array(m_local, mine);
+            delete_gate_bootstrapping_ciphertext_array(24, enc_bound);
+            for (LweSample *p : P) delete_gate_bootstrapping_ciphertext_array(bitsize, p);
+            for (LweSample *p : T) delete_gate_bootstrapping_ciphertext_array(bitsize, p);
+        }
+        int zeros = 0;
+        for (int k = 0; k < world * m_local; ++k) {
+            const int bit = bootsSymDecrypt(all + k, key);
+            if (bit != expect[(size_t)k]) { std::printf("identify: gathered bit %d is %d\n", k, bit); return 1; }
+            zeros += bit == 0;
+        }
+        if (expect[1] != 0 || zeros < 1) { std::printf("identify: the genuine template did not match\n"); return 1; }
+        delete_gate_bootstrapping_ciphertext_array(world * m_local, all);
     }
     // bad arguments are reported, not fatal
     if (peba1_dist_init_host(nullptr, nullptr, 2, 0) != nullptr || !*peba1_dist_last_error()) return 1;

@@ -45,7 +45,26 @@ S = [enc(probe[i], 8) for i in range(lo, hi)]
 T = [enc(tmpl[i], 8) for i in range(lo, hi)]
 bound = enc(int(os.environ["PEBA1_BOUND"]), 24)
 fast = os.environ.get("PEBA1_FAST") == "1"
-res = pd.sharded_match(dist, torch, gate, circ, params, cloud, 2, S, T, bound, 8, device="cpu", fast_combine=fast, fast_partial=fast)
+inject = int(os.environ.get("PEBA1_INJECT", "-1"))
+if inject >= 0:
+    # failure containment: rank `inject` fails locally; every rank must come back from the collective call -- the
+    # failed one and rank 0 with an error that says what happened, the others clean -- and nobody hangs in the gather
+    comm = pd.Comm(dist, torch, "cpu")
+    if rank == inject:
+        comm.inject_failure(1)
+    try:
+        pd.sharded_match(dist, torch, gate, circ, params, cloud, 2, S, T, bound, 8, device="cpu", comm=comm)
+        outcome = "clean"
+    except RuntimeError as e:
+        outcome = str(e)
+    want = "injected failure" if rank == inject else (f"rank {inject} reported a failure" if rank == 0 else "clean")
+    assert want in outcome, (rank, outcome)
+    # the communicator stays usable: the next match goes through
+    res = pd.sharded_match(dist, torch, gate, circ, params, cloud, 2, S, T, bound, 8, device="cpu", comm=comm)
+    comm.close()
+    print("CONTAINED", rank, flush=True)
+else:
+    res = pd.sharded_match(dist, torch, gate, circ, params, cloud, 2, S, T, bound, 8, device="cpu", fast_combine=fast, fast_partial=fast)
 if rank == 0:
     bit = gate.bootsSymDecrypt(res, key)
     d = sum((a - b) ** 2 for a, b in zip(probe, tmpl))
@@ -91,6 +110,20 @@ def test_sharded_match_gloo(built, world, case, bound, fast):
                          env=env, capture_output=True, text=True, timeout=300)
     assert out.returncode == 0, out.stdout + out.stderr
     assert "OK" in out.stdout
+
+
+@pytest.mark.parametrize("world,inject", [(2, 1), (3, 2), (3, 0)])
+def test_a_local_failure_is_contained_around_the_gather(built, world, inject):
+    """VERDICT r3 item 3 / ADVICE r3: a rank that fails before the exchange still enters it (status word in front of its
+    payload), so the others are not left inside the collective: the failed rank and rank 0 get -1 with a message naming
+    what happened, the rest return clean, and the same communicator then runs a match normally."""
+    env = dict(os.environ, PEBA1_ROOT=ROOT, PEBA1_TMP=built, PEBA1_SLOTS="7", PEBA1_CASE="impostor",
+               PEBA1_BOUND="256", PEBA1_FAST="0", PEBA1_INJECT=str(inject), MASTER_ADDR="127.0.0.1")
+    out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={world}",
+                          "--master-addr", "127.0.0.1", "--master-port", str(29650 + 3 * world + inject), built + "/worker.py"],
+                         env=env, capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stdout + out.stderr
+    assert out.stdout.count("CONTAINED") == world and "OK" in out.stdout
 
 
 LOGICAL_WORKER = r'''

@@ -134,9 +134,110 @@ def test_sharded_match_over_rccl_world1(p128_keys):
         res_ls = C.cast(res, lib.LS)
         assert L.bootsSymDecrypt(res_ls, ks.ptr) == 1               # d > d-1
         L.delete_gate_bootstrapping_ciphertext_array(24, res_ls)
+        # the status word (round 4): every collective of libpeba1-dist first all-gathers one status word per rank over
+        # RCCL, so a rank that failed locally makes every rank return -1 instead of leaving the others in the gather.
+        # The match above went through it; here this rank reports a failure -- nobody enters the gather, the call returns
+        # -1 naming the rank -- and the communicator then runs a match normally
+        comm = pd.Comm(dist, torch, "cuda")
+        try:
+            comm.inject_failure(1)
+            api.set_deferred(True)
+            with pytest.raises(RuntimeError, match=r"rank 0 \(this rank\) failed before the gather: injected failure"):
+                pd.sharded_match(dist, torch, L, circuits.load(), pp.ptr, ks.cloud, pp.words, [a.ptr for a in S.slots],
+                                 [a.ptr for a in T.slots], bound.ptr, 8, device="cuda", comm=comm)
+            res = pd.sharded_match(dist, torch, L, circuits.load(), pp.ptr, ks.cloud, pp.words, [a.ptr for a in S.slots],
+                                   [a.ptr for a in T.slots], bound.ptr, 8, device="cuda", comm=comm, fast_combine=True)
+            api.set_deferred(False)
+            res_ls = C.cast(res, lib.LS)
+            assert L.bootsSymDecrypt(res_ls, ks.ptr) == 1
+            L.delete_gate_bootstrapping_ciphertext_array(24, res_ls)
+            # identification through the C ABI with the gather to rank 0 (peba1_identify): 3 matches, 2 per flush
+            tv = [[100, 3], [90, 7], [91, 9]]
+            templates = [circuits.EncryptedVector(pp, t, 8, ks) for t in tv]
+            from peba1_amd import identify
+            all_bits = api.CiphertextArray(pp, 3)
+            ib = circuits.encrypt_number(pp, 5, 24, ks)
+            bits = identify.identify(pp, ks, S, templates, ib, 8, group=2, comm=comm, all_bits=all_bits)
+            want = [1 if sum((a - b) ** 2 for a, b in zip(probe_v, t)) > 5 else 0 for t in tv]
+            assert [int(b) for b in all_bits.decrypt(ks)] == want == [int(b) for b in bits.decrypt(ks)] and want == [1, 0, 1]
+        finally:
+            comm.close()
     finally:
         api.set_deferred(False)
         dist.destroy_process_group()
+
+
+def test_decrypt_is_ordered_behind_a_stream_ordered_import(p128_keys):
+    """tfhe_hip_import_samples_device_async only ENQUEUES the scatter into the slots -- behind whatever
+    the caller put on tfhe_hip_stream() before it (libpeba1-dist: an ncclGather that waits for remote ranks).  A decrypt
+    right after it used a blocking copy on the null stream, which the library's non-blocking stream does not order: it
+    read the slot before the scatter had written it.  Here the words reach the import's source buffer only after ~50 ms
+    of other work on the library's stream; the decrypts that follow at once must see them."""
+    import numpy as np
+    import torch
+    from peba1_amd import api, lib
+    pp, ks, _ = p128_keys
+    L = lib.load()
+    L.tfhe_hip_set_encrypt_seed(4711)
+    n = 64
+    bits = np.arange(n) % 3 == 0
+    src = api.CiphertextArray(pp, n).encrypt(bits.astype(int), ks)
+    words = torch.from_numpy(np.ascontiguousarray(src.words())).cuda()
+    stream = torch.cuda.ExternalStream(L.tfhe_hip_stream())
+    staging = torch.zeros_like(words)
+    busy = torch.randn(4096, 4096, device="cuda")
+    torch.cuda.synchronize()
+    dst = api.CiphertextArray(pp, n)
+    with torch.cuda.stream(stream):
+        for _ in range(40):                       # the "remote ranks": tens of milliseconds on the library's stream
+            busy = busy @ busy * 1e-3
+        staging.copy_(words)                      # ... and only then do the words exist
+    rc = L.tfhe_hip_import_samples_device_async(dst.ptr, n, pp.ptr, C.c_void_p(staging.data_ptr()))
+    assert rc == 0
+    got = dst.decrypt(ks)                         # immediately: no tfhe_hip_wait, no synchronize
+    assert list(got) == list(bits.astype(int))
+    # the same through the host mirror
+    dst2 = api.CiphertextArray(pp, n)
+    staging.zero_()
+    with torch.cuda.stream(stream):
+        for _ in range(40):
+            busy = busy @ busy * 1e-3
+        staging.copy_(words)
+    assert L.tfhe_hip_import_samples_device_async(dst2.ptr, n, pp.ptr, C.c_void_p(staging.data_ptr())) == 0
+    assert L.tfhe_hip_sync_samples(dst2.ptr, n) == 0
+    assert (dst2.words() == src.words()).all()
+    assert L.tfhe_hip_wait() == 0 and L.tfhe_hip_stream_sync() == 0
+    torch.cuda.synchronize()
+
+
+def test_a_host_wait_past_its_deadline_ends_the_process_with_a_message():
+    """with "sync_deadline_ms" set, a host wait on the library's stream that outlasts the deadline
+    -- here a 2,048-gate launch (~20 ms) against a deadline of 1 ms, standing in for a collective whose peer never arrived
+    -- prints what was waited for and by whom and exits with TFHE_HIP_EXIT_DEADLINE (86): non-zero, no retry.  In a child
+    process: the exit is the point."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = ("import sys; sys.path.insert(0, %r)\n"
+            "import numpy as np\n"
+            "from peba1_amd import api, lib\n"
+            "L = lib.load()\n"
+            "pp = api.ParameterSet(128); ks = api.SecretKeySet(pp, 0x5EBA2, device=True)\n"
+            "api.set_deferred(False)\n"
+            "G = 2048\n"
+            "a = api.CiphertextArray(pp, G).encrypt(np.ones(G, int), ks); b = api.CiphertextArray(pp, G).encrypt(np.ones(G, int), ks)\n"
+            "r = api.CiphertextArray(pp, G)\n"
+            "api.gate_batch('AND', r, a, b, ks)                       # no deadline: completes\n"
+            "assert int(r.decrypt(ks)[0]) == 1\n"
+            "L.tfhe_hip_set_diag_label(b'rank 3 of 8 (test)')\n"
+            "api.set_tuning('sync_deadline_ms', 1)\n"
+            "print('armed', flush=True)\n"
+            "api.gate_batch('AND', r, a, b, ks)                       # ~20 ms of kernels behind a 1 ms deadline\n"
+            "print('NOT REACHED', flush=True)\n" % root)
+    run = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300)
+    assert run.returncode == 86, (run.returncode, run.stdout[-500:], run.stderr[-1500:])
+    assert "armed" in run.stdout and "NOT REACHED" not in run.stdout
+    assert "did not complete within 1 ms on rank 3 of 8 (test)" in run.stderr
 
 
 @pytest.mark.parametrize("fixture,circuit,lanes", [("function_f_digest.json", "function_f", 1),

@@ -292,15 +292,16 @@ def test_cfg4_identification_streams_matches_through_bounded_flushes(p128_keys):
 def test_cfg4_identification_at_the_per_gpu_size_of_configs3(p128_keys):
     """BASELINE configs[3] at its own per-GPU size (only the builder had run it): ONE probe against 128
     enrolled 128-slot x 8-bit templates -- 128 independent runs of the reference's Function_f, 27.6 M blind rotations
-    -- streamed through the slot pool four matches per flush (32 flushes), every one of the 128 decrypted match bits
-    equal to the plaintext rule and the genuine template the only 0.  About five minutes on one MI355X."""
+    -- streamed through the slot pool eight matches per flush (16 pipelined flushes, libpeba1-dist's peba1_identify), every one
+    of the 128 decrypted match bits equal to the plaintext rule and the genuine template the only 0.  About four minutes on
+    one MI355X."""
     import sys
     import time
     from peba1_amd import api, circuits, identify, lib
     pp, ks, _ = p128_keys
     L = lib.load()
     L.tfhe_hip_set_encrypt_seed(4096)
-    nslots, M, group = 128, 128, 4
+    nslots, M, group = 128, 128, 8
     base = [(37 * i + 11) % 255 or 1 for i in range(nslots)]
     probe_v = [v + 1 for v in base]
     templates_v = [identify.synthetic_template(base, k + 1) for k in range(M)]
@@ -406,3 +407,9 @@ def test_bench_multi_process_default_mode_rehearsal():
     # all ranks' rotations are counted: 8 slots of the reference's loop, one adder on rank 0, the comparator
     rotations = j["value"] * j["ms_per_step"] / 1e3
     assert 8 * 1683 - 1 <= rotations <= 8 * 1683 + 1000, rotations
+    # ... and the same line carries the weak-scaling leg: every rank's own 8 independent matches through
+    # peba1_identify, the match bits gathered to rank 0 and checked there (one 0 among 16: the genuine template)
+    w = j["weak_scaling"]
+    assert w["n_gpus"] == 2 and w["matches_per_gpu"] == 8 and w["scaling"] == "weak"
+    per_match = w["gates_per_s_all_ranks"] * w["seconds"] / 16
+    assert 8 * 1683 <= per_match <= 8 * 1683 + 400, per_match
