@@ -258,15 +258,17 @@ struct AccLds {
     template <int REGS>
     __device__ __forceinline__ void rotated_difference(uint32_t (&D)[REGS], int u, int lane, int abar, uint32_t offset) const {
         const uint32_t base = (uint32_t)(lane - abar) & (uint32_t)(2 * N - 1);
-        const uint32_t *own = w[u] + lane;
+        // -ACC comes from the negated run, so that rot - acc + offset is ONE three-operand add (v_add3_u32) instead of a
+        // subtraction and an addition (round 4: 16 VALU instructions less per wave and step)
+        const uint32_t *own_neg = w[u] + N + lane;
         if constexpr (RUNS == 3) {
             const uint32_t *rot = w[u] + base;
 #pragma unroll
-            for (int r = 0; r < REGS; ++r) D[r] = (rot[r * 64] - own[r * 64] + offset) ^ offset;
+            for (int r = 0; r < REGS; ++r) D[r] = (rot[r * 64] + own_neg[r * 64] + offset) ^ offset;
         } else {
 #pragma unroll
             for (int r = 0; r < REGS; ++r)
-                D[r] = (w[u][(base + r * 64) & (uint32_t)(2 * N - 1)] - own[r * 64] + offset) ^ offset;
+                D[r] = (w[u][(base + r * 64) & (uint32_t)(2 * N - 1)] + own_neg[r * 64] + offset) ^ offset;
         }
     }
 };
@@ -564,13 +566,6 @@ __device__ __forceinline__ void blind_rotate4_body(const DevParams &p, const Dev
     STAMP_DECL;
     typename NTT::FwdTw0 t0;                 // first-pass twiddles of every forward transform: loaded once (forward_poly)
     t0.load(c, lane);
-#ifndef BR4_INV_TW0_HOIST
-#define BR4_INV_TW0_HOIST 0
-#endif
-#if BR4_INV_TW0_HOIST
-    typename NTT::InvTw0 it0;                // likewise the last pass of the inverse transform
-    it0.load(c, lane);
-#endif
 
     for (int i = 0; i < n; ++i) {
         if (p.fair_shift > 0) {
@@ -618,11 +613,9 @@ __device__ __forceinline__ void blind_rotate4_body(const DevParams &p, const Dev
             for (int r = 0; r < REGS; ++r) t[r] += other[r];       // |.| < 3.4P (the inverse takes < 4P)
         }
         if constexpr (TR::MERGED_BUFFERS) lds_barrier();          // partner has read my sums: the buffer is scratch again
-#if BR4_INV_TW0_HOIST
-        NTT::template inverse<TR::EARLY_TW>(t, c, scr, lane, t2, &it0);
-#else
+        // (the last pass's lane-uniform twiddles loaded once per kernel instead of per step, like the forward ones:
+        // measured, no gain -- 37.30 against 37.37 ms on one box, profiles/r04_ab_kernel_variants.txt -- and 25 scalar registers)
         NTT::template inverse<TR::EARLY_TW>(t, c, scr, lane, t2);  // signed residues, |t| < P: recombined as they are
-#endif
         STAMP(4);
 
         // CRT of output poly u is split with wave (1-q,u): wave q recombines registers [q*HALF, (q+1)*HALF)

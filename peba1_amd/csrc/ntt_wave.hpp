@@ -588,11 +588,9 @@ struct WaveNtt {
     // inverse NTT (unscaled: the 1/N is folded into the key image):
     // x in L2, |x| < 4P -> L0 (natural order), |x| < P.  t2: the first pass's twiddles (InvTw2), as above
     // LAYOUT_H: the transposes go through layout H (above; scr must hold INV_WORDS words) instead of layout R
-    // pre0: the last pass's twiddles (InvTw0: lane-uniform and the same for every step, like FwdTw0), loaded by the caller
-    // once per kernel; null = loaded here
     template <bool EARLY = true, bool LAYOUT_H = (BR_INV_LAYOUT_H != 0)>
     static __device__ __forceinline__ void inverse(int32_t (&x)[REGS], const PrimeCtx &c, uint32_t *scr, int lane,
-                                                   const InvTw2 &t2, const InvTw0 *pre0 = nullptr) {
+                                                   const InvTw2 &t2) {
         inv_pass<0>(x, c, t2);
         InvTw1 t1;
         if constexpr (EARLY) t1.load(c, lane);
@@ -604,14 +602,14 @@ struct WaveNtt {
         if constexpr (!EARLY) t1.load(c, lane);
         inv_pass<steps_in(LC)>(x, c, t1);
         InvTw0 t0;
-        if (!pre0) { if constexpr (EARLY) t0.load(c, lane); }
+        if constexpr (EARLY) t0.load(c, lane);
         if constexpr (LAYOUT_H) write_row_h(x, scr, lane); else write_row(x, scr, lane);
         wave_lds_fence();
 #pragma unroll
         for (int r = 0; r < REGS; ++r) x[r] = (int32_t)scr[LAYOUT_H ? h_t1_addr(lane, r) : t1_l0_addr(lane, r)];
         wave_lds_fence();
-        if (!pre0) { if constexpr (!EARLY) t0.load(c, lane); }
-        inv_pass<steps_in(LC) + steps_in(RB)>(x, c, pre0 ? *pre0 : t0);
+        if constexpr (!EARLY) t0.load(c, lane);
+        inv_pass<steps_in(LC) + steps_in(RB)>(x, c, t0);
     }
     template <bool EARLY = true>
     static __device__ __forceinline__ void inverse(int32_t (&x)[REGS], const PrimeCtx &c, uint32_t *scr, int lane) {

@@ -152,7 +152,7 @@ def test_sharded_match_over_rccl_world1(p128_keys):
             assert L.bootsSymDecrypt(res_ls, ks.ptr) == 1
             L.delete_gate_bootstrapping_ciphertext_array(24, res_ls)
             # identification through the C ABI with the gather to rank 0 (peba1_identify): 3 matches, 2 per flush
-            tv = [[100, 3], [90, 7], [91, 9]]
+            tv = [[100, 3], [90, 7], [92, 9]]
             templates = [circuits.EncryptedVector(pp, t, 8, ks) for t in tv]
             from peba1_amd import identify
             all_bits = api.CiphertextArray(pp, 3)

@@ -5,7 +5,7 @@
 #   gpurun --timeout 1200 -- 'bash tools/gpu_profile.sh r03'
 # Counter passes never carry a trace option (gpurun refuses --pmc with trace domains).
 set -o pipefail
-TAG=${1:-r03}
+TAG=${1:-r04}
 OUT=gpurun_out/prof_$TAG; mkdir -p $OUT
 export TMPDIR=/tmp
 B="python3 bench.py --extras 0 --no-cpu-baseline"
