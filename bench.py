@@ -138,6 +138,14 @@ def cpu_baseline(seed):
     # the box's real width (SURVEY 8d asks for all cores): the same independent gates, 4 per visible CPU.  The figure
     # above is one GPU's share of the host (16 threads); this one is the whole host the GPU sits in
     visible = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    quota = None                                  # CPUs the container may actually use at once (cgroup v2 cpu.max), if limited
+    try:
+        with open("/sys/fs/cgroup/cpu.max") as f:
+            q, per = f.read().split()[:2]
+            if q != "max":
+                quota = float(q) / float(per)
+    except (OSError, ValueError):
+        pass
     all_cores = None
     if visible > cores:
         reps = max(1, (4 * visible + count - 1) // count)
@@ -148,7 +156,10 @@ def cpu_baseline(seed):
         k = min(count, 4 * visible, 32)
         assert (outw[:k] == out[:k]).all()             # the same gates give the same words
         all_cores = {"threads": visible, "value": 4 * visible / dtw, "unit": "bootstrapped gates/s",
-                     "sample": f"{4 * visible} independent bootsAND, 4 per thread"}
+                     "sample": f"{4 * visible} independent bootsAND, 4 per thread", "cgroup_cpu_quota": quota,
+                     "note": "one thread per CPU the process may be scheduled on; where the container's CPU quota is smaller "
+                             "than that (cgroup_cpu_quota), the threads share the quota and this figure measures the quota, "
+                             "not the host"}
     model = "unknown"
     try:
         with open("/proc/cpuinfo") as f:
@@ -559,6 +570,7 @@ def extras(api, circuits, identify, lib, pd, pp, ks, probe, tmpl, bound, base, p
     api.reset_stats()
     t = time.perf_counter()
     bits = identify.identify(pp, ks, probe, templates, bound, bitsize, group=4)
+    api.wait()                                   # peba1_identify leaves its last group in flight
     t = time.perf_counter() - t
     s = api.stats()
     assert [int(b) for b in bits.decrypt(ks)] == [plain_bit(v) for v in tv]

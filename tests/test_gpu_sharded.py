@@ -169,12 +169,13 @@ def test_cfg3_256_slots_over_8_ranks_ciphertexts_match_oracle_digest(p128_keys):
         L.delete_gate_bootstrapping_ciphertext_array(24, ls)
 
 
-@pytest.mark.parametrize("world", [2, 4, 8])
+@pytest.mark.parametrize("world", [2, 4])
 def test_cfg3_256_slot_match_sharded_over_logical_ranks(p128_keys, world):
     """BASELINE configs[2] at size: 256 slots x 8 bit, uniform bytes, `world` logical ranks of
     256/world slots each.  Every rank's decrypted partial sum equals the plaintext sum of squares
     of its slot range, their total is the distance, and the match bit is (distance > bound)
-     on both sides of the threshold."""
+     on both sides of the threshold.  (World 8, the configuration BASELINE names, is the digest test
+    above: every exchanged partial sum and both combines word for word against the oracle.)"""
     import random
     import torch
     from peba1_amd import api, circuits, lib
