@@ -146,6 +146,10 @@ public:
     // 1 = the coefficient ranges of a key switch add their partial sums into the (zeroed) destination slot with
     // 32-bit atomic adds instead of writing them out for a reduce launch (env TFHE_HIP_KS_ATOMIC, tuning "ks_atomic")
     int ks_atomic = 0;
+    // 1 = the tiled key switch gives a thread 2 words of the row instead of 4: 5 light waves per workgroup at n = 630
+    // instead of 3 heavy ones (kernels.hip keyswitch_tile_kernel W; env TFHE_HIP_KS_NARROW, tuning "ks_narrow"); measured
+    // slower (126 against 111 ms per match), so off
+    int ks_narrow = 0;
     // two-lane execution: 1 = the urgent lane's blind-rotate waves raise their issue priority
     // (measured slower: the co-resident workgroups of the other lane become its stragglers)
     int lane_prio = 0;

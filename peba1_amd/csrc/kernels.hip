@@ -1479,14 +1479,25 @@ __global__ __launch_bounds__(KS_MAX_THREADS) void ks_reduce_kernel(DevParams p, 
 // LDS word per (gate, coefficient), the same for all lanes.  Needs ks_t = 8,
 // ks_basebit = 2 (every built-in parameter set) and at most 64 coefficients per range;
 // partial sums go through ks_reduce_kernel as above.
-typedef uint32_t v4u32 __attribute__((ext_vector_type(4)));
+// W: words of the row a thread owns.  W = 4 (the default): one 16-byte column per thread, 3 waves per workgroup at n = 630,
+// ~190 VGPRs -> two waves per SIMD.  W = 2 (round 4, tuning "ks_narrow"): 5 waves per workgroup, 98 VGPRs -> four waves
+// per SIMD, the same LDS bytes and subtractions spread over more resident waves -- measured SLOWER, 126 against 111 ms per
+// match (tile 32 with it: 147 ms; profiles/r04_ks_tile.txt): the loop is bound by LDS instruction issue, and W = 2 issues
+// twice the reads for the same bytes.  Kept selectable and tested.  Also tried in round 4 and dropped: the rows in REGISTER
+// banks picked by the wave-uniform digit through the VGPR index mode (s_set_gpr_idx_on) -- no LDS access at all on paper;
+// the compiler either moves a dynamically indexed array to scratch memory or, for a 16-word vector value, re-assembles the
+// register tuple with 16 moves in front of every indexed read.  Not reachable from HIP source.
+template <int W> struct KsVec;
+template <> struct KsVec<4> { typedef uint32_t type __attribute__((ext_vector_type(4))); };
+template <> struct KsVec<2> { typedef uint32_t type __attribute__((ext_vector_type(2))); };
 
-template <int THREADS, int G, bool ATOMIC = false>
+template <int THREADS, int G, bool ATOMIC = false, int W = 4>
 __global__ __launch_bounds__(THREADS) void keyswitch_tile_kernel(DevParams p, DevKey key, const int32_t *__restrict__ u_buf,
                                                               const KsDesc *__restrict__ descs, int count,
                                                               int32_t *__restrict__ partial /* ATOMIC: the slot pool */) {
-    constexpr int JB = 4, ROWS = JB * 3, MAXR = 64;
-    __shared__ uint4 rows[JB * 4 * THREADS];
+    typedef typename KsVec<W>::type vw;
+    constexpr int JB = 4, ROWS = JB * 3, MAXR = 64, EB = W * 4;      // EB: bytes of a strip entry
+    __shared__ __align__(16) vw rows[JB * 4 * THREADS];
     __shared__ __align__(16) uint32_t su[MAXR][G];       // [coefficient][gate]: four gates' digit words per 16-byte read
     __shared__ uint32_t sbody[G];
     const int tid = threadIdx.x;
@@ -1512,20 +1523,20 @@ __global__ __launch_bounds__(THREADS) void keyswitch_tile_kernel(DevParams p, De
         sbody[tid] = b;
     }
 #pragma unroll
-    for (int jj = 0; jj < JB; ++jj) rows[(jj * 4) * THREADS + tid] = make_uint4(0, 0, 0, 0);
+    for (int jj = 0; jj < JB; ++jj) rows[(jj * 4) * THREADS + tid] = (vw)(0u);
     __syncthreads();
-    const int nvec = p.ct_stride >> 2;
+    const int nvec = p.ct_stride / W;
     if (tid >= nvec) return;                             // no barrier below
-    const uint4 *ksk = reinterpret_cast<const uint4 *>(key.ksk) + tid;
-    uint4 acc[G];
+    const vw *ksk = reinterpret_cast<const vw *>(key.ksk) + tid;
+    vw acc[G];
 #pragma unroll
-    for (int g = 0; g < G; ++g) acc[g] = make_uint4(0, 0, 0, 0);
+    for (int g = 0; g < G; ++g) acc[g] = (vw)(0u);
     const int nst = range * 2;                           // stage = (coefficient, half of its 8 digits)
-    const uint4 *src = ksk + (size_t)(i0 * 8) * 3 * nvec;
+    const vw *src = ksk + (size_t)(i0 * 8) * 3 * nvec;
 #pragma unroll
     for (int r = 0; r < ROWS; ++r) rows[(r / 3 * 4 + r % 3 + 1) * THREADS + tid] = src[(size_t)r * nvec];
     // byte address of this thread's strip in LDS (the low half of a generic LDS pointer)
-    const uint32_t strip_addr = (uint32_t)reinterpret_cast<uintptr_t>(rows) + (uint32_t)tid * 16u;
+    const uint32_t strip_addr = (uint32_t)reinterpret_cast<uintptr_t>(rows) + (uint32_t)tid * (uint32_t)EB;
     for (int st = 0; st < nst; ++st) {
         // next stage's rows: loads issued before this stage's arithmetic, stored after it
         // (the strip is private to the thread and a wave's LDS operations stay in order).
@@ -1534,19 +1545,19 @@ __global__ __launch_bounds__(THREADS) void keyswitch_tile_kernel(DevParams p, De
         // would keep an array in scratch memory)
         if (st + 1 < nst) src += (size_t)ROWS * nvec;
 #define KS_ROWS(X) X(0) X(1) X(2) X(3) X(4) X(5) X(6) X(7) X(8) X(9) X(10) X(11)
-#define KS_LOAD(r) const uint4 pre##r = src[(size_t)(r) * nvec];
+#define KS_LOAD(r) const vw pre##r = src[(size_t)(r) * nvec];
         KS_ROWS(KS_LOAD)
 #undef KS_LOAD
         const int ii = st >> 1;
         const int sh0 = 24 - 8 * (st & 1);               // digit j sits at bits [31-2j, 30-2j]
         // Four gates at a time: their sixteen strip reads are issued back to back and waited for
         // once.  (Left to the compiler the reads are sunk next to their uses, two in flight,
-        // and the loop is bound by LDS latency; hence the explicit ds_read_b128 / s_waitcnt.
+        // and the loop is bound by LDS latency; hence the explicit ds_read / s_waitcnt.
         // The compiler's own LDS waits stay correct: operations of a wave complete in order
         // and it only ever under-counts what is outstanding.)
 #pragma unroll
         for (int g = 0; g < G; g += 4) {
-            v4u32 row[16];
+            vw row[16];
             const uint4 xs = *reinterpret_cast<const uint4 *>(&su[ii][g]);
             const uint32_t xe[4] = {xs.x, xs.y, xs.z, xs.w};
 #pragma unroll
@@ -1555,9 +1566,13 @@ __global__ __launch_bounds__(THREADS) void keyswitch_tile_kernel(DevParams p, De
 #pragma unroll
                 for (int jj = 0; jj < JB; ++jj) {
                     const uint32_t d = (x >> (6 - 2 * jj)) & 3u;
-                    const uint32_t addr = strip_addr + d * (uint32_t)(THREADS * 16);
-                    asm volatile("ds_read_b128 %0, %1 offset:%2"
-                                 : "=v"(row[e * 4 + jj]) : "v"(addr), "n"(jj * 4 * THREADS * 16) : "memory");
+                    const uint32_t addr = strip_addr + d * (uint32_t)(THREADS * EB);
+                    if constexpr (W == 4)
+                        asm volatile("ds_read_b128 %0, %1 offset:%2"
+                                     : "=v"(row[e * 4 + jj]) : "v"(addr), "n"(jj * 4 * THREADS * EB) : "memory");
+                    else
+                        asm volatile("ds_read_b64 %0, %1 offset:%2"
+                                     : "=v"(row[e * 4 + jj]) : "v"(addr), "n"(jj * 4 * THREADS * EB) : "memory");
                 }
             }
             asm volatile("s_waitcnt lgkmcnt(0)"
@@ -1567,10 +1582,7 @@ __global__ __launch_bounds__(THREADS) void keyswitch_tile_kernel(DevParams p, De
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
 #pragma unroll
-                for (int jj = 0; jj < JB; ++jj) {
-                    const v4u32 r = row[e * 4 + jj];
-                    acc[g + e].x -= r.x; acc[g + e].y -= r.y; acc[g + e].z -= r.z; acc[g + e].w -= r.w;
-                }
+                for (int jj = 0; jj < JB; ++jj) acc[g + e] -= row[e * 4 + jj];
             }
         }
 #define KS_STORE(r) rows[((r) / 3 * 4 + (r) % 3 + 1) * THREADS + tid] = pre##r;
@@ -1581,21 +1593,24 @@ __global__ __launch_bounds__(THREADS) void keyswitch_tile_kernel(DevParams p, De
 #pragma unroll
     for (int g = 0; g < G; ++g) {
         if (g0 + g >= count) break;
-        uint32_t o[4] = {acc[g].x, acc[g].y, acc[g].z, acc[g].w};
+        uint32_t o[W];
 #pragma unroll
-        for (int e = 0; e < 4; ++e) {
-            const int wi = 4 * tid + e;
+        for (int e = 0; e < W; ++e) {
+            o[e] = acc[g][e];
+            const int wi = W * tid + e;
             if (wi == p.n && split == 0) o[e] += sbody[g];
             if (wi > p.n) o[e] = 0;
         }
         if constexpr (ATOMIC) {
-            uint32_t *dst = reinterpret_cast<uint32_t *>(partial + (size_t)descs[g0 + g].dst_slot * p.ct_stride) + 4 * tid;
+            uint32_t *dst = reinterpret_cast<uint32_t *>(partial + (size_t)descs[g0 + g].dst_slot * p.ct_stride) + W * tid;
 #pragma unroll
-            for (int e = 0; e < 4; ++e)
-                if (4 * tid + e <= p.n) __hip_atomic_fetch_add(dst + e, o[e], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            for (int e = 0; e < W; ++e)
+                if (W * tid + e <= p.n) __hip_atomic_fetch_add(dst + e, o[e], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         } else {
-            reinterpret_cast<uint4 *>(partial + ((size_t)(g0 + g) * splits + split) * p.ct_stride)[tid] =
-                make_uint4(o[0], o[1], o[2], o[3]);
+            vw out;
+#pragma unroll
+            for (int e = 0; e < W; ++e) out[e] = o[e];
+            reinterpret_cast<vw *>(partial + ((size_t)(g0 + g) * splits + split) * p.ct_stride)[tid] = out;
         }
     }
 }
@@ -1719,7 +1734,8 @@ void launch_gate_dataflow(hipStream_t s, const DevParams &p, const DevKey &key, 
 #endif
 
 void launch_keyswitch(hipStream_t s, const DevParams &p, const DevKey &key, const int32_t *u_buf,
-                      const KsDesc *descs, int count, int32_t *pool, int splits, int32_t *partial, int tile, bool atomic) {
+                      const KsDesc *descs, int count, int32_t *pool, int splits, int32_t *partial, int tile, bool atomic,
+                      bool narrow) {
     if (count <= 0) return;
     const int threads = ((p.ct_stride / 4 + 63) / 64) * 64;      // one 16-byte lane per 4 output words
     if (splits <= 1 || (!partial && !atomic)) {
@@ -1730,6 +1746,20 @@ void launch_keyswitch(hipStream_t s, const DevParams &p, const DevKey &key, cons
     const int range = (p.k * p.N + splits - 1) / splits;
     if (tile > 0 && count >= 2 * tile && p.ks_t == 8 && p.ks_basebit == 2 && range <= 64 && (tile == 16 || tile == 32)) {
         const dim3 grid((count + tile - 1) / tile, splits);
+        // W = 2 form: a thread per 2 words of the row (tuning "ks_narrow")
+        const int threads2 = ((p.ct_stride / 2 + 63) / 64) * 64;
+        if (narrow && (threads2 == 256 || threads2 == 320 || threads2 == 576)) {
+#define KS_NARROW(T, GT)                                                                                                    \
+    do {                                                                                                                    \
+        if (atomic) hipLaunchKernelGGL((keyswitch_tile_kernel<T, GT, true, 2>), grid, dim3(T), 0, s, p, key, u_buf, descs, count, pool); \
+        else hipLaunchKernelGGL((keyswitch_tile_kernel<T, GT, false, 2>), grid, dim3(T), 0, s, p, key, u_buf, descs, count, partial);    \
+    } while (0)
+            if (tile == 16) { if (threads2 == 256) KS_NARROW(256, 16); else if (threads2 == 320) KS_NARROW(320, 16); else KS_NARROW(576, 16); }
+            else { if (threads2 == 256) KS_NARROW(256, 32); else if (threads2 == 320) KS_NARROW(320, 32); else KS_NARROW(576, 32); }
+#undef KS_NARROW
+            if (!atomic) hipLaunchKernelGGL(ks_reduce_kernel, dim3(count), dim3(threads), 0, s, p, descs, splits, partial, pool);
+            return;
+        }
 #define KS_TILE(T, GT)                                                                                                      \
     do {                                                                                                                    \
         if (atomic) hipLaunchKernelGGL((keyswitch_tile_kernel<T, GT, true>), grid, dim3(T), 0, s, p, key, u_buf, descs, count, pool); \

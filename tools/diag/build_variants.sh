@@ -7,10 +7,12 @@ set -euo pipefail
 ROOT=$(cd "$(dirname "$0")/../.." && pwd)
 S=$ROOT/peba1_amd/csrc; O=$ROOT/tools/diag/_ab; mkdir -p $O
 ROCM=${ROCM_PATH:-/opt/rocm}
-F="-O3 -std=c++17 -fPIC -ffp-contract=off -Wall -Wno-unused-result -mllvm -amdgpu-sched-strategy=max-ilp"
+F="-O3 -std=c++17 -fPIC -ffp-contract=off -Wall -Wno-unused-result"
 for spec in "$@"; do
   name=${spec%%=*}; defs=${spec#*=}
-  $ROCM/bin/hipcc $F $defs --offload-arch=gfx950 -c $S/kernels.hip -o $O/kernels-$name.o &
+  # the build's scheduling strategy (build.sh) unless the variant names its own, or NOSTRAT for the compiler's default
+  case "$defs" in *amdgpu-sched-strategy*) strat="";; *NOSTRAT*) strat=""; defs=${defs//NOSTRAT/};; *) strat="-mllvm -amdgpu-sched-strategy=max-ilp";; esac
+  $ROCM/bin/hipcc $F $strat $defs --offload-arch=gfx950 -c $S/kernels.hip -o $O/kernels-$name.o &
 done
 wait
 for spec in "$@"; do
