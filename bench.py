@@ -234,6 +234,10 @@ def main():
         import torch.distributed as dist
         if "MASTER_ADDR" not in os.environ:
             os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT="29577", RANK="0", WORLD_SIZE="1")
+        # one node, rendezvous on the loopback address: RCCL's bootstrap (torch's communicator and libpeba1-dist's own) may
+        # use the loopback interface too -- a container without another interface would otherwise find none
+        if os.environ.get("MASTER_ADDR") in ("127.0.0.1", "localhost"):
+            os.environ.setdefault("NCCL_SOCKET_IFNAME", "lo")
         if args.backend == "gloo":
             xdev = "cpu"
             local_rank = local_rank % max(1, torch.cuda.device_count())
@@ -500,6 +504,9 @@ def weak_scaling_leg(api, circuits, identify, dist, torch, pp, ks, probe, bound,
         tv[M // 2] = base                                   # the genuine template: the only match bit 0
     templates = [circuits.EncryptedVector(pp, t, bitsize, ks).to_device() for t in tv]
     all_bits = api.CiphertextArray(pp, world * M) if rank == 0 else None
+    # ONE encrypted probe: rank 0's ciphertexts reach every rank (peba1_dist_broadcast_samples: 128 x 8 samples, 2.6 MB)
+    from peba1_amd import dist as pd
+    pd.broadcast_vector(comm, pp, ks, probe, root=0)
     identify.identify(pp, ks, probe, templates[:min(group, M)], bound, bitsize, group=group)       # warm-up group
     api.wait()
     dist.barrier()
@@ -529,8 +536,9 @@ def weak_scaling_leg(api, circuits, identify, dist, torch, pp, ks, probe, bound,
             "seconds": float(tt.item()), "n_gpus": world, "scaling": "weak",
             "checked": f"all {M} decrypted match bits per rank == plaintext rule; the {world * M} gathered bits on rank 0 hold exactly "
                        "one 0 (the genuine template)",
-            "note": "independent matches per GPU (1-to-N identification, BASELINE configs[3]) through peba1_identify; no data-path "
-                    "collective, one gather of the match bits; timed on its own after the strong-scaling steps"}
+            "note": "independent matches per GPU (1-to-N identification, BASELINE configs[3]) through peba1_identify: rank 0's "
+                    "encrypted probe broadcast to every rank, no data-path collective, one gather of the match bits; timed on "
+                    "its own after the strong-scaling steps"}
 
 
 def extras(api, circuits, identify, lib, pd, pp, ks, probe, tmpl, bound, base, probe_vals, bitsize, plain_bit, last):

@@ -87,6 +87,16 @@ int peba1_sharded_combine_packed(LweSample *result_b, const int32_t *packed, int
 int peba1_dist_gather_samples(Peba1Comm *comm, LweSample *all, const LweSample *mine, int count,
                               const TFheGateBootstrappingParameterSet *params);
 
+/* Broadcast `count` ciphertexts from `root` to every rank (identification: the ONE encrypted probe reaches every rank's
+ * share of the gallery).  `samples`: sample array of parameter set `params` on every rank -- read on root, written
+ * elsewhere.  RCCL: export -> ncclBroadcast -> import on the provider's stream (2.5 KB per sample).  Host transport: through
+ * the callback given to peba1_dist_set_host_bcast (bcast(ctx, buffer, bytes, root): in place; returns 0), without one the
+ * call fails with a message.  Collective; failure containment as below.  Returns 0 or -1. */
+typedef int (*peba1_bcast_fn)(void *ctx, void *buffer, size_t bytes, int root);
+void peba1_dist_set_host_bcast(Peba1Comm *comm, peba1_bcast_fn bcast);
+int peba1_dist_broadcast_samples(Peba1Comm *comm, LweSample *samples, int count,
+                                 const TFheGateBootstrappingParameterSet *params, int root);
+
 /* 1-to-N identification (BASELINE configs[3]): the loop a PEBA1 server puts around Function_f, one call per enrolled
  * client (/root/reference/src/main.cpp:533-542), for THIS rank's share of the gallery -- with no Python in the process.
  *   probe: nslots slot arrays of `bitsize` samples; templates: m_local * nslots slot arrays, template m at

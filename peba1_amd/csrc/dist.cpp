@@ -45,6 +45,7 @@ struct Rccl {
     ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
     ncclResult_t (*Gather)(const void *, void *, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
     ncclResult_t (*AllGather)(const void *, void *, size_t, ncclDataType_t, ncclComm_t, hipStream_t) = nullptr;
+    ncclResult_t (*Bcast)(void *, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
     const char *(*GetErrorString)(ncclResult_t) = nullptr;
     bool load() {
         if (handle) return true;
@@ -58,8 +59,9 @@ struct Rccl {
         CommDestroy = reinterpret_cast<decltype(CommDestroy)>(dlsym(handle, "ncclCommDestroy"));
         Gather = reinterpret_cast<decltype(Gather)>(dlsym(handle, "ncclGather"));
         AllGather = reinterpret_cast<decltype(AllGather)>(dlsym(handle, "ncclAllGather"));
+        Bcast = reinterpret_cast<decltype(Bcast)>(dlsym(handle, "ncclBcast"));
         GetErrorString = reinterpret_cast<decltype(GetErrorString)>(dlsym(handle, "ncclGetErrorString"));
-        return GetUniqueId && CommInitRank && CommDestroy && Gather && AllGather && GetErrorString;
+        return GetUniqueId && CommInitRank && CommDestroy && Gather && AllGather && Bcast && GetErrorString;
     }
 };
 Rccl g_rccl;
@@ -71,6 +73,7 @@ struct Peba1Comm {
     bool rccl = false, own = false;
     ncclComm_t nccl = nullptr;
     peba1_gather_fn gather = nullptr;
+    peba1_bcast_fn bcast = nullptr;
     void *ctx = nullptr;
     // grow-only device buffers of the RCCL path: they must outlive the stream operations that use them
     int32_t *send = nullptr, *recv = nullptr;
@@ -189,9 +192,58 @@ int gather_samples(Peba1Comm *c, LweSample *all, const LweSample *mine, int coun
     return 0;
 }
 
+// `count` samples of `root` -> every rank.  The status exchange of the RCCL path is the all-gather above; over the host
+// transport the status word of the ROOT rides in front of the payload (a root that failed broadcasts a failure), a failed
+// receiver still takes part and returns -1 itself.
+int broadcast_samples(Peba1Comm *c, LweSample *samples, int count, const TFheGateBootstrappingParameterSet *params, int root) {
+    const size_t words = (size_t)tfhe_hip_sample_words(params) * (size_t)count;
+    int local = 0;
+    std::string why;
+    auto note = [&](const std::string &msg) { if (local == 0) { local = -1; why = msg; } };
+    if (c->inject_failures > 0) { --c->inject_failures; note("injected failure (peba1_dist_inject_failure)"); }
+    if (c->rccl) {
+        if (!tfhe_hip_export_samples_device_async || !tfhe_hip_import_samples_device_async || !tfhe_hip_stream)
+            return fail("the RCCL transport needs libtfhe-hip as the gate provider");
+        if (local == 0 && !device_buffer(c->send, c->send_words, words)) note("hipMalloc of the broadcast buffer failed");
+        hipStream_t stream = static_cast<hipStream_t>(tfhe_hip_stream());
+        if (local == 0 && c->rank == root && tfhe_hip_export_samples_device_async(samples, count, params, c->send) != 0)
+            note("export of the samples: " + provider_error());
+        const int bad = exchange_status_rccl(c, local);
+        if (bad == -2) return -1;
+        if (bad >= 0)
+            return fail(bad == c->rank ? "rank " + std::to_string(bad) + " (this rank) failed before the broadcast: " + why
+                                       : "rank " + std::to_string(bad) + " reported a failure before the broadcast; no rank entered it");
+        const ncclResult_t r = g_rccl.Bcast(c->send, words, ncclInt32, root, c->nccl, stream);
+        if (r != ncclSuccess) return fail(std::string("ncclBcast: ") + g_rccl.GetErrorString(r));
+        if (c->rank != root && tfhe_hip_import_samples_device_async(samples, count, params, c->send) != 0)
+            return fail("import of the broadcast samples: " + provider_error());
+        return 0;
+    }
+    if (!c->bcast) return fail("the host transport has no broadcast: give one to peba1_dist_set_host_bcast");
+    std::vector<int32_t> buf(1 + words, 0);
+    if (c->rank == root) {
+        if (local == 0 && tfhe_hip_export_samples(samples, count, params, buf.data() + 1) != 0) note("export of the samples: " + provider_error());
+        buf[0] = local;
+    }
+    if (c->bcast(c->ctx, buf.data(), (1 + words) * sizeof(int32_t), root) != 0) return fail("the host broadcast callback failed");
+    if (local != 0) return fail("rank " + std::to_string(c->rank) + " (this rank) failed before the broadcast: " + why);
+    if (buf[0] != 0) return fail("rank " + std::to_string(root) + " (the root) reported a failure before the broadcast; its payload is void");
+    if (c->rank != root && tfhe_hip_import_samples(samples, count, params, buf.data() + 1) != 0)
+        return fail("import of the broadcast samples: " + provider_error());
+    return 0;
+}
+
 }  // namespace
 
 extern "C" {
+
+void peba1_dist_set_host_bcast(Peba1Comm *c, peba1_bcast_fn bcast) { if (c) c->bcast = bcast; }
+
+int peba1_dist_broadcast_samples(Peba1Comm *c, LweSample *samples, int count, const TFheGateBootstrappingParameterSet *params,
+                                 int root) {
+    if (!c || !samples || count < 1 || !params || root < 0 || root >= c->world) return fail("peba1_dist_broadcast_samples: bad arguments");
+    return broadcast_samples(c, samples, count, params, root);
+}
 
 void peba1_dist_shard_slots(int nslots, int world, int rank, int *lo, int *hi) {
     const int base = nslots / world, rem = nslots % world;

@@ -38,6 +38,7 @@ IDENTIFY_FAST = 1         # PEBA1_IDENTIFY_FAST
 _HERE = os.path.dirname(os.path.abspath(__file__))
 DIST_PATH = os.path.join(_HERE, "libpeba1-dist.so")
 _GATHER_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_int)
+_BCAST_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_size_t, C.c_int)
 _dlib = None
 
 
@@ -68,6 +69,9 @@ def load():
         D.peba1_sharded_combine_packed.argtypes = [V, V, I, V, V, I]
         D.peba1_dist_gather_samples.argtypes = [V, V, V, I, V]
         D.peba1_identify.argtypes = [V, V, V, V, V, I, I, V, I, V, I, I]
+        D.peba1_dist_set_host_bcast.restype = None
+        D.peba1_dist_set_host_bcast.argtypes = [V, _BCAST_FN]
+        D.peba1_dist_broadcast_samples.argtypes = [V, V, I, V, I]
         D.peba1_dist_set_timeout.argtypes = [V, C.c_double]
         D.peba1_dist_inject_failure.restype = None
         D.peba1_dist_inject_failure.argtypes = [V, I]
@@ -144,8 +148,22 @@ class Comm:
                     return 0
                 except Exception:      # never unwind through the C frame
                     return -1
+            def bcast(_ctx, buf, nbytes, root):
+                try:
+                    view = np.ctypeslib.as_array(C.cast(buf, C.POINTER(C.c_uint8)), shape=(nbytes,))
+                    t = torch.from_numpy(view.copy())
+                    dist.broadcast(t, src=root)
+                    if self.rank != root:
+                        whole = t.contiguous().numpy()
+                        C.memmove(buf, whole.ctypes.data, nbytes)
+                    return 0
+                except Exception:      # never unwind through the C frame
+                    return -1
             self._keep = _GATHER_FN(gather)
+            self._keep_b = _BCAST_FN(bcast)
             self.ptr = D.peba1_dist_init_host(self._keep, None, self.world, self.rank)
+            if self.ptr:
+                D.peba1_dist_set_host_bcast(self.ptr, self._keep_b)
         if not self.ptr:
             raise RuntimeError("cannot create the communicator: " + D.peba1_dist_last_error().decode())
 
@@ -246,3 +264,30 @@ def identify(comm, all_ptr, mine_ptr, probe_slots, template_slots, nslots, bound
     _check(load().peba1_identify(comm.ptr if comm is not None else None, all_ptr, mine_ptr, _ptr_array(probe_slots),
                                  _ptr_array(template_slots), m_local, nslots, bound_ptr, bitsize, cloud_ptr, group,
                                  IDENTIFY_FAST if fast else 0), "peba1_identify")
+
+
+def broadcast_samples(comm, samples_ptr, count, params_ptr, root=0):
+    """`count` ciphertexts of `root` -> every rank (peba1_dist_broadcast_samples): the ONE encrypted probe of an
+    identification reaches every rank's share of the gallery."""
+    _check(load().peba1_dist_broadcast_samples(comm.ptr, samples_ptr, count, params_ptr, root), "peba1_dist_broadcast_samples")
+
+
+def broadcast_vector(comm, params, key, vec, root=0):
+    """Broadcast a circuits.EncryptedVector (one sample array per slot) in ONE collective: the slots' handles are copied
+    into one contiguous array (bootsCOPY re-points handles: no data moves), that array is broadcast, and on the other
+    ranks the slots are re-pointed at what arrived."""
+    from . import api
+    from . import lib as _l
+    L = _l.load()
+    bits = vec.slots[0].count
+    flat = api.CiphertextArray(params, len(vec.slots) * bits)
+    if comm.rank == root:
+        for i, a in enumerate(vec.slots):
+            for k in range(bits):
+                L.bootsCOPY(flat.at(i * bits + k), a.at(k), key.cloud)
+    broadcast_samples(comm, flat.ptr, flat.count, params.ptr, root)
+    if comm.rank != root:
+        for i, a in enumerate(vec.slots):
+            for k in range(bits):
+                L.bootsCOPY(a.at(k), flat.at(i * bits + k), key.cloud)
+    return vec

@@ -26,6 +26,15 @@ static int gather_cb(void *ctx, const void *send, void *recv, size_t bytes, int 
     return 0;
 }
 
+static std::vector<char> g_bmail;                 // what the broadcast root has sent
+static int bcast_cb(void *ctx, void *buffer, size_t bytes, int root) {
+    const int rank = *static_cast<int *>(ctx);
+    if (rank == root) { g_bmail.assign(static_cast<char *>(buffer), static_cast<char *>(buffer) + bytes); return 0; }
+    if (g_bmail.size() != bytes) return -1;                   // the root has not called yet
+    std::memcpy(buffer, g_bmail.data(), bytes);
+    return 0;
+}
+
 static LweSample *encrypt_number(unsigned v, int bits, const TFheGateBootstrappingParameterSet *pp,
                                  const TFheGateBootstrappingSecretKeySet *key) {
     LweSample *a = new_gate_bootstrapping_ciphertext_array(bits, pp);
@@ -120,9 +129,25 @@ int main(int argc, char **argv) {
         std::vector<int> ranks;
         for (int r = 1; r < world; ++r) ranks.push_back(r);
         ranks.push_back(0);
+        // the ONE encrypted probe: rank 0 encrypts it, peba1_dist_broadcast_samples brings it to every rank (root first here:
+        // the ranks are simulated one after the other)
+        std::vector<LweSample *> probe_of((size_t)world);
+        g_bmail.clear();
+        for (int rank = 0; rank < world; ++rank) {
+            LweSample *pa = new_gate_bootstrapping_ciphertext_array(ns * bitsize, pp);
+            if (rank == 0)
+                for (int i = 0; i < ns; ++i)
+                    for (int k = 0; k < bitsize; ++k) bootsSymEncrypt(pa + i * bitsize + k, (pr[i] >> k) & 1, key);
+            Peba1Comm *comm = peba1_dist_init_host(gather_cb, &rank, world, rank);
+            if (peba1_dist_broadcast_samples(comm, pa, ns * bitsize, pp, 0) == 0) { std::printf("broadcast without a callback succeeded\n"); return 1; }
+            peba1_dist_set_host_bcast(comm, bcast_cb);
+            if (peba1_dist_broadcast_samples(comm, pa, ns * bitsize, pp, 0) != 0) { std::printf("broadcast rank %d: %s\n", rank, peba1_dist_last_error()); return 1; }
+            peba1_dist_destroy(comm);
+            probe_of[(size_t)rank] = pa;
+        }
         for (int rank : ranks) {
             std::vector<LweSample *> P, T;
-            for (int i = 0; i < ns; ++i) P.push_back(encrypt_number(pr[i], bitsize, pp, key));
+            for (int i = 0; i < ns; ++i) P.push_back(probe_of[(size_t)rank] + i * bitsize);      // slot i of the broadcast probe
             for (int m = 0; m < m_local; ++m) {
                 long dd = 0;
                 for (int i = 0; i < ns; ++i) {
@@ -146,7 +171,7 @@ int main(int argc, char **argv) {
             peba1_dist_destroy(comm);
             delete_gate_bootstrapping_ciphertext_array(m_local, mine);
             delete_gate_bootstrapping_ciphertext_array(24, enc_bound);
-            for (LweSample *p : P) delete_gate_bootstrapping_ciphertext_array(bitsize, p);
+            delete_gate_bootstrapping_ciphertext_array(ns * bitsize, probe_of[(size_t)rank]);
             for (LweSample *p : T) delete_gate_bootstrapping_ciphertext_array(bitsize, p);
         }
         int zeros = 0;

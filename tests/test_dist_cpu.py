@@ -65,6 +65,12 @@ if inject >= 0:
     print("CONTAINED", rank, flush=True)
 else:
     res = pd.sharded_match(dist, torch, gate, circ, params, cloud, 2, S, T, bound, 8, device="cpu", fast_combine=fast, fast_partial=fast)
+# the ONE encrypted probe of an identification reaches every rank: peba1_dist_broadcast_samples over the host transport
+bc = pd.Comm(dist, torch, "cpu")
+pb = enc(0xA5 if rank == 1 % world else 0, 8)
+pd.broadcast_samples(bc, pb, 8, params, root=1 % world)
+assert sum(gate.bootsSymDecrypt(pb + i * SZ, key) << i for i in range(8)) == 0xA5, rank
+bc.close()
 if rank == 0:
     bit = gate.bootsSymDecrypt(res, key)
     d = sum((a - b) ** 2 for a, b in zip(probe, tmpl))

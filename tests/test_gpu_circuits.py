@@ -157,6 +157,7 @@ def test_sharded_match_over_rccl_world1(p128_keys):
             from peba1_amd import identify
             all_bits = api.CiphertextArray(pp, 3)
             ib = circuits.encrypt_number(pp, 5, 24, ks)
+            pd.broadcast_vector(comm, pp, ks, S, root=0)          # the probe's broadcast: export -> ncclBcast on the library's stream
             bits = identify.identify(pp, ks, S, templates, ib, 8, group=2, comm=comm, all_bits=all_bits)
             want = [1 if sum((a - b) ** 2 for a, b in zip(probe_v, t)) > 5 else 0 for t in tv]
             assert [int(b) for b in all_bits.decrypt(ks)] == want == [int(b) for b in bits.decrypt(ks)] and want == [1, 0, 1]
