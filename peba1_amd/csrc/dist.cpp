@@ -22,6 +22,7 @@ __attribute__((weak)) int tfhe_hip_import_samples_device_async(LweSample *, int3
 __attribute__((weak)) void *tfhe_hip_stream(void);
 __attribute__((weak)) const char *tfhe_hip_last_error(void);
 __attribute__((weak)) int tfhe_hip_stream_sync(void);
+__attribute__((weak)) int tfhe_hip_get_device(void);
 __attribute__((weak)) int tfhe_hip_set_tuning(const char *, int64_t);
 __attribute__((weak)) void tfhe_hip_set_diag_label(const char *);
 __attribute__((weak)) int tfhe_hip_flush_async(void);
@@ -84,6 +85,13 @@ struct Peba1Comm {
 };
 
 namespace {
+
+// this library calls the HIP runtime itself (exchange buffers, the status words): on the provider's device, whatever the
+// calling thread had current
+void bind_device() {
+    if (tfhe_hip_stream) (void)tfhe_hip_stream();                     // initialises the provider if nothing has yet
+    if (tfhe_hip_get_device) (void)hipSetDevice(tfhe_hip_get_device());
+}
 
 // every host wait of this library goes through the provider's bounded wait (tfhe_hip.h "bounded host waits")
 void stream_sync() {
@@ -157,6 +165,7 @@ int gather_samples(Peba1Comm *c, LweSample *all, const LweSample *mine, int coun
     if (c->rccl) {
         if (!tfhe_hip_export_samples_device_async || !tfhe_hip_import_samples_device_async || !tfhe_hip_stream)
             return fail("the RCCL transport needs libtfhe-hip as the gate provider");
+        bind_device();
         if (local == 0 && !device_buffer(c->send, c->send_words, words)) note("hipMalloc of the send buffer failed");
         if (local == 0 && c->rank == 0 && !device_buffer(c->recv, c->recv_words, words * (size_t)c->world)) note("hipMalloc of the receive buffer failed");
         hipStream_t stream = static_cast<hipStream_t>(tfhe_hip_stream());
@@ -204,6 +213,7 @@ int broadcast_samples(Peba1Comm *c, LweSample *samples, int count, const TFheGat
     if (c->rccl) {
         if (!tfhe_hip_export_samples_device_async || !tfhe_hip_import_samples_device_async || !tfhe_hip_stream)
             return fail("the RCCL transport needs libtfhe-hip as the gate provider");
+        bind_device();
         if (local == 0 && !device_buffer(c->send, c->send_words, words)) note("hipMalloc of the broadcast buffer failed");
         hipStream_t stream = static_cast<hipStream_t>(tfhe_hip_stream());
         if (local == 0 && c->rank == root && tfhe_hip_export_samples_device_async(samples, count, params, c->send) != 0)
@@ -270,7 +280,7 @@ Peba1Comm *peba1_dist_init_rccl(const void *id128, int world, int rank) {
     if (!id128 || world < 1 || rank < 0 || rank >= world) { fail("peba1_dist_init_rccl: bad arguments"); return nullptr; }
     if (!g_rccl.load()) { fail(std::string("cannot open RCCL: ") + (dlerror() ? dlerror() : "symbols missing")); return nullptr; }
     if (!tfhe_hip_stream) { fail("the RCCL transport needs libtfhe-hip as the gate provider"); return nullptr; }
-    (void)tfhe_hip_stream();                  // initialises the engine: the device it selected is current for RCCL
+    bind_device();                            // initialises the engine: the device it selected is current for RCCL
     ncclUniqueId id;
     std::memcpy(&id, id128, sizeof id);
     auto *c = new Peba1Comm();

@@ -91,6 +91,16 @@ void SlotPool::release(int32_t s) {
 // ---- engine ------------------------------------------------------------------
 Engine &Engine::get() {
     static Engine e;
+    // HIP's current device is per host thread and starts at 0: a worker thread of a multi-GPU server (rank r drives GPU r)
+    // that calls in without ever having selected a device would launch on the engine's stream with another device current.
+    // Every entry of the library passes through here; bind the thread to the engine's device the first time it does
+    if (e.inited_) {
+        thread_local int bound = -1;
+        if (bound != e.device_) {
+            (void)hipSetDevice(e.device_);
+            bound = e.device_;
+        }
+    }
     return e;
 }
 
