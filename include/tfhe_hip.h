@@ -158,6 +158,9 @@ int tfhe_hip_gate_batch(int gate, LweSample *result, const LweSample *a, const L
  * "ks_narrow": 1 = in the tiled kernel a thread owns 2 words of the output row instead of 4 (five light waves per
  * workgroup at n = 630 instead of three heavy ones); 0 (default) = 4 words per thread.  Measured slower (126 against 111 ms
  * per match: twice the LDS instructions for the same bytes); kept selectable and tested; env TFHE_HIP_KS_NARROW.
+ * "ks_pipe": 1 (default) = the tiled kernel issues the LDS reads of the next pair of gates before it subtracts the current
+ * pair's rows and waits for "all but the last eight" (105 against 111.5 ms per match); 0 = sixteen reads, then one wait;
+ * env TFHE_HIP_KS_PIPE.
  * "ks_atomic": 1 = the ranges of a split key switch add their partial sums into the zeroed destination
  * slot with 32-bit atomic adds (no partial-sum buffer, no reduce launch); 0 (default) = partial sums + reduce;
  * env TFHE_HIP_KS_ATOMIC.  Integer adds commute: the same words either way.

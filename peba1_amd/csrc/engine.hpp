@@ -150,6 +150,9 @@ public:
     // instead of 3 heavy ones (kernels.hip keyswitch_tile_kernel W; env TFHE_HIP_KS_NARROW, tuning "ks_narrow"); measured
     // slower (126 against 111 ms per match), so off
     int ks_narrow = 0;
+    // 1 = the tiled key switch issues the strip reads of the next pair of gates before it subtracts the current pair's rows
+    // (keyswitch_tile_kernel PIPE; env TFHE_HIP_KS_PIPE, tuning "ks_pipe"): 105 against 111.5 ms per match, so on
+    int ks_pipe = 1;
     // two-lane execution: 1 = the urgent lane's blind-rotate waves raise their issue priority
     // (measured slower: the co-resident workgroups of the other lane become its stragglers)
     int lane_prio = 0;

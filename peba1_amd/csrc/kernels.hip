@@ -1491,7 +1491,11 @@ template <int W> struct KsVec;
 template <> struct KsVec<4> { typedef uint32_t type __attribute__((ext_vector_type(4))); };
 template <> struct KsVec<2> { typedef uint32_t type __attribute__((ext_vector_type(2))); };
 
-template <int THREADS, int G, bool ATOMIC = false, int W = 4>
+// PIPE (round 4): the strip reads of the next pair of gates are issued BEFORE the subtractions of the current pair, and the
+// wait is for "all but the last eight reads" (a wave's LDS operations complete in order, so s_waitcnt lgkmcnt(8) means the
+// older eight have arrived): the wave no longer sits at s_waitcnt lgkmcnt(0) four times per stage with nothing in flight
+// (SQ counters: 29 % of its cycles parked, profiles/r04_ks_counters.txt).  Same registers (two buffers of eight rows).
+template <int THREADS, int G, bool ATOMIC = false, int W = 4, bool PIPE = false>
 __global__ __launch_bounds__(THREADS) void keyswitch_tile_kernel(DevParams p, DevKey key, const int32_t *__restrict__ u_buf,
                                                               const KsDesc *__restrict__ descs, int count,
                                                               int32_t *__restrict__ partial /* ATOMIC: the slot pool */) {
@@ -1550,6 +1554,51 @@ __global__ __launch_bounds__(THREADS) void keyswitch_tile_kernel(DevParams p, De
 #undef KS_LOAD
         const int ii = st >> 1;
         const int sh0 = 24 - 8 * (st & 1);               // digit j sits at bits [31-2j, 30-2j]
+        auto issue = [&](vw (&buf)[8], uint32_t x0, uint32_t x1) {      // the eight strip reads of two gates
+#pragma unroll
+            for (int e = 0; e < 2; ++e) {
+                const uint32_t x = (e ? x1 : x0) >> sh0;         // this stage's four digits in the low byte
+#pragma unroll
+                for (int jj = 0; jj < JB; ++jj) {
+                    const uint32_t d = (x >> (6 - 2 * jj)) & 3u;
+                    const uint32_t addr = strip_addr + d * (uint32_t)(THREADS * EB);
+                    if constexpr (W == 4)
+                        asm volatile("ds_read_b128 %0, %1 offset:%2"
+                                     : "=v"(buf[e * 4 + jj]) : "v"(addr), "n"(jj * 4 * THREADS * EB) : "memory");
+                    else
+                        asm volatile("ds_read_b64 %0, %1 offset:%2"
+                                     : "=v"(buf[e * 4 + jj]) : "v"(addr), "n"(jj * 4 * THREADS * EB) : "memory");
+                }
+            }
+        };
+        if constexpr (PIPE) {
+            // all sixteen gates' digit words first (one wait), then pairs of gates through two buffers of eight rows
+            uint32_t xg[G];
+#pragma unroll
+            for (int g = 0; g < G; g += 4) {
+                const uint4 xs = *reinterpret_cast<const uint4 *>(&su[ii][g]);
+                xg[g] = xs.x; xg[g + 1] = xs.y; xg[g + 2] = xs.z; xg[g + 3] = xs.w;
+            }
+            vw bufA[8], bufB[8];
+            issue(bufA, xg[0], xg[1]);
+#pragma unroll
+            for (int g = 0; g < G; g += 2) {
+                vw (&cur)[8] = (g & 2) ? bufB : bufA;
+                vw (&nxt)[8] = (g & 2) ? bufA : bufB;
+                if (g + 2 < G) {
+                    issue(nxt, xg[g + 2], xg[g + 3]);
+                    asm volatile("s_waitcnt lgkmcnt(8)"
+                                 : "+v"(cur[0]), "+v"(cur[1]), "+v"(cur[2]), "+v"(cur[3]), "+v"(cur[4]), "+v"(cur[5]), "+v"(cur[6]), "+v"(cur[7]));
+                } else {
+                    asm volatile("s_waitcnt lgkmcnt(0)"
+                                 : "+v"(cur[0]), "+v"(cur[1]), "+v"(cur[2]), "+v"(cur[3]), "+v"(cur[4]), "+v"(cur[5]), "+v"(cur[6]), "+v"(cur[7]));
+                }
+#pragma unroll
+                for (int e = 0; e < 2; ++e)
+#pragma unroll
+                    for (int jj = 0; jj < JB; ++jj) acc[g + e] -= cur[e * 4 + jj];
+            }
+        } else {
         // Four gates at a time: their sixteen strip reads are issued back to back and waited for
         // once.  (Left to the compiler the reads are sunk next to their uses, two in flight,
         // and the loop is bound by LDS latency; hence the explicit ds_read / s_waitcnt.
@@ -1559,22 +1608,8 @@ __global__ __launch_bounds__(THREADS) void keyswitch_tile_kernel(DevParams p, De
         for (int g = 0; g < G; g += 4) {
             vw row[16];
             const uint4 xs = *reinterpret_cast<const uint4 *>(&su[ii][g]);
-            const uint32_t xe[4] = {xs.x, xs.y, xs.z, xs.w};
-#pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                const uint32_t x = xe[e] >> sh0;             // this stage's four digits in the low byte
-#pragma unroll
-                for (int jj = 0; jj < JB; ++jj) {
-                    const uint32_t d = (x >> (6 - 2 * jj)) & 3u;
-                    const uint32_t addr = strip_addr + d * (uint32_t)(THREADS * EB);
-                    if constexpr (W == 4)
-                        asm volatile("ds_read_b128 %0, %1 offset:%2"
-                                     : "=v"(row[e * 4 + jj]) : "v"(addr), "n"(jj * 4 * THREADS * EB) : "memory");
-                    else
-                        asm volatile("ds_read_b64 %0, %1 offset:%2"
-                                     : "=v"(row[e * 4 + jj]) : "v"(addr), "n"(jj * 4 * THREADS * EB) : "memory");
-                }
-            }
+            issue(reinterpret_cast<vw (&)[8]>(row[0]), xs.x, xs.y);
+            issue(reinterpret_cast<vw (&)[8]>(row[8]), xs.z, xs.w);
             asm volatile("s_waitcnt lgkmcnt(0)"
                          : "+v"(row[0]), "+v"(row[1]), "+v"(row[2]), "+v"(row[3]), "+v"(row[4]), "+v"(row[5]),
                            "+v"(row[6]), "+v"(row[7]), "+v"(row[8]), "+v"(row[9]), "+v"(row[10]), "+v"(row[11]),
@@ -1584,6 +1619,7 @@ __global__ __launch_bounds__(THREADS) void keyswitch_tile_kernel(DevParams p, De
 #pragma unroll
                 for (int jj = 0; jj < JB; ++jj) acc[g + e] -= row[e * 4 + jj];
             }
+        }
         }
 #define KS_STORE(r) rows[((r) / 3 * 4 + (r) % 3 + 1) * THREADS + tid] = pre##r;
         KS_ROWS(KS_STORE)
@@ -1735,7 +1771,7 @@ void launch_gate_dataflow(hipStream_t s, const DevParams &p, const DevKey &key, 
 
 void launch_keyswitch(hipStream_t s, const DevParams &p, const DevKey &key, const int32_t *u_buf,
                       const KsDesc *descs, int count, int32_t *pool, int splits, int32_t *partial, int tile, bool atomic,
-                      bool narrow) {
+                      bool narrow, bool pipe) {
     if (count <= 0) return;
     const int threads = ((p.ct_stride / 4 + 63) / 64) * 64;      // one 16-byte lane per 4 output words
     if (splits <= 1 || (!partial && !atomic)) {
@@ -1765,7 +1801,15 @@ void launch_keyswitch(hipStream_t s, const DevParams &p, const DevKey &key, cons
         if (atomic) hipLaunchKernelGGL((keyswitch_tile_kernel<T, GT, true>), grid, dim3(T), 0, s, p, key, u_buf, descs, count, pool); \
         else hipLaunchKernelGGL((keyswitch_tile_kernel<T, GT, false>), grid, dim3(T), 0, s, p, key, u_buf, descs, count, partial);    \
     } while (0)
-        if (tile == 16) {
+        if (tile == 16 && pipe) {
+#define KS_PIPE(T)                                                                                                          \
+    do {                                                                                                                    \
+        if (atomic) hipLaunchKernelGGL((keyswitch_tile_kernel<T, 16, true, 4, true>), grid, dim3(T), 0, s, p, key, u_buf, descs, count, pool); \
+        else hipLaunchKernelGGL((keyswitch_tile_kernel<T, 16, false, 4, true>), grid, dim3(T), 0, s, p, key, u_buf, descs, count, partial);    \
+    } while (0)
+            if (threads == 128) KS_PIPE(128); else if (threads == 192) KS_PIPE(192); else if (threads == 320) KS_PIPE(320); else tile = 0;
+#undef KS_PIPE
+        } else if (tile == 16) {
             if (threads == 128) KS_TILE(128, 16); else if (threads == 192) KS_TILE(192, 16); else if (threads == 320) KS_TILE(320, 16); else tile = 0;
         } else {
             if (threads == 128) KS_TILE(128, 32); else if (threads == 192) KS_TILE(192, 32); else if (threads == 320) KS_TILE(320, 32); else tile = 0;

@@ -154,7 +154,8 @@ def test_tiled_keyswitch_matches_oracle(p128_keys, oracle, tile, count):
     u[1, :-1] = -1
     u[count - 1, :-1] = 0x40000000   # digit 1 at the first position only
     api.set_tuning("ks_tile", tile)
-    narrow_default = 0
+    api.set_tuning("ks_pipe", 0)                 # the round-2 form first: sixteen reads, one wait
+    narrow_default, pipe_default = 0, 1
     try:
         forms = {}
         for narrow in (0, 1):                    # a thread per 4 words of the row (default) / per 2 words (round 4, selectable)
@@ -164,6 +165,12 @@ def test_tiled_keyswitch_matches_oracle(p128_keys, oracle, tile, count):
             forms[narrow, 1] = api.kernel_keyswitch(ks, u)
             api.set_tuning("ks_atomic", 0)
         got, in_place = forms[0, 0], forms[0, 1]
+        api.set_tuning("ks_pipe", 1)             # strip reads a pair of gates ahead of the subtractions (tile 16; the default)
+        forms["pipe", 0] = api.kernel_keyswitch(ks, u)
+        api.set_tuning("ks_atomic", 1)
+        forms["pipe", 1] = api.kernel_keyswitch(ks, u)
+        api.set_tuning("ks_atomic", 0)
+        api.set_tuning("ks_pipe", 0)
         api.set_tuning("ks_tile", 0)
         api.set_tuning("ks_atomic", 1)
         per_gate_in_place = api.kernel_keyswitch(ks, u)
@@ -173,8 +180,10 @@ def test_tiled_keyswitch_matches_oracle(p128_keys, oracle, tile, count):
         api.set_tuning("ks_tile", 16)
         api.set_tuning("ks_atomic", 0)
         api.set_tuning("ks_narrow", narrow_default)
+        api.set_tuning("ks_pipe", pipe_default)
     assert (got == per_gate).all() and (in_place == per_gate).all() and (per_gate_in_place == per_gate).all()
     assert (forms[1, 0] == per_gate).all() and (forms[1, 1] == per_gate).all()
+    assert (forms["pipe", 0] == per_gate).all() and (forms["pipe", 1] == per_gate).all()
     for c in list(range(4)) + [count // 2, count - 2, count - 1]:
         assert (got[c] == oks.keyswitch(u[c])).all(), f"sample {c}"
 
