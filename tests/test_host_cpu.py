@@ -255,6 +255,43 @@ def test_secure_randomness_is_rekeyed_in_a_fork_child():
     assert run.returncode == 0 and "ok" in run.stdout, run.stdout + run.stderr
 
 
+def test_counted_lds_waits_see_no_scalar_memory_load(tmp_path):
+    """The pipelined key switch waits with s_waitcnt lgkmcnt(12 / 8 / 4): "all but the last N" -- sound only while everything
+    counted by lgkmcnt in that loop completes in order, i.e. is an LDS operation.  Scalar memory loads share the counter and
+    return out of order: one inside the loop would let a wait pass before its rows have arrived.  The loop is compiler
+    output, so the invariant is checked on the ISA of every build: no s_load / s_buffer_load in a basic block that holds a
+    counted LDS wait."""
+    import re
+    import shutil
+    hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    if not os.path.exists(hipcc):
+        pytest.skip("no hipcc")
+    asm = tmp_path / "kernels.s"
+    subprocess.check_call([hipcc, "-O3", "-std=c++17", "-ffp-contract=off", "-mllvm", "-amdgpu-sched-strategy=max-ilp",
+                           "--offload-arch=gfx950", "--cuda-device-only", "-S", os.path.join(ROOT, "peba1_amd", "csrc", "kernels.hip"),
+                           "-o", str(asm)], stderr=subprocess.DEVNULL)
+    kernel, block, checked = None, [], 0
+    def flush():
+        nonlocal checked
+        if kernel and "keyswitch_tile_kernel" in kernel and any(re.search(r"lgkmcnt\((4|8|12)\)", i) for i in block):
+            bad = [i for i in block if i.startswith(("s_load", "s_buffer_load", "s_sendmsg", "s_memtime", "s_memrealtime"))]
+            assert not bad, (kernel, bad[:3])
+            checked += 1
+    for line in asm.read_text().split("\n"):
+        m = re.match(r"^(_Z\w+):", line)
+        if m:
+            flush(); kernel, block = m.group(1), []
+            continue
+        if re.match(r"^\.LBB\d+_\d+:", line):
+            flush(); block = []
+            continue
+        t = line.strip()
+        if t and not t.startswith((";", ".", "//")):
+            block.append(t)
+    flush()
+    assert checked >= 6            # three row widths x (plain, in place) of the pipelined form
+
+
 def test_parity_kit_files_are_what_the_oracle_produces():
     """tests/golden/parity_kit: the committed raw-word fixtures are exactly what make_kit.py
     regenerates from the oracle (schoolbook and two-prime evaluators agree inside it), and the product's seeded key
