@@ -203,6 +203,8 @@ def main():
                          "independent matches of its own (--group per flush; BASELINE configs[3]) -- timed on its own, reported "
                          "as `weak_scaling` beside the strong curve; 0 = skip")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-kernel-timing", action="store_true",
+                    help="diagnostic: no HIP events around the launches (the roofline block is then empty): what the events cost")
     ap.add_argument("--extras", type=int, default=1,
                     help="at --gpus 1 --mode match: also run the untimed extra workloads (gate sharing, batched "
                          "matches, 256-slot match, Hamming, optimised DAG); 0 = skip")
@@ -267,7 +269,7 @@ def main():
     def plain_bit(tmpl_vals):
         return 1 if sum((a - b) ** 2 for a, b in zip(probe_vals, tmpl_vals)) > threshold else 0
 
-    L.tfhe_hip_set_kernel_timing(1)
+    L.tfhe_hip_set_kernel_timing(0 if args.no_kernel_timing else 1)
     api.set_deferred(True)
     # The headline executes every gate the circuit records: the library's sharing of identical
     # pending gates (tuning "reuse_gates", on by default) is switched off for the timed steps
