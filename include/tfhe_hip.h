@@ -152,7 +152,7 @@ int tfhe_hip_gate_batch(int gate, LweSample *result, const LweSample *a, const L
  * "ks_target_blocks": a launch's key switches are each cut into 2^s <= 32 ranges of
  * input coefficients until about this many workgroups exist (default 32768, env
  * TFHE_HIP_KS_BLOCKS); 0 disables splitting.
- * "ks_tile": 16 (default) or 32 = launches of at least 2*tile key switches use the tiled
+ * "ks_tile": 16 (default), 24 ("ks_branch" 2 only; elsewhere read as 16) or 32 = launches of at least 2*tile key switches use the tiled
  * kernel (a workgroup streams the KSK rows of one range once for `tile` gates); 0 = always
  * one workgroup per (gate, range); env TFHE_HIP_KS_TILE.
  * "ks_narrow": 1 = in the tiled kernel a thread owns 2 words of the output row instead of 4 (five light waves per
@@ -161,6 +161,11 @@ int tfhe_hip_gate_batch(int gate, LweSample *result, const LweSample *a, const L
  * "ks_pipe": 1 (default) = the tiled kernel issues the LDS reads of the next pair of gates before it subtracts the current
  * pair's rows and waits for "all but the last eight" (105 against 111.5 ms per match); 0 = sixteen reads, then one wait;
  * env TFHE_HIP_KS_PIPE.
+ * "ks_branch": register forms of the tiled kernel -- a thread keeps its 16-byte column of the three rows of a digit position
+ * in registers (loaded straight from global memory a position ahead), no LDS read per subtraction: 2 (default) = pinned
+ * registers addressed through the VGPR index mode by the wave-uniform digit (tiles of 16, 24 or 32; 60.8 ms per match
+ * against 105 ms of the LDS-strip form); 1 = scalar branches on the digit (73 ms); 0 = the LDS-strip form ("ks_pipe",
+ * "ks_narrow" apply to it); ignored with "ks_atomic"; env TFHE_HIP_KS_BRANCH.
  * "ks_atomic": 1 = the ranges of a split key switch add their partial sums into the zeroed destination
  * slot with 32-bit atomic adds (no partial-sum buffer, no reduce launch); 0 (default) = partial sums + reduce;
  * env TFHE_HIP_KS_ATOMIC.  Integer adds commute: the same words either way.

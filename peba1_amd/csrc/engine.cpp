@@ -122,6 +122,7 @@ void Engine::ensure_init() {
     if (const char *env = std::getenv("TFHE_HIP_KS_ATOMIC")) ks_atomic = std::atoi(env);
     if (const char *env = std::getenv("TFHE_HIP_KS_NARROW")) ks_narrow = std::atoi(env);
     if (const char *env = std::getenv("TFHE_HIP_KS_PIPE")) ks_pipe = std::atoi(env);
+    if (const char *env = std::getenv("TFHE_HIP_KS_BRANCH")) ks_branch = std::atoi(env);
     hip_check(hipSetDevice(device_), "hipSetDevice");
     {
         hipDeviceProp_t prop;
@@ -571,6 +572,8 @@ void Engine::launch_ks(const DeviceKeyImage *key, const int32_t *u_buf, const Ks
     if (!stream) stream = stream_;
     const DevParams &dp = key->dp;
     const int nin = dp.k * dp.N;
+    // tiles of 24 gates exist in the index form of the register key switch only (kernels.hip keyswitch_index_kernel)
+    const int ks_tile = (this->ks_tile == 24 && !(ks_branch == 2 && !ks_atomic)) ? 16 : this->ks_tile;
     // tiled kernel: wide launches, ranges of at most 64 input coefficients
     const bool tiled = ks_tile > 0 && count >= 2 * ks_tile && dp.ks_t == 8 && dp.ks_basebit == 2 && ks_max_splits > 1 &&
                        (nin + ks_max_splits - 1) / ks_max_splits <= 64;
@@ -586,7 +589,9 @@ void Engine::launch_ks(const DeviceKeyImage *key, const int32_t *u_buf, const Ks
             // 1008 of 1024 slots in two rounds instead of 36 x 32 = 1152 in three
             const int threads = ((dp.ct_stride / 4 + 63) / 64) * 64;
             const size_t lds = (size_t)16 * threads * 16 + (size_t)ks_tile * 65 * 4;
-            const int per_cu = std::max(1, std::min((int)((160 * 1024) / lds), 8 / (threads / 64)));
+            int per_cu = std::max(1, std::min((int)((160 * 1024) / lds), 8 / (threads / 64)));
+            // register form: no LDS strips; 116 VGPRs at tile 16 (four waves per SIMD), 196 at tile 32 (two)
+            if (ks_branch && !ks_atomic) per_cu = std::max(1, (ks_tile == 16 ? 16 : ks_tile == 24 && ks_branch == 2 ? 12 : 8) / (threads / 64));
             const long long slots = (long long)cu_count_ * per_cu;
             const long long tiles = (cnt + ks_tile - 1) / ks_tile;
             const int lo = std::max(2, (nin + 63) / 64);
@@ -602,7 +607,7 @@ void Engine::launch_ks(const DeviceKeyImage *key, const int32_t *u_buf, const Ks
         int32_t *partial = nullptr;
         if (splits > 1 && !ks_atomic) partial = static_cast<int32_t *>(scratch(10 + (size_t)lane, (size_t)cnt * splits * dp.ct_stride * 4));
         launch_keyswitch(stream, dp, key->key, u_buf, descs + done, cnt, pool, splits, partial, tiled ? ks_tile : 0,
-                         ks_atomic != 0, ks_narrow != 0, ks_pipe != 0);
+                         ks_atomic != 0, ks_narrow != 0, ks_pipe != 0, ks_branch);
     }
 }
 

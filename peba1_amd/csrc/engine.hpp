@@ -153,6 +153,11 @@ public:
     // 1 = the tiled key switch issues the strip reads of the next pair of gates before it subtracts the current pair's rows
     // (keyswitch_tile_kernel PIPE; env TFHE_HIP_KS_PIPE, tuning "ks_pipe"): 105 against 111.5 ms per match, so on
     int ks_pipe = 1;
+    // register forms of the tiled key switch (env TFHE_HIP_KS_BRANCH, tuning "ks_branch"; ignored with ks_atomic):
+    // 2 (default) = a thread's column of the staged rows in PINNED registers, picked through the VGPR index mode
+    // (kernels.hip keyswitch_index_kernel; tiles of 16, 24 or 32): 60.8 ms per match against 105 ms of the LDS-strip form;
+    // 1 = rows in registers, picked by scalar branches (keyswitch_branch_kernel): 73 ms; 0 = the LDS-strip form
+    int ks_branch = 2;
     // two-lane execution: 1 = the urgent lane's blind-rotate waves raise their issue priority
     // (measured slower: the co-resident workgroups of the other lane become its stragglers)
     int lane_prio = 0;

@@ -1651,6 +1651,269 @@ __global__ __launch_bounds__(THREADS) void keyswitch_tile_kernel(DevParams p, De
     }
 }
 
+// Register form of the tiled key switch (round 4, tuning "ks_branch").  The tiled kernel above keeps the staged rows in
+// LDS because the row a gate subtracts is picked by a run-time digit -- and pays one 16-byte LDS read per four
+// subtractions, which is what bounds it (the LDS array moves 128 bytes per cycle and CU; profiles/r04_ks_tile.txt).  But
+// the digit is the same for every lane of a wave: it can live in a SCALAR register and pick the row by a scalar branch.
+// Here a thread holds its 16-byte column of the three non-zero rows of one digit position in registers (loaded straight
+// from global memory, a position ahead), every gate's digit is a scalar bit-field extract of the gate's coefficient word
+// (one v_readfirstlane per gate and coefficient), and a three-way scalar branch runs the four subtractions against the
+// picked row -- or nothing for digit 0, a quarter of all digits, which the LDS form subtracts as a strip of zeros.  No
+// LDS access in the loop except the 16-byte reads of the digit words.  The subtractions are asm volatile so that the
+// compiler cannot turn the branches into per-lane selects (3 v_cndmask per word would cost more than the LDS read).
+// Same grid, same partial sums and reduce launch as the tiled kernel; needs ks_t = 8, ks_basebit = 2.
+// One (gate, digit position): the two bits of the digit are tested in the gate's scalar coefficient word (s_bitcmp1_b32,
+// bit numbers as immediates) and the branch tree runs the four subtractions against the picked row, or none.  Everything
+// -- tests, branches, subtractions -- is ONE asm block: left to the compiler, the same tree comes out with a copy of the
+// accumulator in front of every arm (the arms define new values that it merges through moves: 1,682 v_mov_b32 in a first build).
+template <int SH>
+__device__ __forceinline__ void ks_branch_sub(uint4 &a, uint32_t x, const uint4 &r1, const uint4 &r2, const uint4 &r3) {
+    asm volatile(
+        "s_bitcmp1_b32 %[x], %[hi]\n\t"
+        "s_cbranch_scc1 .Lks_hi_%=\n\t"
+        "s_bitcmp1_b32 %[x], %[lo]\n\t"
+        "s_cbranch_scc0 .Lks_end_%=\n\t"
+        "v_sub_u32 %[a0], %[a0], %[p0]\n\tv_sub_u32 %[a1], %[a1], %[p1]\n\tv_sub_u32 %[a2], %[a2], %[p2]\n\tv_sub_u32 %[a3], %[a3], %[p3]\n\t"
+        "s_branch .Lks_end_%=\n"
+        ".Lks_hi_%=:\n\t"
+        "s_bitcmp1_b32 %[x], %[lo]\n\t"
+        "s_cbranch_scc1 .Lks_three_%=\n\t"
+        "v_sub_u32 %[a0], %[a0], %[q0]\n\tv_sub_u32 %[a1], %[a1], %[q1]\n\tv_sub_u32 %[a2], %[a2], %[q2]\n\tv_sub_u32 %[a3], %[a3], %[q3]\n\t"
+        "s_branch .Lks_end_%=\n"
+        ".Lks_three_%=:\n\t"
+        "v_sub_u32 %[a0], %[a0], %[t0]\n\tv_sub_u32 %[a1], %[a1], %[t1]\n\tv_sub_u32 %[a2], %[a2], %[t2]\n\tv_sub_u32 %[a3], %[a3], %[t3]\n"
+        ".Lks_end_%=:"
+        : [a0] "+v"(a.x), [a1] "+v"(a.y), [a2] "+v"(a.z), [a3] "+v"(a.w)
+        : [x] "s"(x), [hi] "n"(SH + 1), [lo] "n"(SH),
+          [p0] "v"(r1.x), [p1] "v"(r1.y), [p2] "v"(r1.z), [p3] "v"(r1.w),
+          [q0] "v"(r2.x), [q1] "v"(r2.y), [q2] "v"(r2.z), [q3] "v"(r2.w),
+          [t0] "v"(r3.x), [t1] "v"(r3.y), [t2] "v"(r3.z), [t3] "v"(r3.w)
+        : "scc");
+}
+template <int SH, int G>
+__device__ __forceinline__ void ks_branch_apply(uint4 (&acc)[G], const uint32_t (&x)[G], const uint4 &r1, const uint4 &r2,
+                                                const uint4 &r3) {
+#pragma unroll
+    for (int g = 0; g < G; ++g) ks_branch_sub<SH>(acc[g], x[g], r1, r2, r3);
+}
+template <int THREADS, int G>
+__global__ __launch_bounds__(THREADS) void keyswitch_branch_kernel(DevParams p, DevKey key, const int32_t *__restrict__ u_buf,
+                                                                const KsDesc *__restrict__ descs, int count,
+                                                                int32_t *__restrict__ partial) {
+    constexpr int MAXR = 64;
+    __shared__ __align__(16) uint32_t su[MAXR][G];       // [coefficient][gate]
+    __shared__ uint32_t sbody[G];
+    const int tid = threadIdx.x;
+    const int nin = p.k * p.N;
+    const int splits = gridDim.y, split = blockIdx.y;
+    const int i0 = (int)((long long)nin * split / splits), i1 = (int)((long long)nin * (split + 1) / splits);
+    const int range = i1 - i0;
+    const int g0 = blockIdx.x * G;
+    for (int e = tid; e < G * range; e += THREADS) {
+        const int g = e / range, ii = e - g * range;
+        uint32_t v = 0;                                  // gates past the end: every digit 0
+        if (g0 + g < count) {
+            const KsDesc d = descs[g0 + g];
+            v = (uint32_t)u_buf[(size_t)d.u0 * p.u_stride + i0 + ii] + p.ks_prec_offset;
+            if (d.u1 >= 0) v += (uint32_t)u_buf[(size_t)d.u1 * p.u_stride + i0 + ii];
+        }
+        su[ii][g] = v;
+    }
+    if (tid < G && g0 + tid < count) {
+        const KsDesc d = descs[g0 + tid];
+        uint32_t b = (uint32_t)u_buf[(size_t)d.u0 * p.u_stride + nin] + (uint32_t)d.add_b;
+        if (d.u1 >= 0) b += (uint32_t)u_buf[(size_t)d.u1 * p.u_stride + nin];
+        sbody[tid] = b;
+    }
+    __syncthreads();
+    const int nvec = p.ct_stride >> 2;
+    if (tid >= nvec) return;                             // no barrier below
+    const uint4 *src = reinterpret_cast<const uint4 *>(key.ksk) + tid + (size_t)(i0 * 8) * 3 * nvec;
+    const size_t step = (size_t)3 * nvec;
+    uint4 acc[G];
+#pragma unroll
+    for (int g = 0; g < G; ++g) acc[g] = make_uint4(0, 0, 0, 0);
+    // digit j of a coefficient word sits at bits [31-2j, 30-2j]
+    uint4 a1 = src[0], a2 = src[nvec], a3 = src[2 * nvec];
+    for (int ii = 0; ii < range; ++ii) {
+        uint32_t x[G];
+#pragma unroll
+        for (int g = 0; g < G; g += 4) {
+            const uint4 xs = *reinterpret_cast<const uint4 *>(&su[ii][g]);
+            x[g] = __builtin_amdgcn_readfirstlane(xs.x); x[g + 1] = __builtin_amdgcn_readfirstlane(xs.y);
+            x[g + 2] = __builtin_amdgcn_readfirstlane(xs.z); x[g + 3] = __builtin_amdgcn_readfirstlane(xs.w);
+        }
+        const bool last_coeff = ii + 1 == range;
+        // the rows of the next digit position are requested before this position's subtractions (two register sets in
+        // turn, no copies); the very last request of the range re-reads its own rows instead of running past the table
+#define KS_PAIR(JP, LAST)                                                                             \
+        {                                                                                             \
+            src += step;                                                                              \
+            const uint4 b1 = src[0], b2 = src[nvec], b3 = src[2 * nvec];                              \
+            ks_branch_apply<30 - 4 * (JP), G>(acc, x, a1, a2, a3);                                    \
+            if (!(LAST)) src += step;                                                                 \
+            a1 = src[0]; a2 = src[nvec]; a3 = src[2 * nvec];                                          \
+            ks_branch_apply<28 - 4 * (JP), G>(acc, x, b1, b2, b3);                                    \
+        }
+        KS_PAIR(0, false) KS_PAIR(1, false) KS_PAIR(2, false) KS_PAIR(3, last_coeff)
+#undef KS_PAIR
+    }
+#pragma unroll
+    for (int g = 0; g < G; ++g) {
+        if (g0 + g >= count) break;
+        uint32_t o[4] = {acc[g].x, acc[g].y, acc[g].z, acc[g].w};
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const int wi = 4 * tid + e;
+            if (wi == p.n && split == 0) o[e] += sbody[g];
+            if (wi > p.n) o[e] = 0;
+        }
+        reinterpret_cast<uint4 *>(partial + ((size_t)(g0 + g) * splits + split) * p.ct_stride)[tid] = make_uint4(o[0], o[1], o[2], o[3]);
+    }
+}
+
+// Index form of the register key switch (round 4, tuning "ks_branch" 2).  The branch form above is bound by the latency of
+// its taken branches (about 130 cycles per wave, gate and digit whatever the occupancy: tile 32 at two waves per SIMD takes
+// exactly twice as long as tile 16 at four).  gfx9's VGPR index mode removes the branches: with SRC1_REL set, the row
+// operand of a v_sub_u32 is VGPR[encoded + M0[7:0]], so ONE instruction sequence subtracts whichever row the scalar index
+// picks.  The compiler cannot express that (section 5 of DESIGN.md: a dynamically indexed
+// register array goes to scratch memory), and inline asm cannot name a sub-register of a tuple operand -- but an asm operand
+// can be PINNED to physical registers ("{v[96:99]}"), and then the asm text may name them.  Register map (pinned only at
+// the asm statements; the compiler keeps the values there in between because every statement of the loop wants them there):
+// (tile 16; tile 32 has its accumulators in v32..v159 and the rows from v160 -- the statements are generated,
+// tools/gen_ks_index_asm.py -> ks_index_asm.inc)
+//     v32..v95    accumulators, four per gate
+//     v96..v107   rows 1, 2, 3 of an even digit position (set 0)   v108..v119  rows 1, 2, 3 of an odd position (set 1)
+// The prologue stores every coefficient word as eight nibbles 4 x digit; a (gate, position) is s_bfe_u32 of its nibble,
+// a scalar branch over the gate for digit 0 (a quarter of all digits; s_bfe_u32 leaves SCC = result != 0, and a branch
+// that is mostly not taken costs the wave little), s_set_gpr_idx_idx and four v_sub_u32 whose row operand is encoded as
+// the register four below row 1.  M0 is saved and restored around each statement (the compiler treats it as reserved).
+#ifndef KS_IDX_EXPERIMENT
+#define KS_IDX_EXPERIMENT 0
+#endif
+typedef uint32_t ks_u4 __attribute__((ext_vector_type(4)));
+#include "ks_index_asm.inc"      // KsIndexSub<G, OCT, SETB>::run<NIB>: the asm statements (tools/gen_ks_index_asm.py)
+
+// the coefficient word of a gate (digit j at bits [31-2j, 30-2j]) as eight index nibbles (comment above)
+__device__ __forceinline__ uint32_t ks_index_nibbles(uint32_t v) {
+    uint32_t y = 0;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const uint32_t d = (v >> (30 - 2 * j)) & 3u;
+        y |= (d << 2) << (4 * j);
+    }
+    return y;
+}
+
+template <int THREADS, int G>
+__global__ __launch_bounds__(THREADS) void keyswitch_index_kernel(DevParams p, DevKey key, const int32_t *__restrict__ u_buf,
+                                                               const KsDesc *__restrict__ descs, int count,
+                                                               int32_t *__restrict__ partial) {
+    constexpr int MAXR = 64;
+    static_assert(G == 16 || G == 24 || G == 32, "tile sizes the statements are generated for");
+    __shared__ __align__(16) uint32_t su[MAXR][G];       // [coefficient][gate]: index nibbles
+    __shared__ uint32_t sbody[G];
+    const int tid = threadIdx.x;
+    const int nin = p.k * p.N;
+    const int splits = gridDim.y, split = blockIdx.y;
+    const int i0 = (int)((long long)nin * split / splits), i1 = (int)((long long)nin * (split + 1) / splits);
+    const int range = i1 - i0;
+    const int g0 = blockIdx.x * G;
+    for (int e = tid; e < G * range; e += THREADS) {
+        const int g = e / range, ii = e - g * range;
+        uint32_t v = 0;                                  // gates past the end: every digit 0
+        if (g0 + g < count) {
+            const KsDesc d = descs[g0 + g];
+            v = (uint32_t)u_buf[(size_t)d.u0 * p.u_stride + i0 + ii] + p.ks_prec_offset;
+            if (d.u1 >= 0) v += (uint32_t)u_buf[(size_t)d.u1 * p.u_stride + i0 + ii];
+        }
+        su[ii][g] = ks_index_nibbles(v);
+    }
+    if (tid < G && g0 + tid < count) {
+        const KsDesc d = descs[g0 + tid];
+        uint32_t b = (uint32_t)u_buf[(size_t)d.u0 * p.u_stride + nin] + (uint32_t)d.add_b;
+        if (d.u1 >= 0) b += (uint32_t)u_buf[(size_t)d.u1 * p.u_stride + nin];
+        sbody[tid] = b;
+    }
+    __syncthreads();
+    const int nvec = p.ct_stride >> 2;
+    if (tid >= nvec) return;                             // no barrier below
+    const ks_u4 *src = reinterpret_cast<const ks_u4 *>(key.ksk) + tid + (size_t)(i0 * 8) * 3 * nvec;
+    const size_t step = (size_t)3 * nvec;
+    ks_u4 acc[G];
+#pragma unroll
+    for (int g = 0; g < G; ++g) acc[g] = (ks_u4)(0u);
+    ks_u4 a1 = src[0], a2 = src[nvec], a3 = src[2 * nvec];
+    for (int ii = 0; ii < range; ++ii) {
+        uint32_t y[G];
+#pragma unroll
+        for (int g = 0; g < G; g += 4) {
+            const uint4 ys = *reinterpret_cast<const uint4 *>(&su[ii][g]);
+            y[g] = __builtin_amdgcn_readfirstlane(ys.x); y[g + 1] = __builtin_amdgcn_readfirstlane(ys.y);
+            y[g + 2] = __builtin_amdgcn_readfirstlane(ys.z); y[g + 3] = __builtin_amdgcn_readfirstlane(ys.w);
+        }
+        const bool last_coeff = ii + 1 == range;
+        // The rows of the next digit position are requested before this position's subtractions (the two register sets in
+        // turn); the very last request of the range re-reads its own rows instead of running past the table.  (Four sets,
+        // three positions ahead: slower, 67.6 against 60.8 ms per match -- the waves' waits are not load latency.)
+#define KS_IDX_OCT(O, SET, NIB, R1, R2, R3)                                                                                     \
+        KsIndexSub<G, O, SET>::template run<NIB>(acc[8 * (O)], acc[8 * (O) + 1], acc[8 * (O) + 2], acc[8 * (O) + 3],            \
+                                                 acc[8 * (O) + 4], acc[8 * (O) + 5], acc[8 * (O) + 6], acc[8 * (O) + 7],        \
+                                                 R1, R2, R3, y[8 * (O)], y[8 * (O) + 1], y[8 * (O) + 2], y[8 * (O) + 3],        \
+                                                 y[8 * (O) + 4], y[8 * (O) + 5], y[8 * (O) + 6], y[8 * (O) + 7]);
+#define KS_IDX_APPLY(SET, NIB, R1, R2, R3)                                                                                      \
+        KS_IDX_OCT(0, SET, NIB, R1, R2, R3) KS_IDX_OCT(1, SET, NIB, R1, R2, R3)                                                 \
+        if constexpr (G >= 24) { KS_IDX_OCT(2, SET, NIB, R1, R2, R3) }                                                          \
+        if constexpr (G == 32) { KS_IDX_OCT(3, SET, NIB, R1, R2, R3) }
+        // KS_IDX_EXPERIMENT (timing only, wrong results; tools/diag/r4_ksx.sh): 1 = no row loads inside the loop, 2 = the loads
+        // without the subtractions
+#if KS_IDX_EXPERIMENT == 1
+#define KS_IDX_PAIR(JP, LAST)                                                                         \
+        {                                                                                             \
+            KS_IDX_APPLY(0, 2 * (JP), a1, a2, a3)                                                     \
+            KS_IDX_APPLY(1, 2 * (JP) + 1, a1, a2, a3)                                                 \
+        }
+#elif KS_IDX_EXPERIMENT == 2
+#define KS_IDX_KEEP(R) asm volatile("" ::"v"(R));
+#define KS_IDX_PAIR(JP, LAST)                                                                         \
+        {                                                                                             \
+            src += step;                                                                              \
+            const ks_u4 b1 = src[0], b2 = src[nvec], b3 = src[2 * nvec];                              \
+            KS_IDX_KEEP(a1) KS_IDX_KEEP(a2) KS_IDX_KEEP(a3)                                           \
+            if (!(LAST)) src += step;                                                                 \
+            a1 = src[0]; a2 = src[nvec]; a3 = src[2 * nvec];                                          \
+            KS_IDX_KEEP(b1) KS_IDX_KEEP(b2) KS_IDX_KEEP(b3)                                           \
+        }
+#else
+#define KS_IDX_PAIR(JP, LAST)                                                                         \
+        {                                                                                             \
+            src += step;                                                                              \
+            const ks_u4 b1 = src[0], b2 = src[nvec], b3 = src[2 * nvec];                              \
+            KS_IDX_APPLY(0, 2 * (JP), a1, a2, a3)                                                     \
+            if (!(LAST)) src += step;                                                                 \
+            a1 = src[0]; a2 = src[nvec]; a3 = src[2 * nvec];                                          \
+            KS_IDX_APPLY(1, 2 * (JP) + 1, b1, b2, b3)                                                 \
+        }
+#endif
+        KS_IDX_PAIR(0, false) KS_IDX_PAIR(1, false) KS_IDX_PAIR(2, false) KS_IDX_PAIR(3, last_coeff)
+#undef KS_IDX_PAIR
+#undef KS_IDX_APPLY
+#undef KS_IDX_OCT
+    }
+#pragma unroll
+    for (int g = 0; g < G; ++g) {
+        if (g0 + g >= count) break;
+        uint32_t o[4] = {acc[g].x, acc[g].y, acc[g].z, acc[g].w};
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const int wi = 4 * tid + e;
+            if (wi == p.n && split == 0) o[e] += sbody[g];
+            if (wi > p.n) o[e] = 0;
+        }
+        reinterpret_cast<uint4 *>(partial + ((size_t)(g0 + g) * splits + split) * p.ct_stride)[tid] = make_uint4(o[0], o[1], o[2], o[3]);
+    }
+}
+
 // K5: bootsNOT
 __global__ __launch_bounds__(256) void not_kernel(DevParams p, const NotDesc *__restrict__ descs, int32_t *__restrict__ pool) {
     const NotDesc d = descs[blockIdx.x];
@@ -1771,7 +2034,7 @@ void launch_gate_dataflow(hipStream_t s, const DevParams &p, const DevKey &key, 
 
 void launch_keyswitch(hipStream_t s, const DevParams &p, const DevKey &key, const int32_t *u_buf,
                       const KsDesc *descs, int count, int32_t *pool, int splits, int32_t *partial, int tile, bool atomic,
-                      bool narrow, bool pipe) {
+                      bool narrow, bool pipe, int branch) {
     if (count <= 0) return;
     const int threads = ((p.ct_stride / 4 + 63) / 64) * 64;      // one 16-byte lane per 4 output words
     if (splits <= 1 || (!partial && !atomic)) {
@@ -1780,8 +2043,27 @@ void launch_keyswitch(hipStream_t s, const DevParams &p, const DevKey &key, cons
     }
     if (atomic) hipLaunchKernelGGL(ks_zero_kernel, dim3(count), dim3(threads), 0, s, p, descs, pool);
     const int range = (p.k * p.N + splits - 1) / splits;
-    if (tile > 0 && count >= 2 * tile && p.ks_t == 8 && p.ks_basebit == 2 && range <= 64 && (tile == 16 || tile == 32)) {
+    if (tile > 0 && count >= 2 * tile && p.ks_t == 8 && p.ks_basebit == 2 && range <= 64 &&
+        (tile == 16 || tile == 32 || (tile == 24 && branch == 2 && !atomic))) {
         const dim3 grid((count + tile - 1) / tile, splits);
+        // register form: rows in registers, picked by scalar branches (tuning "ks_branch")
+        if (branch == 2 && !atomic && (threads == 128 || threads == 192 || threads == 320)) {
+#define KS_INDEX(T, GT) hipLaunchKernelGGL((keyswitch_index_kernel<T, GT>), grid, dim3(T), 0, s, p, key, u_buf, descs, count, partial)
+            if (tile == 16) { if (threads == 128) KS_INDEX(128, 16); else if (threads == 192) KS_INDEX(192, 16); else KS_INDEX(320, 16); }
+            else if (tile == 24) { if (threads == 128) KS_INDEX(128, 24); else if (threads == 192) KS_INDEX(192, 24); else KS_INDEX(320, 24); }
+            else { if (threads == 128) KS_INDEX(128, 32); else if (threads == 192) KS_INDEX(192, 32); else KS_INDEX(320, 32); }
+#undef KS_INDEX
+            hipLaunchKernelGGL(ks_reduce_kernel, dim3(count), dim3(threads), 0, s, p, descs, splits, partial, pool);
+            return;
+        }
+        if (branch && !atomic && (threads == 128 || threads == 192 || threads == 320)) {
+#define KS_BRANCH(T, GT) hipLaunchKernelGGL((keyswitch_branch_kernel<T, GT>), grid, dim3(T), 0, s, p, key, u_buf, descs, count, partial)
+            if (tile == 16) { if (threads == 128) KS_BRANCH(128, 16); else if (threads == 192) KS_BRANCH(192, 16); else KS_BRANCH(320, 16); }
+            else { if (threads == 128) KS_BRANCH(128, 32); else if (threads == 192) KS_BRANCH(192, 32); else KS_BRANCH(320, 32); }
+#undef KS_BRANCH
+            hipLaunchKernelGGL(ks_reduce_kernel, dim3(count), dim3(threads), 0, s, p, descs, splits, partial, pool);
+            return;
+        }
         // W = 2 form: a thread per 2 words of the row (tuning "ks_narrow")
         const int threads2 = ((p.ct_stride / 2 + 63) / 64) * 64;
         if (narrow && (threads2 == 256 || threads2 == 320 || threads2 == 576)) {

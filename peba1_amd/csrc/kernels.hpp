@@ -91,10 +91,11 @@ void launch_blind_rotate_split(hipStream_t s, const DevParams &p, const DevKey &
 // every range adds its sum with 32-bit atomic adds (tuning "ks_atomic"; same words: integer adds commute)
 // narrow: the tiled launch gives a thread 2 words of the row instead of 4 (more, lighter waves: kernels.hip
 // keyswitch_tile_kernel W; tuning "ks_narrow"); pipe: its strip reads run a pair of gates ahead of the subtractions
-// (keyswitch_tile_kernel PIPE; tuning "ks_pipe"; tiles of 16, 4 words per thread)
+// (keyswitch_tile_kernel PIPE; tuning "ks_pipe"; tiles of 16, 4 words per thread); branch: the rows in registers,
+// picked by scalar branches on the wave-uniform digit (keyswitch_branch_kernel; tuning "ks_branch"; not with atomic)
 void launch_keyswitch(hipStream_t s, const DevParams &p, const DevKey &key, const int32_t *u_buf,
                       const KsDesc *descs, int count, int32_t *pool, int splits, int32_t *partial, int tile,
-                      bool atomic = false, bool narrow = false, bool pipe = false);
+                      bool atomic = false, bool narrow = false, bool pipe = false, int branch = 0);
 void launch_not(hipStream_t s, const DevParams &p, const NotDesc *descs, int count, int32_t *pool);
 // res[c] = ip[c] * (poly whose image is img[c]) through the device NTT
 void launch_negacyclic(hipStream_t s, const DevParams &p, const uint32_t *tw, const int32_t *ip,

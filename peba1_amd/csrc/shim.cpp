@@ -1043,13 +1043,14 @@ int tfhe_hip_set_tuning(const char *name, int64_t value) {
     if (name && std::strcmp(name, "br4_max_rotations") == 0) { Engine::get().br4_max_rotations = (int)value; return 0; }
     if (name && std::strcmp(name, "ks_target_blocks") == 0) { Engine::get().ks_target_blocks = (int)value; return 0; }
     if (name && std::strcmp(name, "ks_tile") == 0) {
-        if (value != 0 && value != 16 && value != 32) { set_error("ks_tile must be 0, 16 or 32"); return -1; }
+        if (value != 0 && value != 16 && value != 24 && value != 32) { set_error("ks_tile must be 0, 16, 24 or 32"); return -1; }
         Engine::get().ks_tile = (int)value;
         return 0;
     }
     if (name && std::strcmp(name, "ks_atomic") == 0) { Engine::get().ks_atomic = value != 0; return 0; }
     if (name && std::strcmp(name, "ks_narrow") == 0) { Engine::get().ks_narrow = value != 0; return 0; }
     if (name && std::strcmp(name, "ks_pipe") == 0) { Engine::get().ks_pipe = value != 0; return 0; }
+    if (name && std::strcmp(name, "ks_branch") == 0) { Engine::get().ks_branch = (int)value; return 0; }
     if (name && std::strcmp(name, "br_fair") == 0) { Engine::get().br_fair = (int)value; return 0; }
     if (name && std::strcmp(name, "br_digit_table") == 0) { Engine::get().br_digit_table = (int)value; return 0; }
     if (name && std::strcmp(name, "br8_max_rotations") == 0) { Engine::get().br8_max_rotations = (int)value; return 0; }

@@ -142,7 +142,7 @@ def test_keyswitch_matches_oracle(p128_keys, oracle, ks_blocks):
         assert (got[c] == oks.keyswitch(u[c])).all(), f"sample {c}"
 
 
-@pytest.mark.parametrize("tile,count", [(16, 32), (16, 45), (32, 64), (32, 77)])
+@pytest.mark.parametrize("tile,count", [(16, 32), (16, 45), (24, 48), (24, 61), (32, 64), (32, 77)])
 def test_tiled_keyswitch_matches_oracle(p128_keys, oracle, tile, count):
     """a17, wide launches: one pass over a range's KSK rows serves a tile of gates; full and
     ragged last tiles, all-zero and all-three digits, against the oracle and the per-gate kernel."""
@@ -155,7 +155,8 @@ def test_tiled_keyswitch_matches_oracle(p128_keys, oracle, tile, count):
     u[count - 1, :-1] = 0x40000000   # digit 1 at the first position only
     api.set_tuning("ks_tile", tile)
     api.set_tuning("ks_pipe", 0)                 # the round-2 form first: sixteen reads, one wait
-    narrow_default, pipe_default = 0, 1
+    narrow_default, pipe_default, branch_default = 0, 1, 2
+    api.set_tuning("ks_branch", 0)               # the LDS-strip forms first
     try:
         forms = {}
         for narrow in (0, 1):                    # a thread per 4 words of the row (default) / per 2 words (round 4, selectable)
@@ -171,6 +172,11 @@ def test_tiled_keyswitch_matches_oracle(p128_keys, oracle, tile, count):
         forms["pipe", 1] = api.kernel_keyswitch(ks, u)
         api.set_tuning("ks_atomic", 0)
         api.set_tuning("ks_pipe", 0)
+        api.set_tuning("ks_branch", 1)           # rows in registers, picked by scalar branches on the digit
+        forms["branch"] = api.kernel_keyswitch(ks, u)
+        api.set_tuning("ks_branch", 2)           # rows in pinned registers, picked through the VGPR index mode (tile 16)
+        forms["index"] = api.kernel_keyswitch(ks, u)
+        api.set_tuning("ks_branch", 0)
         api.set_tuning("ks_tile", 0)
         api.set_tuning("ks_atomic", 1)
         per_gate_in_place = api.kernel_keyswitch(ks, u)
@@ -181,7 +187,9 @@ def test_tiled_keyswitch_matches_oracle(p128_keys, oracle, tile, count):
         api.set_tuning("ks_atomic", 0)
         api.set_tuning("ks_narrow", narrow_default)
         api.set_tuning("ks_pipe", pipe_default)
+        api.set_tuning("ks_branch", branch_default)
     assert (got == per_gate).all() and (in_place == per_gate).all() and (per_gate_in_place == per_gate).all()
+    assert (forms["branch"] == per_gate).all() and (forms["index"] == per_gate).all()
     assert (forms[1, 0] == per_gate).all() and (forms[1, 1] == per_gate).all()
     assert (forms["pipe", 0] == per_gate).all() and (forms["pipe", 1] == per_gate).all()
     for c in list(range(4)) + [count // 2, count - 2, count - 1]:

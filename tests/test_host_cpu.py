@@ -255,21 +255,27 @@ def test_secure_randomness_is_rekeyed_in_a_fork_child():
     assert run.returncode == 0 and "ok" in run.stdout, run.stdout + run.stderr
 
 
-def test_counted_lds_waits_see_no_scalar_memory_load(tmp_path):
+@pytest.fixture(scope="module")
+def kernels_isa(tmp_path_factory):
+    """gfx950 assembly of kernels.hip with the flags of build.sh (one compile for the ISA checks below)."""
+    import shutil
+    hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    if not os.path.exists(hipcc):
+        pytest.skip("no hipcc")
+    asm = tmp_path_factory.mktemp("isa") / "kernels.s"
+    subprocess.check_call([hipcc, "-O3", "-std=c++17", "-ffp-contract=off", "-mllvm", "-amdgpu-sched-strategy=max-ilp",
+                           "--offload-arch=gfx950", "--cuda-device-only", "-S", os.path.join(ROOT, "peba1_amd", "csrc", "kernels.hip"),
+                           "-o", str(asm)], stderr=subprocess.DEVNULL)
+    return asm.read_text()
+
+
+def test_counted_lds_waits_see_no_scalar_memory_load(kernels_isa):
     """The pipelined key switch waits with s_waitcnt lgkmcnt(12 / 8 / 4): "all but the last N" -- sound only while everything
     counted by lgkmcnt in that loop completes in order, i.e. is an LDS operation.  Scalar memory loads share the counter and
     return out of order: one inside the loop would let a wait pass before its rows have arrived.  The loop is compiler
     output, so the invariant is checked on the ISA of every build: no s_load / s_buffer_load in a basic block that holds a
     counted LDS wait."""
     import re
-    import shutil
-    hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
-    if not os.path.exists(hipcc):
-        pytest.skip("no hipcc")
-    asm = tmp_path / "kernels.s"
-    subprocess.check_call([hipcc, "-O3", "-std=c++17", "-ffp-contract=off", "-mllvm", "-amdgpu-sched-strategy=max-ilp",
-                           "--offload-arch=gfx950", "--cuda-device-only", "-S", os.path.join(ROOT, "peba1_amd", "csrc", "kernels.hip"),
-                           "-o", str(asm)], stderr=subprocess.DEVNULL)
     kernel, block, checked = None, [], 0
     def flush():
         nonlocal checked
@@ -277,7 +283,7 @@ def test_counted_lds_waits_see_no_scalar_memory_load(tmp_path):
             bad = [i for i in block if i.startswith(("s_load", "s_buffer_load", "s_sendmsg", "s_memtime", "s_memrealtime"))]
             assert not bad, (kernel, bad[:3])
             checked += 1
-    for line in asm.read_text().split("\n"):
+    for line in kernels_isa.split("\n"):
         m = re.match(r"^(_Z\w+):", line)
         if m:
             flush(); kernel, block = m.group(1), []
@@ -290,6 +296,51 @@ def test_counted_lds_waits_see_no_scalar_memory_load(tmp_path):
             block.append(t)
     flush()
     assert checked >= 6            # three row widths x (plain, in place) of the pipelined form
+
+
+def test_index_keyswitch_statements_are_current_and_fit_their_registers(kernels_isa):
+    """The index form of the key switch (kernels.hip keyswitch_index_kernel) names physical registers in its asm text and
+    pins its operands to them; the statements are generated.  Checked on every build: the committed ks_index_asm.inc is
+    what tools/gen_ks_index_asm.py writes; between s_set_gpr_idx_on and s_set_gpr_idx_off (where EVERY vector instruction's
+    second source is taken relative to M0) there is nothing but the statements' own instructions; no build of the kernel
+    spills; the tile-16 form stays within 128 VGPRs (four waves per SIMD) and its loop copies nothing into the pinned rows."""
+    import importlib.util
+    import re
+    spec = importlib.util.spec_from_file_location("gen_ks_index_asm", os.path.join(ROOT, "tools", "gen_ks_index_asm.py"))
+    gen = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(gen)
+    assert open(os.path.join(ROOT, "peba1_amd", "csrc", "ks_index_asm.inc")).read() == gen.generate(), \
+        "peba1_amd/csrc/ks_index_asm.inc is stale: run python tools/gen_ks_index_asm.py"
+    bodies = {}
+    for m in re.finditer(r"^(_ZN\w*keyswitch_index_kernelILi(\d+)ELi(\d+)E\w*):[^\n]*\n(.*?)s_endpgm", kernels_isa, re.S | re.M):
+        bodies[int(m.group(2)), int(m.group(3))] = (m.group(1), m.group(4))
+    assert set(bodies) == {(t, g) for t in (128, 192, 320) for g in (16, 24, 32)}
+    allowed = ("v_sub_u32", "s_bfe_u32", "s_cbranch_scc0", "s_set_gpr_idx_idx", ".Lksi_")
+    for (threads, g), (name, body) in bodies.items():
+        vgprs = int(re.search(re.escape(name) + r"\.num_vgpr, (\d+)", kernels_isa).group(1))
+        scratch = int(re.search(re.escape(name) + r"\.private_seg_size, (\d+)", kernels_isa).group(1))
+        assert scratch == 0, (threads, g, scratch)
+        assert vgprs <= {16: 128, 24: 168, 32: 256}[g], (threads, g, vgprs)
+        inside, regions = False, 0
+        for line in body.split("\n"):
+            t = line.strip()
+            if not t or t.startswith(";"):
+                continue
+            if t.startswith("s_set_gpr_idx_on"):
+                assert not inside
+                inside, regions = True, regions + 1
+            elif t.startswith("s_set_gpr_idx_off"):
+                assert inside
+                inside = False
+            elif inside:
+                assert t.startswith(allowed), (threads, g, t)
+        assert not inside and regions == 8 * (g // 8)          # eight digit positions x one statement per eight gates
+        if g == 16:
+            loop = body[body.index("Loop Header"):]
+            rows = range(32 + 4 * g, 32 + 4 * g + 24)
+            copies = [l for l in loop.split("\n") if re.match(r"\s*v_mov_b(32|64)", l) and
+                      int(re.search(r"v\[?(\d+)", l).group(1)) in rows]
+            assert not copies, copies[:3]
 
 
 def test_parity_kit_files_are_what_the_oracle_produces():
