@@ -123,7 +123,6 @@ void Engine::ensure_init() {
     if (const char *env = std::getenv("TFHE_HIP_KS_NARROW")) ks_narrow = std::atoi(env);
     if (const char *env = std::getenv("TFHE_HIP_KS_PIPE")) ks_pipe = std::atoi(env);
     if (const char *env = std::getenv("TFHE_HIP_KS_BRANCH")) ks_branch = std::atoi(env);
-    if (const char *env = std::getenv("TFHE_HIP_KS_CU_MAP")) ks_cu_map = std::atoi(env);
     hip_check(hipSetDevice(device_), "hipSetDevice");
     {
         hipDeviceProp_t prop;
@@ -608,7 +607,7 @@ void Engine::launch_ks(const DeviceKeyImage *key, const int32_t *u_buf, const Ks
         int32_t *partial = nullptr;
         if (splits > 1 && !ks_atomic) partial = static_cast<int32_t *>(scratch(10 + (size_t)lane, (size_t)cnt * splits * dp.ct_stride * 4));
         launch_keyswitch(stream, dp, key->key, u_buf, descs + done, cnt, pool, splits, partial, tiled ? ks_tile : 0,
-                         ks_atomic != 0, ks_narrow != 0, ks_pipe != 0, ks_branch, ks_cu_map ? cu_count_ : 0);
+                         ks_atomic != 0, ks_narrow != 0, ks_pipe != 0, ks_branch);
     }
 }
 

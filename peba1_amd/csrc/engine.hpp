@@ -158,9 +158,6 @@ public:
     // (kernels.hip keyswitch_index_kernel; tiles of 16, 24 or 32): 60.8 ms per match against 105 ms of the LDS-strip form;
     // 1 = rows in registers, picked by scalar branches (keyswitch_branch_kernel): 73 ms; 0 = the LDS-strip form
     int ks_branch = 2;
-    // 1 = the index form's workgroups that share a CU take tiles of ONE coefficient range (same KSK rows at the same time:
-    // L1 hits instead of L2 fetches; kernels.hip keyswitch_index_kernel; env TFHE_HIP_KS_CU_MAP, tuning "ks_cu_map")
-    int ks_cu_map = 0;
     // two-lane execution: 1 = the urgent lane's blind-rotate waves raise their issue priority
     // (measured slower: the co-resident workgroups of the other lane become its stragglers)
     int lane_prio = 0;

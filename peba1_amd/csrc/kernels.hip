@@ -1808,30 +1808,17 @@ __device__ __forceinline__ uint32_t ks_index_nibbles(uint32_t v) {
 template <int THREADS, int G>
 __global__ __launch_bounds__(THREADS) void keyswitch_index_kernel(DevParams p, DevKey key, const int32_t *__restrict__ u_buf,
                                                                const KsDesc *__restrict__ descs, int count,
-                                                               int32_t *__restrict__ partial, int tiles, int splits, int ncu) {
+                                                               int32_t *__restrict__ partial) {
     constexpr int MAXR = 64;
     static_assert(G == 16 || G == 24 || G == 32, "tile sizes the statements are generated for");
     __shared__ __align__(16) uint32_t su[MAXR][G];       // [coefficient][gate]: index nibbles
     __shared__ uint32_t sbody[G];
     const int tid = threadIdx.x;
     const int nin = p.k * p.N;
-    // Which (tile, range) a workgroup takes.  ncu == 0: grid (tiles, splits) as it stands.  ncu > 0 (tuning "ks_cu_map"): a
-    // 1-D grid of ncu * R workgroups, R = ceil(tiles * splits / ncu); the dispatcher hands consecutive workgroups to the CUs
-    // in turn, so workgroups k, k + ncu, k + 2 ncu, ... share a CU -- they take CONSECUTIVE items of the range-major list,
-    // i.e. tiles of the same coefficient range, and walk the same KSK rows at the same time: the second to fifth fetch of a
-    // row hits the CU's vector L1 instead of going to L2 (the kernel is at the L2's delivery rate: DESIGN.md section 5).
-    // Placement is speed only: any map of workgroups to items that covers every item once gives the same sums.
-    int tile = blockIdx.x, split = blockIdx.y;
-    if (ncu > 0) {
-        const int total = tiles * splits, per = (total + ncu - 1) / ncu;
-        const int item = ((int)blockIdx.x % ncu) * per + (int)blockIdx.x / ncu;
-        if (item >= total) return;
-        split = item / tiles;
-        tile = item - split * tiles;
-    }
+    const int splits = gridDim.y, split = blockIdx.y;
     const int i0 = (int)((long long)nin * split / splits), i1 = (int)((long long)nin * (split + 1) / splits);
     const int range = i1 - i0;
-    const int g0 = tile * G;
+    const int g0 = blockIdx.x * G;
     for (int e = tid; e < G * range; e += THREADS) {
         const int g = e / range, ii = e - g * range;
         uint32_t v = 0;                                  // gates past the end: every digit 0
@@ -2047,7 +2034,7 @@ void launch_gate_dataflow(hipStream_t s, const DevParams &p, const DevKey &key, 
 
 void launch_keyswitch(hipStream_t s, const DevParams &p, const DevKey &key, const int32_t *u_buf,
                       const KsDesc *descs, int count, int32_t *pool, int splits, int32_t *partial, int tile, bool atomic,
-                      bool narrow, bool pipe, int branch, int ncu) {
+                      bool narrow, bool pipe, int branch) {
     if (count <= 0) return;
     const int threads = ((p.ct_stride / 4 + 63) / 64) * 64;      // one 16-byte lane per 4 output words
     if (splits <= 1 || (!partial && !atomic)) {
@@ -2061,9 +2048,7 @@ void launch_keyswitch(hipStream_t s, const DevParams &p, const DevKey &key, cons
         const dim3 grid((count + tile - 1) / tile, splits);
         // register form: rows in registers, picked by scalar branches (tuning "ks_branch")
         if (branch == 2 && !atomic && (threads == 128 || threads == 192 || threads == 320)) {
-            const int tiles = (count + tile - 1) / tile, total = tiles * splits;
-            const dim3 igrid = ncu > 0 ? dim3((unsigned)(ncu * ((total + ncu - 1) / ncu))) : grid;
-#define KS_INDEX(T, GT) hipLaunchKernelGGL((keyswitch_index_kernel<T, GT>), igrid, dim3(T), 0, s, p, key, u_buf, descs, count, partial, tiles, splits, ncu)
+#define KS_INDEX(T, GT) hipLaunchKernelGGL((keyswitch_index_kernel<T, GT>), grid, dim3(T), 0, s, p, key, u_buf, descs, count, partial)
             if (tile == 16) { if (threads == 128) KS_INDEX(128, 16); else if (threads == 192) KS_INDEX(192, 16); else KS_INDEX(320, 16); }
             else if (tile == 24) { if (threads == 128) KS_INDEX(128, 24); else if (threads == 192) KS_INDEX(192, 24); else KS_INDEX(320, 24); }
             else { if (threads == 128) KS_INDEX(128, 32); else if (threads == 192) KS_INDEX(192, 32); else KS_INDEX(320, 32); }

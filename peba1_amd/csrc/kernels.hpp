@@ -92,12 +92,10 @@ void launch_blind_rotate_split(hipStream_t s, const DevParams &p, const DevKey &
 // narrow: the tiled launch gives a thread 2 words of the row instead of 4 (more, lighter waves: kernels.hip
 // keyswitch_tile_kernel W; tuning "ks_narrow"); pipe: its strip reads run a pair of gates ahead of the subtractions
 // (keyswitch_tile_kernel PIPE; tuning "ks_pipe"; tiles of 16, 4 words per thread); branch: the rows in registers,
-// picked by scalar branches on the wave-uniform digit (1: keyswitch_branch_kernel) or through the VGPR index mode (2:
-// keyswitch_index_kernel; tiles of 16, 24, 32) -- tuning "ks_branch"; not with atomic.  ncu > 0: the index form maps
-// the workgroups that share a CU onto tiles of one coefficient range (tuning "ks_cu_map")
+// picked by scalar branches on the wave-uniform digit (keyswitch_branch_kernel; tuning "ks_branch"; not with atomic)
 void launch_keyswitch(hipStream_t s, const DevParams &p, const DevKey &key, const int32_t *u_buf,
                       const KsDesc *descs, int count, int32_t *pool, int splits, int32_t *partial, int tile,
-                      bool atomic = false, bool narrow = false, bool pipe = false, int branch = 0, int ncu = 0);
+                      bool atomic = false, bool narrow = false, bool pipe = false, int branch = 0);
 void launch_not(hipStream_t s, const DevParams &p, const NotDesc *descs, int count, int32_t *pool);
 // res[c] = ip[c] * (poly whose image is img[c]) through the device NTT
 void launch_negacyclic(hipStream_t s, const DevParams &p, const uint32_t *tw, const int32_t *ip,

@@ -1051,7 +1051,6 @@ int tfhe_hip_set_tuning(const char *name, int64_t value) {
     if (name && std::strcmp(name, "ks_narrow") == 0) { Engine::get().ks_narrow = value != 0; return 0; }
     if (name && std::strcmp(name, "ks_pipe") == 0) { Engine::get().ks_pipe = value != 0; return 0; }
     if (name && std::strcmp(name, "ks_branch") == 0) { Engine::get().ks_branch = (int)value; return 0; }
-    if (name && std::strcmp(name, "ks_cu_map") == 0) { Engine::get().ks_cu_map = value != 0; return 0; }
     if (name && std::strcmp(name, "br_fair") == 0) { Engine::get().br_fair = (int)value; return 0; }
     if (name && std::strcmp(name, "br_digit_table") == 0) { Engine::get().br_digit_table = (int)value; return 0; }
     if (name && std::strcmp(name, "br8_max_rotations") == 0) { Engine::get().br8_max_rotations = (int)value; return 0; }

@@ -155,7 +155,7 @@ def test_tiled_keyswitch_matches_oracle(p128_keys, oracle, tile, count):
     u[count - 1, :-1] = 0x40000000   # digit 1 at the first position only
     api.set_tuning("ks_tile", tile)
     api.set_tuning("ks_pipe", 0)                 # the round-2 form first: sixteen reads, one wait
-    narrow_default, pipe_default, branch_default, map_default = 0, 1, 2, 0
+    narrow_default, pipe_default, branch_default = 0, 1, 2
     api.set_tuning("ks_branch", 0)               # the LDS-strip forms first
     try:
         forms = {}
@@ -176,9 +176,6 @@ def test_tiled_keyswitch_matches_oracle(p128_keys, oracle, tile, count):
         forms["branch"] = api.kernel_keyswitch(ks, u)
         api.set_tuning("ks_branch", 2)           # rows in pinned registers, picked through the VGPR index mode (tile 16)
         forms["index"] = api.kernel_keyswitch(ks, u)
-        api.set_tuning("ks_cu_map", 1)           # ... with the workgroups of a CU on tiles of one coefficient range
-        forms["index_map"] = api.kernel_keyswitch(ks, u)
-        api.set_tuning("ks_cu_map", 0)
         api.set_tuning("ks_branch", 0)
         api.set_tuning("ks_tile", 0)
         api.set_tuning("ks_atomic", 1)
@@ -191,9 +188,8 @@ def test_tiled_keyswitch_matches_oracle(p128_keys, oracle, tile, count):
         api.set_tuning("ks_narrow", narrow_default)
         api.set_tuning("ks_pipe", pipe_default)
         api.set_tuning("ks_branch", branch_default)
-        api.set_tuning("ks_cu_map", map_default)
     assert (got == per_gate).all() and (in_place == per_gate).all() and (per_gate_in_place == per_gate).all()
-    assert (forms["branch"] == per_gate).all() and (forms["index"] == per_gate).all() and (forms["index_map"] == per_gate).all()
+    assert (forms["branch"] == per_gate).all() and (forms["index"] == per_gate).all()
     assert (forms[1, 0] == per_gate).all() and (forms[1, 1] == per_gate).all()
     assert (forms["pipe", 0] == per_gate).all() and (forms["pipe", 1] == per_gate).all()
     for c in list(range(4)) + [count // 2, count - 2, count - 1]:
