@@ -675,6 +675,7 @@ void Engine::execute(const DeviceKeyImage *key, SlotPool *pool, LevelPlan &&plan
     int waited[2][2] = {{0, 0}, {0, 0}};                 // waited[s][o]: lane s already waits for lane o up to this level+1
 #endif
     int last_group[2] = {-1, -1};
+    hipEvent_t shared_end = nullptr;
     for (int L = 0; L <= levels; ++L) {
         for (int s = 0; s < K; ++s) {
             const size_t gn = (size_t)L * K + s;                     // NOT / need index
@@ -695,7 +696,14 @@ void Engine::execute(const DeviceKeyImage *key, SlotPool *pool, LevelPlan &&plan
             }
 #endif
             Timed t{nullptr, nullptr, nullptr, false, nrot};
-            if (kernel_timing) { t.e0 = timing_event(); hip_check(hipEventRecord(t.e0, st), "event"); }
+            // a level's start event is the previous level's end event where nothing was enqueued in between (one lane, no
+            // NOT launch behind the key switch): two events per level instead of three -- an event costs the stream
+            // a few microseconds, 1,131 of them 4-15 ms of a match
+            if (kernel_timing) {
+                if (shared_end) t.e0 = shared_end;
+                else { t.e0 = timing_event(); hip_check(hipEventRecord(t.e0, st), "event"); }
+                shared_end = nullptr;
+            }
             if (nrot) {
                 in_execute_ = true;
                 t.wide8 = launch_br(key, pool->data(), drots + plan.rot_off[gg], nrot, u_buf[s], nullptr, st, K > 1 && s == 0 ? lane_prio : 0);
@@ -710,7 +718,10 @@ void Engine::execute(const DeviceKeyImage *key, SlotPool *pool, LevelPlan &&plan
             }
             if (kernel_timing) { t.e1 = timing_event(); hip_check(hipEventRecord(t.e1, st), "event"); }
             if (nks) launch_ks(key, u_buf[s], dks + plan.ks_off[gg], nks, pool->data(), st, s);
-            if (kernel_timing) { t.e2 = timing_event(); hip_check(hipEventRecord(t.e2, st), "event"); timed.push_back(t); }
+            if (kernel_timing) {
+                t.e2 = timing_event(); hip_check(hipEventRecord(t.e2, st), "event"); timed.push_back(t);
+                if (K == 1 && nnot == 0) shared_end = t.e2;
+            }
             launch_not(st, key->dp, dnots + plan.not_off[gn], nnot, pool->data());
 #ifdef TFHE_HIP_EXPERIMENTAL
             if (K > 1) hip_check(hipEventRecord(order_events_[gn], st), "lane event");
