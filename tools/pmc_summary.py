@@ -24,7 +24,8 @@ def kernel_source_hash():
             h.update(fh.read())
     return h.hexdigest()[:16]
 
-WIDE_STREAM = ("blind_rotate_kernel", "blind_rotate4_kernel", "blind_rotate8_kernel", "keyswitch_kernel", "keyswitch_tile_kernel")
+WIDE_STREAM = ("blind_rotate_kernel", "blind_rotate4_kernel", "blind_rotate8_kernel", "keyswitch_kernel", "keyswitch_tile_kernel",
+               "keyswitch_branch_kernel", "keyswitch_index_kernel")
 
 
 def short(name):
