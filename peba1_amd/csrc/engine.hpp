@@ -138,9 +138,12 @@ public:
     int br4_max_rotations = 1 << 30;
     // key switches of a launch are split (power of two <= ks_max_splits) until about this many
     // workgroups exist: beyond filling the chip, more splits mean the blocks in flight share a
-    // KSK sub-table small enough for an XCD's L2 (measured optimum: 32 splits)
+    // KSK sub-table small enough for an XCD's L2 (measured optimum of the per-gate kernel: 32 splits).  The tiled launches
+    // take any count of coefficient ranges up to ks_max_splits whose grid fills whole rounds of resident workgroups
+    // (launch_ks); with the index form of the key switch a cap of 48 measured 56.1 against 61.0 ms per match at 32
+    // (24: 64.4, 64: 57.1; tools/diag/r4_ks_splits.sh, env TFHE_HIP_KS_MAX_SPLITS)
     int ks_target_blocks = 32768;
-    int ks_max_splits = 32;
+    int ks_max_splits = 48;
     // gates per workgroup of the tiled key switch (16 or 32; 0 = per-gate kernel only)
     int ks_tile = 16;
     // 1 = the coefficient ranges of a key switch add their partial sums into the (zeroed) destination slot with
