@@ -123,6 +123,7 @@ void Engine::ensure_init() {
     if (const char *env = std::getenv("TFHE_HIP_KS_NARROW")) ks_narrow = std::atoi(env);
     if (const char *env = std::getenv("TFHE_HIP_KS_PIPE")) ks_pipe = std::atoi(env);
     if (const char *env = std::getenv("TFHE_HIP_KS_BRANCH")) ks_branch = std::atoi(env);
+    if (const char *env = std::getenv("TFHE_HIP_KS_SPLIT_TIES")) ks_split_ties = std::atoi(env);
     hip_check(hipSetDevice(device_), "hipSetDevice");
     {
         hipDeviceProp_t prop;
@@ -599,7 +600,8 @@ void Engine::launch_ks(const DeviceKeyImage *key, const int32_t *u_buf, const Ks
             for (int sp = lo; sp <= ks_max_splits; ++sp) {
                 const long long blocks = tiles * sp, rounds = (blocks + slots - 1) / slots;
                 const double eff = (double)blocks / (double)(rounds * slots);
-                if (eff >= best - 1e-9) { best = eff; splits = sp; }        // ties: more, shorter ranges
+                // ties: fewer, longer ranges (less partial-sum traffic) or more, shorter ones (ks_split_ties)
+                if (ks_split_ties ? eff >= best - 1e-9 : eff > best + 1e-9) { best = eff; splits = sp; }
             }
         } else {
             while (splits < ks_max_splits && cnt * splits * 2 <= ks_target_blocks) splits *= 2;

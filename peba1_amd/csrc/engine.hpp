@@ -144,6 +144,10 @@ public:
     // (24: 64.4, 64: 57.1; tools/diag/r4_ks_splits.sh, env TFHE_HIP_KS_MAX_SPLITS)
     int ks_target_blocks = 32768;
     int ks_max_splits = 48;
+    // among the range counts that fill the workgroup slots equally well: 1 = the largest (more, shorter ranges), 0 = the smallest
+    // (less partial-sum traffic; 16 matches per flush: key switch 772 against 834 ms, one match 55.4 against 56.1 ms;
+    // env TFHE_HIP_KS_SPLIT_TIES)
+    int ks_split_ties = 0;
     // gates per workgroup of the tiled key switch (16 or 32; 0 = per-gate kernel only)
     int ks_tile = 16;
     // 1 = the coefficient ranges of a key switch add their partial sums into the (zeroed) destination slot with
