@@ -55,12 +55,10 @@ def algorithmic_bytes(pp):
 
 
 def kernel_source_hash():
-    """Identifies the kernels a committed counter summary was measured on."""
-    h = hashlib.sha256()
-    for f in ("kernels.hip", "ntt_wave.hpp", "ntt_field.hpp"):
-        with open(os.path.join(ROOT, "peba1_amd", "csrc", f), "rb") as fh:
-            h.update(fh.read())
-    return h.hexdigest()[:16]
+    """Identifies the kernels a committed counter summary was measured on: every file kernels.hip is built from, the
+    generated key-switch statements and build.sh with its compile flags (peba1_amd/kernel_id.py)."""
+    from peba1_amd.kernel_id import kernels_sha16
+    return kernels_sha16()
 
 
 def committed_counters():
@@ -101,6 +99,78 @@ def committed_set_profile(name):
             "valu_insts_per_wave_step", "valu_busy_frac", "wave_cycles_issuing", "wave_cycles_issue_stalled", "wave_cycles_parked",
             "wave_cycles_lds_issue_stalled", "lds_conflict_share_of_active", "kernels_sha16")
     return {k: j[k] for k in keep if k in j}
+
+
+MI355X_CUS = 256        # /opt/skills/guides/MI355X_MICROARCH.md: 8 XCDs x 32 CUs, 4 SIMDs per CU
+
+
+def valu_issue_model():
+    """The roofline that binds: cycles one SIMD needs just to ISSUE the vector instructions of one
+    blind-rotate step, from two tracked files -- profiles/isa_mix.json (static instruction mix per wave and step of the
+    kernels as built, tools/isa_mix.py at build() time; quoted only while its kernels_sha16 is the running one) priced
+    with profiles/valu_issue_costs.json (measured issue cost per instruction class, tools/valu_rates*.hip).
+    Returns {kernel: {...}} or None."""
+    try:
+        with open(os.path.join(ROOT, "profiles", "isa_mix.json")) as f:
+            mix = json.load(f)
+        with open(os.path.join(ROOT, "profiles", "valu_issue_costs.json")) as f:
+            costs = json.load(f)["classes"]
+    except (OSError, ValueError, KeyError):
+        return None
+    if mix.get("kernels_sha16") != kernel_source_hash():
+        return None
+    out = {}
+    for name, k in mix["kernels"].items():
+        cycles, per_role, resident = 0.0, [], 0
+        for role in k["roles"]:
+            v = role["variants"][0]                         # the heaviest variant of the role (they differ in scalar code only)
+            resident += role["waves_per_simd"]
+        for role in k["roles"]:
+            v = role["variants"][0]
+            rate = "two_waves_per_simd" if resident >= 2 else "one_wave_per_simd"
+            c = sum(v[cls] * costs[cls][rate] for cls in ("mul", "three_operand", "two_operand"))
+            cycles += c * role["waves_per_simd"]
+            per_role.append({"role": role["role"], "waves_per_simd": role["waves_per_simd"], "gadget_rows": role["gadget_rows"],
+                             "valu": v["valu"], "mul": v["mul"], "three_operand": v["three_operand"], "two_operand": v["two_operand"],
+                             "lds": v["lds"], "barriers": v["barriers"], "issue_cycles_per_wave_step": c})
+        out[name] = {"l": k["l"], "insts_per_wave_step": per_role, "model_cycles_per_simd_step": cycles}
+    return out
+
+
+def valu_issue_block(gates4096, sweep):
+    """`roofline.valu_issue`: the model above beside what a step takes -- launch time x shader clock / rounds / steps of
+    the 4,096-gate launches (4-wave form: two workgroups per CU, 8 rounds; split form at N = 2048: one per CU, 16 rounds)
+    and of the 256-gate launch of the batch sweep (8-wave form: one round).  frac = model / measured <= 1: the share of a
+    step's cycles that the SIMD's vector issue port is busy by the issue-cost model; the rest is LDS issue, waits and
+    barrier skew."""
+    model = valu_issue_model()
+    if model is None:
+        return None
+    blk = {"files": ["profiles/isa_mix.json", "profiles/valu_issue_costs.json"], "kernels_sha16": kernel_source_hash(),
+           "costs_cycles_per_wave_instruction_two_waves_per_simd": {"mul": 5.4, "three_operand": 5.2, "two_operand": 3.0},
+           "kernels": model, "frac": None}
+
+    def measured(entry, name, n_steps, per_cu, gates):
+        if not entry or name not in model or not entry.get("shader_clock_ghz"):
+            return
+        rounds = -(-gates // (per_cu * MI355X_CUS))
+        cyc = entry["ms_blind_rotate"] * 1e-3 * entry["shader_clock_ghz"] * 1e9 / rounds / n_steps
+        m = model[name]
+        m.update({"measured_cycles_per_simd_step": cyc, "measured_on": f"{gates} independent gates, {rounds} round(s) of {per_cu} "
+                  f"workgroup(s) per CU, {n_steps} steps, {entry['ms_blind_rotate']:.3f} ms at {entry['shader_clock_ghz']:.3f} GHz",
+                  "frac": m["model_cycles_per_simd_step"] / cyc})
+    if gates4096:
+        measured(gates4096.get("P128"), "blind_rotate4_kernel<10,0,true>", 630, 2, 4096)
+        measured(gates4096.get("P80"), "blind_rotate4_kernel<10,0,false>", 500, 2, 4096)
+        measured(gates4096.get("P2048"), "blind_rotate_split_kernel<11,2>", 1024, 1, 4096)
+    if sweep:
+        measured(sweep.get("256"), "blind_rotate8_kernel<10,true>", 630, 1, 256)
+    head = model.get("blind_rotate4_kernel<10,0,true>", {})
+    blk["frac"] = head.get("frac")
+    blk["insts_per_wave_step"] = head.get("insts_per_wave_step")
+    blk["model_cycles_per_simd_step"] = head.get("model_cycles_per_simd_step")
+    blk["measured_cycles_per_simd_step"] = head.get("measured_cycles_per_simd_step")
+    return blk
 
 
 def cpu_baseline(seed):
@@ -180,6 +250,63 @@ def cpu_baseline(seed):
                                     "approximate arithmetic, not the parity oracle"}}
 
 
+def self_launch(n):
+    """The parent of `python bench.py --gpus N` (N > 1, no WORLD_SIZE in the environment): starts
+    `python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py <same arguments>` as a CHILD process
+    (subprocess; no exec, and this process never initialises the GPU), rendezvous on the loopback address at a free port,
+    relays the children's output (rank 0's JSON line last, on stdout) and returns the launcher's exit code -- non-zero
+    if any rank failed."""
+    import socket
+    import subprocess
+    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as sock:
+        sock.bind(("127.0.0.1", 0))
+        port = sock.getsockname()[1]
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")          # dmabuf IPC: what RCCL needs on this driver
+    env.setdefault("OMP_NUM_THREADS", "1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    proc = subprocess.Popen(cmd, env=env, cwd=ROOT, stdout=subprocess.PIPE, text=True, bufsize=1)
+    line_json = None
+    for line in proc.stdout:
+        if line.startswith("{") and line.rstrip().endswith("}"):
+            line_json = line
+        else:
+            sys.stderr.write(line)                              # launcher chatter, other ranks' prints
+    rc = proc.wait()
+    if line_json is not None:
+        sys.stdout.write(line_json)
+        sys.stdout.flush()
+    if rc == 0 and line_json is None:
+        sys.stderr.write("bench.py: the ranks exited cleanly but rank 0 printed no JSON line\n")
+        rc = 1
+    return rc
+
+
+def dist_evidence(dist, L, comm, args, world, rank, local_rank):
+    """Who took part: every rank's PCI bus id as libtfhe-hip reports it for the device it runs on (all-gathered), the RCCL
+    version libpeba1-dist opened, what the communicator has done.  N ranks on N distinct bus ids = N GPUs."""
+    import socket
+    buf = ctypes.create_string_buffer(64)
+    L.tfhe_hip_device_pci_bus_id(buf, 64)
+    mine = {"rank": rank, "local_rank": local_rank, "device": int(L.tfhe_hip_get_device()), "pci_bus_id": buf.value.decode(),
+            "host": socket.gethostname(), "pid": os.getpid(),
+            "collectives": comm.counters() if comm is not None else None}
+    everyone = [None] * world
+    dist.all_gather_object(everyone, mine)
+    if rank != 0:
+        return None
+    from peba1_amd import dist as pd
+    ids = [e["pci_bus_id"] for e in everyone]
+    c0 = everyone[0]["collectives"] or {}
+    return {"backend": "rccl" if args.backend == "nccl" else "gloo (host-memory rehearsal on shared GPUs; not a measurement)",
+            "torch_backend": dist.get_backend(), "world": world,
+            "rccl_version": pd.load().peba1_dist_rccl_version() if args.backend == "nccl" else None,
+            "devices": ids, "distinct_devices": len(set(ids)), "one_gpu_per_rank": len(set(ids)) == world,
+            "status_word_collectives": c0.get("status_word_exchanges"), "data_collectives": {k: c0.get(k) for k in ("gathers", "broadcasts")},
+            "transport": c0.get("transport"), "ranks": everyone}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -202,6 +329,9 @@ def main():
                     help="--gpus N > 1, --mode sharded: after the timed (strong-scaling) steps every rank also runs this many "
                          "independent matches of its own (--group per flush; BASELINE configs[3]) -- timed on its own, reported "
                          "as `weak_scaling` beside the strong curve; 0 = skip")
+    ap.add_argument("--reference-combine-leg", type=int, default=1,
+                    help="--gpus N > 1, --mode sharded without --ripple-combine: also time ONE match with the reference-order "
+                         "combine on rank 0 (SURVEY 8e's ADDN tree + minimum), reported as `reference_order_combine`; 0 = skip")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-timing", action="store_true",
                     help="diagnostic: no HIP events around the launches (the roofline block is then empty): what the events cost")
@@ -216,11 +346,17 @@ def main():
                          "logic can be rehearsed with several processes on ONE GPU (tests do; never a measurement)")
     args = ap.parse_args()
 
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # `python bench.py --gpus N` with no launcher: THIS process becomes the launcher and nothing else -- it has not
+        # loaded libtfhe-hip, torch.cuda or any HIP library and never will (a process that has touched the GPU must not
+        # start or become another one on this pool), starts one fresh process per GPU and relays rank 0's line
+        raise SystemExit(self_launch(args.gpus))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != args.gpus and world == 1 and args.gpus > 1:
-        raise SystemExit("launch N>1 with torch.distributed.run (one process per GPU)")
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch one process per GPU "
+                         f"(`python bench.py --gpus N` does it by itself)")
     mode = args.mode
     if mode == "auto":
         mode = "match" if world == 1 else "sharded"
@@ -278,6 +414,7 @@ def main():
     api.set_tuning("eliminate_dead", 0)     # likewise: gates whose result nothing can observe are executed too
 
     checked = None          # what the in-run check of the timed work was
+    comm = None
     if mode == "match":
         tmpl_vals = base if rank == 0 else identify.synthetic_template(base, rank)
         tmpl = circuits.EncryptedVector(pp, tmpl_vals, bitsize, ks).to_device()
@@ -292,8 +429,10 @@ def main():
             api.flush_async()
             if use_dist:
                 # the only exchange: every rank's match-bit ciphertext to rank 0 (libpeba1-dist: RCCL gather enqueued on
-                # the library's own stream between the stream-ordered export and import -- no host wait, and no
-                # buffer of one step is touched by the next before the stream has passed it)
+                # the library's own stream between the stream-ordered export and import; the host waits only for the
+                # ranks' one-word status exchange, which runs on a stream of its own and does not wait for the gates in
+                # flight -- the next step's recording overlaps them; no buffer of one step is touched by the next before
+                # the stream has passed it)
                 pd.gather_samples(comm, all_bits.ptr if rank == 0 else None, rb.ptr, 1, pp.ptr)
             return rb
 
@@ -305,6 +444,13 @@ def main():
             return "decrypted match bit of the last timed match == plaintext rule (distance > bound)"
         workload = (f"Function_f: {nslots} slots x {bitsize} bit template match per GPU, every recorded gate executed")
         parallelism, scaling = f"1 match per GPU x {world}", "weak"
+        if args.mode == "auto":
+            # the driver's default curve (`bench.py --gpus N`, mode auto) is the slot-sharded match: ONE match, its slots
+            # over N ranks -- strong scaling.  This is its N = 1 point: one rank holds every slot, no exchange, and the
+            # reference's unsplit Function_f is what runs.  (The N = 1 point of the OTHER curve -- independent matches per
+            # GPU -- is `weak_scaling` in the same line.)
+            scaling = "strong"
+            parallelism = f"{nslots} slots / 1 GPU (the 1-rank point of the slot-sharded curve: no exchange)"
     elif mode == "sharded":
         tmpl_vals = base
         nranks = world if use_dist else max(1, logical)
@@ -406,6 +552,37 @@ def main():
         weak = weak_scaling_leg(api, circuits, identify, dist, torch, pp, ks, probe, bound, base, bitsize, rank, world,
                                 args.weak_matches, args.group, xdev, plain_bit, comm)
 
+    # N > 1, default combine (carry-save / prefix): beside it, ONE more match with rank 0 combining as SURVEY 8(e) writes it
+    # (the pairwise tree of the reference's ripple adders ADDN(23) + its bit-serial comparator minimum(24), the DAG the
+    # golden digests pin) -- timed on its own, so that the line says what the reference's own combine costs at this N
+    ref_combine = None
+    if use_dist and mode == "sharded" and not args.ripple_combine and args.reference_combine_leg:
+        sync()
+        api.reset_stats()
+        tr = time.perf_counter()
+        res_ref = pd.sharded_match(dist, torch, L, circuits.load(), pp.ptr, ks.cloud, pp.words, S[lo:hi], T[lo:hi], bound.ptr,
+                                   bitsize, device=xdev, fast_combine=False, comm=comm, fast_partial=args.fast_partial)
+        api.flush()
+        api.wait()
+        sync()
+        tr = time.perf_counter() - tr
+        tt = torch.tensor([tr], dtype=torch.float64, device=xdev)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        rr = torch.tensor([float(api.stats()["blind_rotates"])], dtype=torch.float64, device=xdev)
+        dist.all_reduce(rr, op=dist.ReduceOp.SUM)
+        if rank == 0:
+            bit = L.bootsSymDecrypt(ctypes.cast(res_ref, lib.LS), ks.ptr)
+            assert bit == plain_bit(tmpl_vals), f"sharded match (reference-order combine) bit {bit}"
+            L.delete_gate_bootstrapping_ciphertext_array(24, ctypes.cast(res_ref, lib.LS))
+            ref_combine = {"match_ms": float(tt.item()) * 1e3, "gates_per_s_all_ranks": float(rr.item()) / float(tt.item()),
+                           "blind_rotates_all_ranks": int(rr.item()),
+                           "combine": "pairwise tree of the reference's ripple adders (bootsADDNbit, Math.cpp:54-69) + its "
+                                      "bit-serial comparator (minimum, Math.cpp:265-292) on rank 0: SURVEY 8(e)'s form, pinned by "
+                                      "tests/golden/sharded_match*_digest.json",
+                           "checked": "decrypted match bit == plaintext rule"}
+
+    evidence = dist_evidence(dist, L, comm, args, world, rank, local_rank) if use_dist else None
+
     if rank == 0:
         a_br, a_ks, ct = algorithmic_bytes(pp)
         steps = max(1, args.steps)
@@ -442,8 +619,10 @@ def main():
             # The mandated HBM roofline: ALGORITHMIC bytes (the whole 59 MiB key image per blind
             # rotation, no reuse) per second of blind-rotate launch time, against the 8 TB/s peak.  The kernel
             # is NOT HBM-bound -- the key image is served from L2 / Infinity Cache (`traffic` = measured
-            # HBM-side bytes per launch, ~3 % of the algorithmic bytes) -- it is bound by VALU issue
-            # (`valu`: share of SIMD cycles issuing VALU instructions, from the SQ counters).
+            # HBM-side bytes per launch, ~3 % of the algorithmic bytes) -- it is bound by VALU issue:
+            # `valu_issue` prices the static instruction mix of a step (profiles/isa_mix.json, from the
+            # assembly of the kernels as built) with the measured issue costs (profiles/valu_issue_costs.json)
+            # and sets it against the cycles a step takes (`valu`: the SQ counters' view of the same).
             "roofline": {"bound": "valu", "kernel": "blind_rotate8_kernel" if dom8 else "blind_rotate4_kernel", "achieved": br_gbps, "peak": HBM_PEAK_GBPS,
                          "unit": "GB/s", "frac": br_gbps / HBM_PEAK_GBPS, "traffic": traffic,
                          "achieved_is": "algorithmic bytes / launch time (cache reuse across gates counts as bandwidth)",
@@ -463,6 +642,7 @@ def main():
                          "ms_blind_rotate_per_step": st["ms_blind_rotate"] / steps,
                          "ms_keyswitch_per_step": st["ms_keyswitch"] / steps},
         }
+        out["roofline"]["valu_issue"] = valu_issue_block(None, None)      # the model alone; the single-GPU extras add the measured side
         if mode == "sharded" and world == 1 and phase_ms["combine"]:
             # what the same phases would take with one GPU per rank: the slowest rank's partial sum, then
             # rank 0's combine (the gather of 24 x 2.5 KB per rank is microseconds) -- a projection from
@@ -476,10 +656,15 @@ def main():
                 "note": "projection from logical ranks timed on one device; not measured on several GPUs"}
         if weak is not None:
             out["weak_scaling"] = weak
+        if ref_combine is not None:
+            out["reference_order_combine"] = ref_combine
+        if evidence is not None:
+            out["dist"] = evidence
         if world == 1 and mode == "match" and args.extras > 0:
             out.update(extras(api, circuits, identify, lib, pd, pp, ks, probe, tmpl, bound, base, probe_vals, bitsize,
                               plain_bit, last))
             # the N = 1 point of the weak-scaling curve the N > 1 lines carry: independent matches on the one GPU
+            out["roofline"]["valu_issue"] = valu_issue_block(out.get("independent_gates_4096"), out.get("independent_gates_sweep"))
             i4 = out["identify_4_matches_one_flush"]
             out["weak_scaling"] = {"gates_per_s_all_ranks": i4["gates_per_s"], "per_gpu": i4["gates_per_s"], "matches_per_gpu": 4,
                                    "group": 4, "seconds": i4["seconds"], "n_gpus": 1,
@@ -754,6 +939,7 @@ def independent_gates_sweep(api, lib, sizes=(1, 16, 256, 1024, 4096)):
             res[str(g)] = {"ms_blind_rotate": s["ms_blind_rotate"], "ms_keyswitch": s["ms_keyswitch"], "ms_wall": t * 1e3,
                            "rotations_per_s_blind_rotate_only": rps, "gates_per_s_wall": g / t,
                            "roofline_frac_algorithmic": rps * a_br / (HBM_PEAK_GBPS * 1e9),
+                           "shader_clock_ghz": 0.1 * s["clk_shader_cycles"] / s["clk_ref_ticks"] if s["clk_ref_ticks"] else None,
                            "kernel": "blind_rotate8_kernel" if s["br8_launches"] else "blind_rotate4_kernel"}
             del a, b, r
         del A, B

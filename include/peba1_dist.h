@@ -55,6 +55,14 @@ int peba1_dist_world(const Peba1Comm *comm);
 /* message of the last failed call of this library on this thread's communicator ("" if none) */
 const char *peba1_dist_last_error(void);
 
+/* ---- evidence of what ran (bench.py `dist`) ----
+ * version of the RCCL library this process opened (ncclGetVersion: 2xxyy), 0 if RCCL cannot be opened */
+int peba1_dist_rccl_version(void);
+/* 1 = RCCL transport, 0 = host-memory transport */
+int peba1_dist_transport(const Peba1Comm *comm);
+/* out4 = {status-word exchanges, gathers, broadcasts, payload bytes this rank sent} since the communicator was made */
+void peba1_dist_counters(const Peba1Comm *comm, uint64_t out4[4]);
+
 /* flags */
 #define PEBA1_DIST_FAST_COMBINE 1   /* rank 0: carry-save compressor + prefix adder + prefix comparator
                                        (peba1_combine_and_compare_fast, ~20 levels) instead of the pairwise tree of the
@@ -116,10 +124,12 @@ int peba1_identify(Peba1Comm *comm, LweSample *all, LweSample *mine, LweSample *
                    const TFheGateBootstrappingCloudKeySet *ck, int group, int flags);
 
 /* ---- failure containment (every collective of this library) ----
- * A rank that fails locally (an allocation, the export that runs its pending gates) still ENTERS the exchange, carrying a
- * status word, so that no rank is left inside a collective:
- *   RCCL: the status words are all-gathered first (one int per rank, on the provider's stream); if any rank reports a
- *     failure EVERY rank skips the data gather and returns -1, its message naming the failed rank;
+ * A rank that fails locally (an allocation, the export that enqueues its pending gates) still ENTERS the exchange, carrying
+ * a status word, so that no rank is left inside a collective:
+ *   RCCL: the status words are all-gathered first (one int per rank, on a stream of the communicator's own: the host
+ *     waits for the peers' words, NOT for the gates in flight on the provider's stream -- the recording of the next
+ *     circuit overlaps them as in a single-process run); if any rank reports a failure EVERY rank skips the data gather
+ *     and returns -1, its message naming the failed rank;
  *   host transport: the status word rides in front of each rank's payload; rank 0 returns -1 naming the failed rank, the
  *     failed rank returns -1 with its own message (a gather cannot tell the other ranks).
  * Every host wait of a communicator of more than one rank is bounded: PEBA1_DIST_TIMEOUT_S (default 600; 0 = unbounded)

@@ -35,6 +35,11 @@ void tfhe_hip_clear_error(void);
 /* ---- device selection (call before the first keyset is created) ---- */
 int tfhe_hip_set_device(int device);
 int tfhe_hip_get_device(void);
+/* PCI bus id ("0000:c1:00.0", NUL-terminated; len >= 16) of the device the library runs on: what a multi-GPU job prints
+ * per rank to show that N ranks drive N distinct GPUs (bench.py `dist.devices`).  Initialises the engine.  Returns 0 / -1.
+ * The library binds the calling thread to its device only for the duration of the calls that reach the HIP runtime and
+ * gives the caller's current device back on return. */
+int tfhe_hip_device_pci_bus_id(char *out, int len);
 
 /* ---- parameters ---- */
 TFheGateBootstrappingParameterSet *tfhe_hip_new_parameters(
@@ -131,6 +136,10 @@ int tfhe_hip_wait(void);
 /* waits (bounded as above) until everything enqueued on tfhe_hip_stream() so far -- by this library or by the caller
  * (a collective) -- has completed; also completes a flush in flight.  Returns 0. */
 int tfhe_hip_stream_sync(void);
+/* waits (bounded as above) for a HIP event of the caller's own (a hipEvent_t recorded on any stream of the library's
+ * device) -- libpeba1-dist reads the status words of a collective back this way, from a stream of its own, without waiting
+ * for the gates in flight on tfhe_hip_stream().  `what` names the wait in the deadline message.  Returns 0. */
+int tfhe_hip_wait_event(void *hip_event, const char *what);
 /* who is waiting, for that message ("rank 3 of 8: gather of the partial sums"); copied, at most 127 characters */
 void tfhe_hip_set_diag_label(const char *label);
 
@@ -181,20 +190,8 @@ int tfhe_hip_gate_batch(int gate, LweSample *result, const LweSample *a, const L
  * "balance_levels": 1 (default) = slack-aware level filling at flush, 0 = plain ASAP
  * levels.
  * "sync_deadline_ms": see "bounded host waits" above.
- * Only in a library built with -DTFHE_HIP_EXPERIMENTAL (tfhe_hip_has_experimental() == 1; build.sh leaves it
- * off: both executors measured slower than per-level launches):
- * "dataflow": 0 (default) = one blind-rotate + one key-switch launch per level; 1 (env
- * TFHE_HIP_DATAFLOW) = experimental: a flush runs as ONE launch in which workgroups take
- * gates in priority order, wait on done flags of their producers and do the key switch
- * inside the workgroup (measured slower than the default on MI355X).
- * "lanes": 1 (default) = one level sequence on one stream; 2 (env TFHE_HIP_LANES) =
- * experimental: gates with at most "tight_slack" levels of slack (default 64, env
- * TFHE_HIP_TIGHT_SLACK) and the rest run as two level sequences on two HIP streams, ordered
- * by events only where the DAG requires it (measured slower on the match).
  * Returns 0, or -1 for an unknown name. */
 int tfhe_hip_set_tuning(const char *name, int64_t value);
-/* 1 when the library carries the experimental executors ("dataflow", "lanes") */
-int tfhe_hip_has_experimental(void);
 
 /* ---- statistics ---- */
 typedef struct TfheHipStats {
@@ -239,10 +236,6 @@ int tfhe_hip_test_form_admissible(int form, int32_t N, int32_t l, int32_t Bgbit,
  * records (kind: gate code 0..9, 16 = MUX, 17 = NOT; absent operands -1) without
  * touching the device; writes the level of each op, returns the depth ---- */
 int tfhe_hip_test_schedule(const int32_t *ops5, int32_t count, int32_t unit, int32_t balance, int32_t *levels_out);
-#ifdef TFHE_HIP_EXPERIMENTAL
-/* same input; writes the execution lane (0 urgent, 1 background) of each op for two-lane execution */
-int tfhe_hip_test_assign_lanes(const int32_t *ops5, int32_t count, int32_t unit, int32_t tight_slack, int32_t *lanes_out);
-#endif
 /* Diagnostic (tools/lane_probe.py): `levels` rounds of (blind rotate + key switch) over `width`
  * random gates, issued as `lanes` independent chains on `lanes` HIP streams; returns the wall
  * time in ms (negative on error).  Measures what overlapping level-synchronous chains could gain. */

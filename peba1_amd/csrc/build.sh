@@ -6,20 +6,27 @@ OUT=../libtfhe-hip.so
 ROCM=${ROCM_PATH:-/opt/rocm}
 HIPCC=${HIPCC:-$ROCM/bin/hipcc}
 CXX=${HOSTCXX:-$ROCM/lib/llvm/bin/clang++}
-# TFHE_HIP_DEFS="-DTFHE_HIP_EXPERIMENTAL" adds the executors that measured slower than per-level launches
-# (the persistent dataflow launch, two-lane execution) and their tests; off by default
+# TFHE_HIP_DEFS: extra -D switches for diagnostic builds (tools/diag/build_variants.sh, build_stamps.sh)
 FLAGS="-O3 -std=c++17 -fPIC -ffp-contract=off -Wall -Wno-unused-result ${TFHE_HIP_DEFS-}"
 HOSTFLAGS="$FLAGS -D__HIP_PLATFORM_AMD__ -I$ROCM/include"
 # max-ilp scheduling: the blind-rotate kernel is bound by multiplier-class issue and dependency stalls;
 # measured 1 % faster than the default strategy, max-memory-clause and no clustering 3-4 % slower
 # (tools/diag/sched_flags.sh)
-$HIPCC $FLAGS ${HIP_EXTRA_FLAGS--mllvm -amdgpu-sched-strategy=max-ilp} --offload-arch=gfx950 -c kernels.hip -o kernels.o &
+KFLAGS="$FLAGS ${HIP_EXTRA_FLAGS--mllvm -amdgpu-sched-strategy=max-ilp} --offload-arch=gfx950"
+$HIPCC $KFLAGS -c kernels.hip -o kernels.o &
+# EMIT_KERNEL_ASM=<file>: also the assembly listing of exactly this compile (tools/isa_mix.py counts the instructions of a
+# blind-rotate step from it; __graft_entry__.build() asks for it when profiles/isa_mix.json is stale)
+if [ -n "${EMIT_KERNEL_ASM-}" ]; then
+    $HIPCC $KFLAGS --cuda-device-only -S kernels.hip -o "$EMIT_KERNEL_ASM" 2>/dev/null &
+    EXTRA_WAIT=1
+fi
 $CXX $HOSTFLAGS -c host_keys.cpp -o host_keys.o &
 $CXX $HOSTFLAGS -c engine.cpp -o engine.o &
 $CXX $HOSTFLAGS -c shim.cpp -o shim.o &
 $CXX $HOSTFLAGS -c scheduler.cpp -o scheduler.o &
 $CXX $HOSTFLAGS -c io.cpp -o io.o &
 wait -n; wait -n; wait -n; wait -n; wait -n; wait -n
+if [ -n "${EXTRA_WAIT-}" ]; then wait -n; fi
 # -Bsymbolic-functions: calls between the library's own exported functions bind inside the library, so
 # another provider of the tfhe API loaded RTLD_GLOBAL in the same process (a CPU tfhe, the tests'
 # plaintext mock) cannot interpose on them

@@ -22,6 +22,7 @@ __attribute__((weak)) int tfhe_hip_import_samples_device_async(LweSample *, int3
 __attribute__((weak)) void *tfhe_hip_stream(void);
 __attribute__((weak)) const char *tfhe_hip_last_error(void);
 __attribute__((weak)) int tfhe_hip_stream_sync(void);
+__attribute__((weak)) int tfhe_hip_wait_event(void *, const char *);
 __attribute__((weak)) int tfhe_hip_get_device(void);
 __attribute__((weak)) int tfhe_hip_set_tuning(const char *, int64_t);
 __attribute__((weak)) void tfhe_hip_set_diag_label(const char *);
@@ -48,6 +49,7 @@ struct Rccl {
     ncclResult_t (*AllGather)(const void *, void *, size_t, ncclDataType_t, ncclComm_t, hipStream_t) = nullptr;
     ncclResult_t (*Bcast)(void *, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
     const char *(*GetErrorString)(ncclResult_t) = nullptr;
+    ncclResult_t (*GetVersion)(int *) = nullptr;
     bool load() {
         if (handle) return true;
         for (const char *name : {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"}) {
@@ -62,6 +64,7 @@ struct Rccl {
         AllGather = reinterpret_cast<decltype(AllGather)>(dlsym(handle, "ncclAllGather"));
         Bcast = reinterpret_cast<decltype(Bcast)>(dlsym(handle, "ncclBcast"));
         GetErrorString = reinterpret_cast<decltype(GetErrorString)>(dlsym(handle, "ncclGetErrorString"));
+        GetVersion = reinterpret_cast<decltype(GetVersion)>(dlsym(handle, "ncclGetVersion"));     // evidence only: may be absent
         return GetUniqueId && CommInitRank && CommDestroy && Gather && AllGather && Bcast && GetErrorString;
     }
 };
@@ -79,19 +82,36 @@ struct Peba1Comm {
     // grow-only device buffers of the RCCL path: they must outlive the stream operations that use them
     int32_t *send = nullptr, *recv = nullptr;
     size_t send_words = 0, recv_words = 0;
-    // status exchange of the RCCL path: [0] this rank's word, [1 .. world] every rank's (device, and a pinned host mirror)
+    // status exchange of the RCCL path: [0] this rank's word, [1 .. world] every rank's (device, and a pinned host mirror);
+    // it runs on a stream of its own so that reading the words back does not wait for the gates in flight on the
+    // provider's stream (exchange_status_rccl)
     int32_t *st_dev = nullptr, *st_host = nullptr;
+    hipStream_t st_stream = nullptr;
+    hipEvent_t st_event = nullptr;
     int inject_failures = 0;             // test hook (peba1_dist_inject_failure): local failures still to report
+    // what this communicator has done (peba1_dist_counters): status exchanges, gathers, broadcasts, payload bytes sent
+    uint64_t n_status = 0, n_gather = 0, n_bcast = 0, bytes_sent = 0;
 };
 
 namespace {
 
-// this library calls the HIP runtime itself (exchange buffers, the status words): on the provider's device, whatever the
-// calling thread had current
-void bind_device() {
-    if (tfhe_hip_stream) (void)tfhe_hip_stream();                     // initialises the provider if nothing has yet
-    if (tfhe_hip_get_device) (void)hipSetDevice(tfhe_hip_get_device());
-}
+// this library calls the HIP runtime itself (exchange buffers, the status words, RCCL): on the provider's device, whatever
+// the calling thread had current -- and the caller gets its own device back on return
+class DeviceScope {
+public:
+    DeviceScope() {
+        if (tfhe_hip_stream) (void)tfhe_hip_stream();                 // initialises the provider if nothing has yet
+        if (!tfhe_hip_get_device) return;
+        const int want = tfhe_hip_get_device();
+        int cur = -1;
+        if (hipGetDevice(&cur) == hipSuccess && cur != want && hipSetDevice(want) == hipSuccess) prev_ = cur;
+    }
+    ~DeviceScope() { if (prev_ >= 0) (void)hipSetDevice(prev_); }
+    DeviceScope(const DeviceScope &) = delete;
+    DeviceScope &operator=(const DeviceScope &) = delete;
+private:
+    int prev_ = -1;
+};
 
 // every host wait of this library goes through the provider's bounded wait (tfhe_hip.h "bounded host waits")
 void stream_sync() {
@@ -130,25 +150,36 @@ void arm_deadline(Peba1Comm *c) {
 //     returns -1 naming the rank, the failed rank returns -1 with its own message.
 // Returns the first failed rank, -1 if none, -2 if the exchange itself failed (g_error set).
 int exchange_status_rccl(Peba1Comm *c, int local) {
-    hipStream_t stream = static_cast<hipStream_t>(tfhe_hip_stream());
     if (!c->st_dev) {
         if (hipMalloc(reinterpret_cast<void **>(&c->st_dev), (size_t)(c->world + 1) * sizeof(int32_t)) != hipSuccess ||
-            hipHostMalloc(reinterpret_cast<void **>(&c->st_host), (size_t)(c->world + 1) * sizeof(int32_t), hipHostMallocDefault) != hipSuccess) {
+            hipHostMalloc(reinterpret_cast<void **>(&c->st_host), (size_t)(c->world + 1) * sizeof(int32_t), hipHostMallocDefault) != hipSuccess ||
+            hipStreamCreateWithFlags(&c->st_stream, hipStreamNonBlocking) != hipSuccess ||
+            hipEventCreateWithFlags(&c->st_event, hipEventDisableTiming) != hipSuccess) {
             // cannot even report: the peers run into their deadline with a message of their own
             fail("allocation of the status words failed");
             return -2;
         }
     }
+    // On a stream of its own: the words say what the HOST of every rank knows after it has enqueued its
+    // export -- they do not depend on the gates in flight, so reading them back must not wait for those.  The
+    // collectives of one communicator execute in issue order whatever their streams (RCCL chains them), so this
+    // all-gather waits at most for the previous call's data collective, never for the flush enqueued since; the data
+    // collective issued next on the provider's stream is ordered behind it the same way.
+    hipStream_t stream = c->st_stream;
     c->st_host[0] = local;
     for (int r = 0; r < c->world; ++r) c->st_host[1 + r] = 0;
     if (hipMemcpyAsync(c->st_dev, c->st_host, sizeof(int32_t), hipMemcpyHostToDevice, stream) != hipSuccess) { fail("upload of the status word failed"); return -2; }
     const ncclResult_t r = g_rccl.AllGather(c->st_dev, c->st_dev + 1, 1, ncclInt32, c->nccl, stream);
     if (r != ncclSuccess) { fail(std::string("ncclAllGather of the status words: ") + g_rccl.GetErrorString(r)); return -2; }
-    if (hipMemcpyAsync(c->st_host + 1, c->st_dev + 1, (size_t)c->world * sizeof(int32_t), hipMemcpyDeviceToHost, stream) != hipSuccess) {
+    if (hipMemcpyAsync(c->st_host + 1, c->st_dev + 1, (size_t)c->world * sizeof(int32_t), hipMemcpyDeviceToHost, stream) != hipSuccess ||
+        hipEventRecord(c->st_event, stream) != hipSuccess) {
         fail("download of the status words failed");
         return -2;
     }
-    stream_sync();                                      // bounded: a peer that never arrives ends the process with a message
+    ++c->n_status;
+    // bounded: a peer that never arrives ends the process with a message (the provider's deadline, its exit code)
+    if (tfhe_hip_wait_event) (void)tfhe_hip_wait_event(c->st_event, "status words of a collective");
+    else (void)hipEventSynchronize(c->st_event);
     for (int k = 0; k < c->world; ++k)
         if (c->st_host[1 + k] != 0) return k;
     return -1;
@@ -165,7 +196,7 @@ int gather_samples(Peba1Comm *c, LweSample *all, const LweSample *mine, int coun
     if (c->rccl) {
         if (!tfhe_hip_export_samples_device_async || !tfhe_hip_import_samples_device_async || !tfhe_hip_stream)
             return fail("the RCCL transport needs libtfhe-hip as the gate provider");
-        bind_device();
+        DeviceScope on_provider_device;
         if (local == 0 && !device_buffer(c->send, c->send_words, words)) note("hipMalloc of the send buffer failed");
         if (local == 0 && c->rank == 0 && !device_buffer(c->recv, c->recv_words, words * (size_t)c->world)) note("hipMalloc of the receive buffer failed");
         hipStream_t stream = static_cast<hipStream_t>(tfhe_hip_stream());
@@ -178,6 +209,7 @@ int gather_samples(Peba1Comm *c, LweSample *all, const LweSample *mine, int coun
                                        : "rank " + std::to_string(bad) + " reported a failure before the gather; no rank entered it");
         const ncclResult_t r = g_rccl.Gather(c->send, c->rank == 0 ? c->recv : nullptr, words, ncclInt32, 0, c->nccl, stream);
         if (r != ncclSuccess) return fail(std::string("ncclGather: ") + g_rccl.GetErrorString(r));
+        ++c->n_gather; c->bytes_sent += words * sizeof(int32_t);
         if (c->rank == 0 && tfhe_hip_import_samples_device_async(all, count * c->world, params, c->recv) != 0)
             return fail("import of the gathered samples: " + provider_error());
         return 0;
@@ -188,6 +220,7 @@ int gather_samples(Peba1Comm *c, LweSample *all, const LweSample *mine, int coun
     send[0] = local;
     if (c->gather(c->ctx, send.data(), c->rank == 0 ? recv.data() : nullptr, (1 + words) * sizeof(int32_t), 0) != 0)
         return fail("the host gather callback failed");
+    ++c->n_gather; ++c->n_status; c->bytes_sent += (1 + words) * sizeof(int32_t);      // the status word rides in front
     if (local != 0) return fail("rank " + std::to_string(c->rank) + " (this rank) failed before the gather: " + why);
     if (c->rank != 0) return 0;
     for (int k = 0; k < c->world; ++k)
@@ -213,7 +246,7 @@ int broadcast_samples(Peba1Comm *c, LweSample *samples, int count, const TFheGat
     if (c->rccl) {
         if (!tfhe_hip_export_samples_device_async || !tfhe_hip_import_samples_device_async || !tfhe_hip_stream)
             return fail("the RCCL transport needs libtfhe-hip as the gate provider");
-        bind_device();
+        DeviceScope on_provider_device;
         if (local == 0 && !device_buffer(c->send, c->send_words, words)) note("hipMalloc of the broadcast buffer failed");
         hipStream_t stream = static_cast<hipStream_t>(tfhe_hip_stream());
         if (local == 0 && c->rank == root && tfhe_hip_export_samples_device_async(samples, count, params, c->send) != 0)
@@ -225,6 +258,7 @@ int broadcast_samples(Peba1Comm *c, LweSample *samples, int count, const TFheGat
                                        : "rank " + std::to_string(bad) + " reported a failure before the broadcast; no rank entered it");
         const ncclResult_t r = g_rccl.Bcast(c->send, words, ncclInt32, root, c->nccl, stream);
         if (r != ncclSuccess) return fail(std::string("ncclBcast: ") + g_rccl.GetErrorString(r));
+        ++c->n_bcast; if (c->rank == root) c->bytes_sent += words * sizeof(int32_t);
         if (c->rank != root && tfhe_hip_import_samples_device_async(samples, count, params, c->send) != 0)
             return fail("import of the broadcast samples: " + provider_error());
         return 0;
@@ -236,6 +270,7 @@ int broadcast_samples(Peba1Comm *c, LweSample *samples, int count, const TFheGat
         buf[0] = local;
     }
     if (c->bcast(c->ctx, buf.data(), (1 + words) * sizeof(int32_t), root) != 0) return fail("the host broadcast callback failed");
+    ++c->n_bcast; ++c->n_status; if (c->rank == root) c->bytes_sent += (1 + words) * sizeof(int32_t);
     if (local != 0) return fail("rank " + std::to_string(c->rank) + " (this rank) failed before the broadcast: " + why);
     if (buf[0] != 0) return fail("rank " + std::to_string(root) + " (the root) reported a failure before the broadcast; its payload is void");
     if (c->rank != root && tfhe_hip_import_samples(samples, count, params, buf.data() + 1) != 0)
@@ -280,7 +315,7 @@ Peba1Comm *peba1_dist_init_rccl(const void *id128, int world, int rank) {
     if (!id128 || world < 1 || rank < 0 || rank >= world) { fail("peba1_dist_init_rccl: bad arguments"); return nullptr; }
     if (!g_rccl.load()) { fail(std::string("cannot open RCCL: ") + (dlerror() ? dlerror() : "symbols missing")); return nullptr; }
     if (!tfhe_hip_stream) { fail("the RCCL transport needs libtfhe-hip as the gate provider"); return nullptr; }
-    bind_device();                            // initialises the engine: the device it selected is current for RCCL
+    DeviceScope on_provider_device;           // initialises the engine: the device it selected is current for RCCL
     ncclUniqueId id;
     std::memcpy(&id, id128, sizeof id);
     auto *c = new Peba1Comm();
@@ -312,11 +347,14 @@ Peba1Comm *peba1_dist_init_host(peba1_gather_fn gather, void *ctx, int world, in
 void peba1_dist_destroy(Peba1Comm *c) {
     if (!c) return;
     if (c->rccl) {
+        DeviceScope on_provider_device;
         stream_sync();
         if (c->send) (void)hipFree(c->send);
         if (c->recv) (void)hipFree(c->recv);
         if (c->st_dev) (void)hipFree(c->st_dev);
         if (c->st_host) (void)hipHostFree(c->st_host);
+        if (c->st_event) (void)hipEventDestroy(c->st_event);
+        if (c->st_stream) { (void)hipStreamSynchronize(c->st_stream); (void)hipStreamDestroy(c->st_stream); }
         if (c->own && c->nccl) (void)g_rccl.CommDestroy(c->nccl);
     }
     delete c;
@@ -398,6 +436,19 @@ int peba1_sharded_function_f(Peba1Comm *c, LweSample *result_b, LweSample *const
     if (parts) delete_gate_bootstrapping_ciphertext_array(PARTIAL_BITS * c->world, parts);
     return rc;
 }
+
+int peba1_dist_rccl_version(void) {
+    int v = 0;
+    if (!g_rccl.load() || !g_rccl.GetVersion || g_rccl.GetVersion(&v) != ncclSuccess) return 0;
+    return v;
+}
+
+void peba1_dist_counters(const Peba1Comm *c, uint64_t out4[4]) {
+    if (!c || !out4) return;
+    out4[0] = c->n_status; out4[1] = c->n_gather; out4[2] = c->n_bcast; out4[3] = c->bytes_sent;
+}
+
+int peba1_dist_transport(const Peba1Comm *c) { return c && c->rccl ? 1 : 0; }
 
 void peba1_dist_inject_failure(Peba1Comm *c, int count) { if (c) c->inject_failures = count > 0 ? count : 0; }
 

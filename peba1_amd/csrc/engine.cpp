@@ -39,6 +39,28 @@ void hip_check(hipError_t e, const char *what) {
     if (e != hipSuccess) fatal(std::string(what) + ": " + hipGetErrorString(e));
 }
 
+// HIP's current device is per host thread and starts at 0: a worker thread of a multi-GPU server (rank r drives GPU r)
+// that calls in without ever having selected a device -- or after selecting another one for its own work -- would launch
+// on the engine's stream with the wrong device current.  Every method below that calls the HIP runtime therefore binds
+// the calling thread to the engine's device for its duration and gives the caller's device back on return (ADVICE r4:
+// a once-per-thread bind both changed the caller's device for good and missed a later hipSetDevice by the caller).
+// The boots* recording calls never reach the runtime and pay nothing for this.
+namespace {
+class DeviceScope {
+public:
+    explicit DeviceScope(int want) {
+        int cur = -1;
+        if (hipGetDevice(&cur) == hipSuccess && cur != want && hipSetDevice(want) == hipSuccess) prev_ = cur;
+    }
+    ~DeviceScope() { if (prev_ >= 0) (void)hipSetDevice(prev_); }
+    DeviceScope(const DeviceScope &) = delete;
+    DeviceScope &operator=(const DeviceScope &) = delete;
+private:
+    int prev_ = -1;
+};
+}  // namespace
+#define ENGINE_DEVICE_SCOPE() DeviceScope device_scope_(Engine::get().device())
+
 // ---- slot pool ---------------------------------------------------------------
 // The pool is one contiguous device array (kernels index it by slot id) that starts small and doubles on demand up to
 // `capacity` slots: a process that evaluates a few gates holds 0.2 GB, one that records whole matches grows to what its
@@ -48,9 +70,11 @@ SlotPool::SlotPool(int ct_words, int ct_stride, size_t capacity) : words_(ct_wor
     grow(std::min<size_t>(max_cap_, (size_t)1 << 16));
 }
 SlotPool::~SlotPool() {
+    ENGINE_DEVICE_SCOPE();
     if (data_) (void)hipFree(data_);
 }
 void SlotPool::grow(size_t new_cap) {
+    ENGINE_DEVICE_SCOPE();
     int32_t *fresh = nullptr;
     hip_check(hipMalloc(reinterpret_cast<void **>(&fresh), new_cap * (size_t)stride_ * sizeof(int32_t)), "hipMalloc(slot pool)");
     if (data_) {
@@ -91,26 +115,19 @@ void SlotPool::release(int32_t s) {
 // ---- engine ------------------------------------------------------------------
 Engine &Engine::get() {
     static Engine e;
-    // HIP's current device is per host thread and starts at 0: a worker thread of a multi-GPU server (rank r drives GPU r)
-    // that calls in without ever having selected a device would launch on the engine's stream with another device current.
-    // Every entry of the library passes through here; bind the thread to the engine's device the first time it does
-    if (e.inited_) {
-        thread_local int bound = -1;
-        if (bound != e.device_) {
-            (void)hipSetDevice(e.device_);
-            bound = e.device_;
-        }
-    }
     return e;
 }
 
 void Engine::set_device(int d) {
-    if (inited_ && d != device_) fatal("tfhe_hip_set_device after the engine was initialised");
+    if (inited_.load() && d != device_) fatal("tfhe_hip_set_device after the engine was initialised");
     device_ = d;
 }
 
 void Engine::ensure_init() {
-    if (inited_) return;
+    if (inited_.load(std::memory_order_acquire)) return;
+    static std::mutex init_mtx;
+    std::lock_guard<std::mutex> g(init_mtx);
+    if (inited_.load(std::memory_order_relaxed)) return;
     int count = 0;
     if (hipGetDeviceCount(&count) != hipSuccess || count == 0)
         fatal("no HIP device available: libtfhe-hip evaluates gates on the GPU only (there is no CPU fallback)");
@@ -124,7 +141,11 @@ void Engine::ensure_init() {
     if (const char *env = std::getenv("TFHE_HIP_KS_PIPE")) ks_pipe = std::atoi(env);
     if (const char *env = std::getenv("TFHE_HIP_KS_BRANCH")) ks_branch = std::atoi(env);
     if (const char *env = std::getenv("TFHE_HIP_KS_SPLIT_TIES")) ks_split_ties = std::atoi(env);
-    hip_check(hipSetDevice(device_), "hipSetDevice");
+    DeviceScope bind(device_);               // (an invalid device shows at the first runtime call below)
+    {
+        int cur = -1;
+        if (hipGetDevice(&cur) != hipSuccess || cur != device_) hip_check(hipSetDevice(device_), "hipSetDevice");
+    }
     {
         hipDeviceProp_t prop;
         hip_check(hipGetDeviceProperties(&prop, device_), "hipGetDeviceProperties");
@@ -135,7 +156,6 @@ void Engine::ensure_init() {
         hip_check(hipDeviceGetStreamPriorityRange(&least, &greatest), "priority range");
         hip_check(hipStreamCreateWithPriority(&stream_, hipStreamNonBlocking, greatest), "hipStreamCreate");
     }
-    if (const char *env = std::getenv("TFHE_HIP_LANE_PRIO")) lane_prio = std::atoi(env);
     if (const char *env = std::getenv("TFHE_HIP_BR_FAIR")) br_fair = std::atoi(env);
     if (const char *env = std::getenv("TFHE_HIP_BR8_MAX")) br8_max_rotations = std::atoi(env);
     if (const char *env = std::getenv("TFHE_HIP_BR_TAIL8")) br_tail8 = std::atoi(env);
@@ -143,7 +163,7 @@ void Engine::ensure_init() {
     if (const char *env = std::getenv("TFHE_HIP_BR_TABLE")) br_digit_table = std::atoi(env);
     if (const char *env = std::getenv("TFHE_HIP_SYNC_DEADLINE_MS")) sync_deadline_ms = std::atoll(env);
     for (auto &e : ev_) hip_check(hipEventCreate(&e), "hipEventCreate");
-    inited_ = true;
+    inited_.store(true, std::memory_order_release);
 }
 
 // ---- host waits ----------------------------------------------------------------
@@ -179,6 +199,7 @@ static void bounded_wait(Query &&query, const char *what, long long deadline_ms,
 }
 
 void Engine::sync_stream(const char *what) {
+    ENGINE_DEVICE_SCOPE();
     if (sync_deadline_ms <= 0) hip_check(hipStreamSynchronize(stream_), what);
     else bounded_wait([&] { return hipStreamQuery(stream_); }, what, sync_deadline_ms, diag_label);
     io_pending_ = false;                     // whatever was enqueued without a host wait has completed too
@@ -192,7 +213,21 @@ void Engine::note_async_io() {
     hip_check(hipEventRecord(io_event_, stream_), "io event record");
     io_pending_ = true;
 }
+// a caller's own event (libpeba1-dist: the status words of a collective, on a stream of their own), bounded like every
+// other host wait of the library.  Takes no engine state: safe beside a flush in flight.
+void Engine::wait_event(hipEvent_t ev, const char *what) {
+    ENGINE_DEVICE_SCOPE();
+    if (sync_deadline_ms <= 0) hip_check(hipEventSynchronize(ev), what);
+    else bounded_wait([&] { return hipEventQuery(ev); }, what, sync_deadline_ms, diag_label);
+}
+
+bool Engine::pci_bus_id(char *out, int len) {
+    ENGINE_DEVICE_SCOPE();
+    return hipDeviceGetPCIBusId(out, len, device_) == hipSuccess;
+}
+
 void Engine::sync_io() {
+    ENGINE_DEVICE_SCOPE();
     if (!io_pending_) return;
     if (sync_deadline_ms <= 0) hip_check(hipEventSynchronize(io_event_), "stream-ordered transfer");
     else bounded_wait([&] { return hipEventQuery(io_event_); }, "stream-ordered transfer", sync_deadline_ms, diag_label);
@@ -319,6 +354,7 @@ const char *unsupported_reason(const Params &p) {
 }
 
 DeviceKeyImage *Engine::upload_key(const TfheHipCloudKey &ck) {
+    ENGINE_DEVICE_SCOPE();
     ensure_init();
     const Params &p = ck.p;
     // a parameter set the kernels cannot run exactly is refused (the call that needed the key has no effect and
@@ -363,6 +399,7 @@ DeviceKeyImage *Engine::upload_key(const TfheHipCloudKey &ck) {
 }
 
 void Engine::free_key(DeviceKeyImage *img) {
+    ENGINE_DEVICE_SCOPE();
     if (!img) return;
     if (inited_) sync_stream("sync before key free");
     if (img->bk_img) (void)hipFree(img->bk_img);
@@ -378,6 +415,7 @@ SlotPool *Engine::find_pool(const Params &p) const {
 }
 
 SlotPool *Engine::pool_for(const Params &p) {
+    ENGINE_DEVICE_SCOPE();
     ensure_init();
     if (SlotPool *pl = find_pool(p)) return pl;
     // what the pool may GROW to (it starts at 65,536 slots and doubles on demand): 4,194,304 slots = 10.6 GB at n = 630 of
@@ -401,6 +439,7 @@ SlotPool *Engine::pool_for(const Params &p) {
 }
 
 void Engine::write_slot(SlotPool *pool, int32_t slot, const Torus32 *a, Torus32 b) {
+    ENGINE_DEVICE_SCOPE();
     // A blocking copy on the null stream is not ordered against the engine's non-blocking stream.  Slots a flush in
     // flight touches stay pinned, so a fresh slot is never one of those; but a slot freed right after a stream-ordered
     // export may still be waiting for its gather kernel: wait for such transfers, not for the whole stream
@@ -414,6 +453,7 @@ void Engine::write_slot(SlotPool *pool, int32_t slot, const Torus32 *a, Torus32 
 }
 
 void Engine::read_slot(SlotPool *pool, int32_t slot, Torus32 *a, Torus32 *b) {
+    ENGINE_DEVICE_SCOPE();
     wait_flight();
     // on the engine's stream, then waited for: ordered behind everything enqueued there -- a flush, and a stream-ordered
     // import that nobody waited for (the scatter behind an ncclGather of tfhe_hip_import_samples_device_async)
@@ -446,6 +486,7 @@ int32_t *Engine::stage_slots(const int32_t *slots, int count) {
 }
 
 void Engine::write_slots_packed(SlotPool *pool, const int32_t *slots, int count, const Torus32 *words, bool on_device, bool wait) {
+    ENGINE_DEVICE_SCOPE();
     if (count <= 0) return;
     const size_t wbytes = (size_t)count * pool->ct_words() * 4;
     int32_t *dslots = static_cast<int32_t *>(scratch(3, (size_t)count * 4));
@@ -462,6 +503,7 @@ void Engine::write_slots_packed(SlotPool *pool, const int32_t *slots, int count,
 }
 
 void Engine::read_slots_packed(SlotPool *pool, const int32_t *slots, int count, Torus32 *words, bool on_device, bool wait) {
+    ENGINE_DEVICE_SCOPE();
     if (count <= 0) return;
     const size_t wbytes = (size_t)count * pool->ct_words() * 4;
     // (a list in flight from an earlier stream-ordered call is read by its kernel before this copy lands: one stream)
@@ -485,6 +527,7 @@ hipEvent_t Engine::next_timing_event() {
 
 bool Engine::launch_br(const DeviceKeyImage *key, const int32_t *pool, const RotDesc *rots, int count, int32_t *u_buf,
                        int32_t *acc_dbg, hipStream_t stream, int wave_prio) {
+    ENGINE_DEVICE_SCOPE();
     if (!stream) stream = stream_;
     tail_event_ = nullptr;                   // what an earlier launch left is not this one's
     tail_count_ = 0;
@@ -568,7 +611,8 @@ bool Engine::launch_br(const DeviceKeyImage *key, const int32_t *pool, const Rot
 }
 
 void Engine::launch_ks(const DeviceKeyImage *key, const int32_t *u_buf, const KsDesc *descs, int count, int32_t *pool,
-                       hipStream_t stream, int lane) {
+                       hipStream_t stream, int scratch_set) {
+    ENGINE_DEVICE_SCOPE();
     if (count <= 0) return;
     if (!stream) stream = stream_;
     const DevParams &dp = key->dp;
@@ -607,7 +651,7 @@ void Engine::launch_ks(const DeviceKeyImage *key, const int32_t *u_buf, const Ks
             while (splits < ks_max_splits && cnt * splits * 2 <= ks_target_blocks) splits *= 2;
         }
         int32_t *partial = nullptr;
-        if (splits > 1 && !ks_atomic) partial = static_cast<int32_t *>(scratch(10 + (size_t)lane, (size_t)cnt * splits * dp.ct_stride * 4));
+        if (splits > 1 && !ks_atomic) partial = static_cast<int32_t *>(scratch(10 + (size_t)scratch_set, (size_t)cnt * splits * dp.ct_stride * 4));
         launch_keyswitch(stream, dp, key->key, u_buf, descs + done, cnt, pool, splits, partial, tiled ? ks_tile : 0,
                          ks_atomic != 0, ks_narrow != 0, ks_pipe != 0, ks_branch);
     }
@@ -618,21 +662,19 @@ void Engine::launch_ks(const DeviceKeyImage *key, const int32_t *u_buf, const Ks
 // host work of the NEXT flush -- recording, dead-gate elimination, levelling, building its plan -- then overlaps this
 // one's execution (shim.cpp flush_locked).
 void Engine::execute(const DeviceKeyImage *key, SlotPool *pool, LevelPlan &&plan_in, bool wait) {
+    ENGINE_DEVICE_SCOPE();
     wait_flight();                                   // at most one flush in flight: its descriptors and scratch are in use
     flight_t0_ = std::chrono::steady_clock::now();
     flight_plan_ = std::move(plan_in);               // owns the host descriptors until the uploads have certainly happened
     const LevelPlan &plan = flight_plan_;
-    const int levels = plan.levels, K = plan.lanes;
+    const int levels = plan.levels;
     RotDesc *drots = static_cast<RotDesc *>(scratch(0, plan.rots.size() * sizeof(RotDesc) + 16));
     KsDesc *dks = static_cast<KsDesc *>(scratch(1, plan.kss.size() * sizeof(KsDesc) + 16));
     NotDesc *dnots = static_cast<NotDesc *>(scratch(2, plan.nots.size() * sizeof(NotDesc) + 16));
-    // per lane: extract buffer and key-switch partial sums, sized for the lane's widest group
-    // before anything runs (scratch() may reallocate, which must not happen under a running lane)
-    int32_t *u_buf[2] = {nullptr, nullptr};
-    for (int s = 0; s < K; ++s) {
-        u_buf[s] = static_cast<int32_t *>(scratch(s == 0 ? 5 : 20 + (size_t)s, (size_t)(plan.max_rots[s] + 1) * key->dp.u_stride * 4));
-        (void)scratch(10 + (size_t)s, (size_t)std::min(plan.max_rots[s] + 1, 8192) * ks_max_splits * key->dp.ct_stride * 4);
-    }
+    // extract buffer and key-switch partial sums, sized for the widest level before anything runs (scratch() may
+    // reallocate, which must not happen under a running launch)
+    int32_t *u_buf = static_cast<int32_t *>(scratch(5, (size_t)(plan.max_rots + 1) * key->dp.u_stride * 4));
+    (void)scratch(10, (size_t)std::min(plan.max_rots + 1, 8192) * ks_max_splits * key->dp.ct_stride * 4);
     if (!plan.rots.empty())
         hip_check(hipMemcpyAsync(drots, plan.rots.data(), plan.rots.size() * sizeof(RotDesc), hipMemcpyHostToDevice, stream_), "upload rots");
     if (!plan.kss.empty())
@@ -640,29 +682,7 @@ void Engine::execute(const DeviceKeyImage *key, SlotPool *pool, LevelPlan &&plan
     if (!plan.nots.empty())
         hip_check(hipMemcpyAsync(dnots, plan.nots.data(), plan.nots.size() * sizeof(NotDesc), hipMemcpyHostToDevice, stream_), "upload nots");
 
-    lane_stream_[0] = stream_;
-    const size_t ngroups = ((size_t)levels + 1) * K;
-#ifndef TFHE_HIP_EXPERIMENTAL
-    if (K != 1) fatal("two-lane execution is an experimental executor: build with -DTFHE_HIP_EXPERIMENTAL");
-#else
-    if (K > 1) {
-        if (!lane_stream_[1]) {
-            // the background lane: lowest queue priority, so freed workgroup slots go to the urgent lane first
-            int least = 0, greatest = 0;
-            hip_check(hipDeviceGetStreamPriorityRange(&least, &greatest), "priority range");
-            hip_check(hipStreamCreateWithPriority(&lane_stream_[1], hipStreamNonBlocking, least), "lane stream");
-        }
-        while (order_events_.size() < ngroups + 1) {
-            hipEvent_t e;
-            hip_check(hipEventCreateWithFlags(&e, hipEventDisableTiming), "order event");
-            order_events_.push_back(e);
-        }
-        // lane 1 starts after the descriptor upload (enqueued on lane 0's stream)
-        hip_check(hipEventRecord(order_events_[ngroups], stream_), "upload event");
-        hip_check(hipStreamWaitEvent(lane_stream_[1], order_events_[ngroups], 0), "wait upload");
-    }
-#endif
-    timing_used_ = 0;                                    // timing events used: base, then 3 (4 with a tail launch) per group
+    timing_used_ = 0;                                    // timing events used: base, then 2-3 (one more with a tail launch) per level
     auto timing_event = [&]() { return next_timing_event(); };
     std::vector<Timed> &timed = flight_timed_;
     timed.clear();
@@ -671,91 +691,64 @@ void Engine::execute(const DeviceKeyImage *key, SlotPool *pool, LevelPlan &&plan
     if (kernel_timing) {
         base = timing_event();
         hip_check(hipEventRecord(base, stream_), "event");
-        timed.reserve(ngroups);
+        timed.reserve((size_t)levels + 1);
     }
-#ifdef TFHE_HIP_EXPERIMENTAL
-    int waited[2][2] = {{0, 0}, {0, 0}};                 // waited[s][o]: lane s already waits for lane o up to this level+1
-#endif
-    int last_group[2] = {-1, -1};
     hipEvent_t shared_end = nullptr;
     for (int L = 0; L <= levels; ++L) {
-        for (int s = 0; s < K; ++s) {
-            const size_t gn = (size_t)L * K + s;                     // NOT / need index
-            const size_t gg = L > 0 ? (size_t)(L - 1) * K + s : 0;   // gate index
-            const int nrot = L > 0 ? plan.rot_off[gg + 1] - plan.rot_off[gg] : 0;
-            const int nks = L > 0 ? plan.ks_off[gg + 1] - plan.ks_off[gg] : 0;
-            const int nnot = plan.not_off[gn + 1] - plan.not_off[gn];
-            if (nrot == 0 && nks == 0 && nnot == 0) continue;
-            hipStream_t st = lane_stream_[s];
-#ifdef TFHE_HIP_EXPERIMENTAL
-            if (K > 1) {
-                const int o = 1 - s;
-                const int w = plan.need[gn * K + o];
-                if (w > waited[s][o]) {
-                    hip_check(hipStreamWaitEvent(st, order_events_[(size_t)(w - 1) * K + o], 0), "lane wait");
-                    waited[s][o] = w;
-                }
-            }
-#endif
-            Timed t{nullptr, nullptr, nullptr, false, nrot};
-            // a level's start event is the previous level's end event where nothing was enqueued in between (one lane, no
-            // NOT launch behind the key switch): two events per level instead of three -- an event costs the stream
-            // a few microseconds, 1,131 of them 4-15 ms of a match
-            if (kernel_timing) {
-                if (shared_end) t.e0 = shared_end;
-                else { t.e0 = timing_event(); hip_check(hipEventRecord(t.e0, st), "event"); }
-                shared_end = nullptr;
-            }
-            if (nrot) {
-                in_execute_ = true;
-                t.wide8 = launch_br(key, pool->data(), drots + plan.rot_off[gg], nrot, u_buf[s], nullptr, st, K > 1 && s == 0 ? lane_prio : 0);
-                in_execute_ = false;
-                if (t.wide8) { ++stats.br8_launches; stats.br8_rotations += (uint64_t)nrot; }
-                if (tail_count_) {                       // a second launch, of the 8-wave kernel
-                    t.em = tail_event_;
-                    t.tail = tail_count_;
-                    ++stats.br8_launches; ++stats.br_launches;
-                    stats.br8_rotations += (uint64_t)tail_count_;
-                }
-            }
-            if (kernel_timing) { t.e1 = timing_event(); hip_check(hipEventRecord(t.e1, st), "event"); }
-            if (nks) launch_ks(key, u_buf[s], dks + plan.ks_off[gg], nks, pool->data(), st, s);
-            if (kernel_timing) {
-                t.e2 = timing_event(); hip_check(hipEventRecord(t.e2, st), "event"); timed.push_back(t);
-                if (K == 1 && nnot == 0) shared_end = t.e2;
-            }
-            launch_not(st, key->dp, dnots + plan.not_off[gn], nnot, pool->data());
-#ifdef TFHE_HIP_EXPERIMENTAL
-            if (K > 1) hip_check(hipEventRecord(order_events_[gn], st), "lane event");
-#endif
-            last_group[s] = (int)gn;
-            stats.blind_rotates += (uint64_t)nrot;
-            stats.keyswitches += (uint64_t)nks;
-            stats.linear_ops += (uint64_t)nnot;
-            if (nrot) ++stats.br_launches;
+        const size_t gg = L > 0 ? (size_t)(L - 1) : 0;       // gate index
+        const int nrot = L > 0 ? plan.rot_off[gg + 1] - plan.rot_off[gg] : 0;
+        const int nks = L > 0 ? plan.ks_off[gg + 1] - plan.ks_off[gg] : 0;
+        const int nnot = plan.not_off[(size_t)L + 1] - plan.not_off[(size_t)L];
+        if (nrot == 0 && nks == 0 && nnot == 0) continue;
+        Timed t{nullptr, nullptr, nullptr, false, nrot};
+        // a level's start event is the previous level's end event where nothing was enqueued in between (no NOT launch
+        // behind the key switch): two events per level instead of three -- an event costs the stream a few
+        // microseconds, 1,131 of them 4-15 ms of a match
+        if (kernel_timing) {
+            if (shared_end) t.e0 = shared_end;
+            else { t.e0 = timing_event(); hip_check(hipEventRecord(t.e0, stream_), "event"); }
+            shared_end = nullptr;
         }
+        if (nrot) {
+            in_execute_ = true;
+            t.wide8 = launch_br(key, pool->data(), drots + plan.rot_off[gg], nrot, u_buf, nullptr, stream_, 0);
+            in_execute_ = false;
+            if (t.wide8) { ++stats.br8_launches; stats.br8_rotations += (uint64_t)nrot; }
+            if (tail_count_) {                       // a second launch, of the 8-wave kernel
+                t.em = tail_event_;
+                t.tail = tail_count_;
+                ++stats.br8_launches; ++stats.br_launches;
+                stats.br8_rotations += (uint64_t)tail_count_;
+            }
+        }
+        if (kernel_timing) { t.e1 = timing_event(); hip_check(hipEventRecord(t.e1, stream_), "event"); }
+        if (nks) launch_ks(key, u_buf, dks + plan.ks_off[gg], nks, pool->data(), stream_, 0);
+        if (kernel_timing) {
+            t.e2 = timing_event(); hip_check(hipEventRecord(t.e2, stream_), "event"); timed.push_back(t);
+            if (nnot == 0) shared_end = t.e2;
+        }
+        launch_not(stream_, key->dp, dnots + plan.not_off[(size_t)L], nnot, pool->data());
+        stats.blind_rotates += (uint64_t)nrot;
+        stats.keyswitches += (uint64_t)nks;
+        stats.linear_ops += (uint64_t)nnot;
+        if (nrot) ++stats.br_launches;
     }
-    if (const char *trace = std::getenv("TFHE_HIP_TRACE_LEVELS")) {   // diagnostic: rotations per (level, lane)
+    if (const char *trace = std::getenv("TFHE_HIP_TRACE_LEVELS")) {   // diagnostic: rotations per level
         if (FILE *f = std::fopen(trace, "a")) {
-            std::fprintf(f, "flush levels=%d lanes=%d\n", levels, K);
+            std::fprintf(f, "flush levels=%d lanes=1\n", levels);
             for (int L = 1; L <= levels; ++L)
-                for (int s = 0; s < K; ++s) {
-                    const size_t gg = (size_t)(L - 1) * K + s;
-                    std::fprintf(f, "%d %d %d\n", L, s, plan.rot_off[gg + 1] - plan.rot_off[gg]);
-                }
+                std::fprintf(f, "%d 0 %d\n", L, plan.rot_off[(size_t)L] - plan.rot_off[(size_t)L - 1]);
             std::fclose(f);
         }
     }
     hip_check(hipGetLastError(), "kernel launch");
-#ifdef TFHE_HIP_EXPERIMENTAL
-    if (K > 1 && last_group[1] >= 0) hip_check(hipStreamWaitEvent(stream_, order_events_[last_group[1]], 0), "join lanes");
-#endif
     flight_levels_ = levels;
     in_flight_ = true;
     if (wait) wait_flight();
 }
 
 void Engine::wait_flight() {
+    ENGINE_DEVICE_SCOPE();
     if (!in_flight_) return;
     in_flight_ = false;
     const int levels = flight_levels_;
@@ -763,7 +756,7 @@ void Engine::wait_flight() {
     hipEvent_t base = flight_base_;
     sync_stream("level execution");
     if (kernel_timing && base) {
-        // durations per launch, and the union of the blind-rotate intervals (two lanes overlap)
+        // durations per launch, and the union of the blind-rotate intervals
         std::vector<std::pair<float, float>> br;
         br.reserve(timed.size());
         // diagnostic: start, blind-rotate and key-switch time of every level (TFHE_HIP_TRACE_TIMES = file)
@@ -813,62 +806,9 @@ void Engine::wait_flight() {
     flight_plan_ = LevelPlan{};
 }
 
-#ifdef TFHE_HIP_EXPERIMENTAL
-void Engine::execute_dataflow(const DeviceKeyImage *key, SlotPool *pool, const std::vector<GateTask> &tasks, int depth) {
-    const auto t0 = std::chrono::steady_clock::now();
-    const int ntasks = (int)tasks.size();
-    if (ntasks == 0) return;
-    GateTask *dtasks = static_cast<GateTask *>(scratch(11, tasks.size() * sizeof(GateTask)));
-    constexpr int CTRL_WORDS = 4 + 64;   // next, error, 2 spare, 64 progress words (debug)
-    int32_t *dflags = static_cast<int32_t *>(scratch(12, ((size_t)ntasks + CTRL_WORDS) * sizeof(int32_t)));   // done[ntasks], ctrl[]
-    hip_check(hipMemcpyAsync(dtasks, tasks.data(), tasks.size() * sizeof(GateTask), hipMemcpyHostToDevice, stream_), "upload tasks");
-    hip_check(hipMemsetAsync(dflags, 0, ((size_t)ntasks + CTRL_WORDS) * sizeof(int32_t), stream_), "clear flags");
-    if (kernel_timing) hip_check(hipEventRecord(ev_[0], stream_), "event");
-    launch_gate_dataflow(stream_, key->dp, key->key, pool->data(), dtasks, ntasks, dflags, dflags + ntasks,
-                         cu_count_ * (key->dp.N == 1024 ? 2 : 1));
-    if (kernel_timing) hip_check(hipEventRecord(ev_[1], stream_), "event");
-    hip_check(hipGetLastError(), "dataflow launch");
-    if (std::getenv("TFHE_HIP_DF_DEBUG")) {
-        // watchdog for development: poll progress words from a second stream, give up after 20 s
-        hipStream_t s2;
-        hip_check(hipStreamCreateWithFlags(&s2, hipStreamNonBlocking), "debug stream");
-        hipEvent_t evd;
-        hip_check(hipEventCreate(&evd), "debug event");
-        hip_check(hipEventRecord(evd, stream_), "debug event record");
-        for (int sec = 0; sec < 20 && hipEventQuery(evd) == hipErrorNotReady; ++sec) {
-            int32_t w[CTRL_WORDS];
-            hip_check(hipMemcpyAsync(w, dflags + ntasks, sizeof w, hipMemcpyDeviceToHost, s2), "debug copy");
-            hip_check(hipStreamSynchronize(s2), "debug sync");
-            std::fprintf(stderr, "[df %2ds] ntasks %d next %d err %d marks:", sec, ntasks, w[0], w[1]);
-            for (int k = 0; k < 8; ++k) std::fprintf(stderr, " %d:%d", w[4 + k] >> 8, w[4 + k] & 255);
-            std::fprintf(stderr, "\n");
-            std::fflush(stderr);
-            struct timespec ts = {1, 0};
-            nanosleep(&ts, nullptr);
-        }
-        if (hipEventQuery(evd) == hipErrorNotReady) { std::fprintf(stderr, "[df] still running after 20 s, exiting\n"); _exit(3); }
-    }
-    int32_t ctrl[2] = {0, 0};
-    hip_check(hipMemcpyAsync(ctrl, dflags + ntasks, sizeof ctrl, hipMemcpyDeviceToHost, stream_), "read ctrl");
-    sync_stream("dataflow execution");
-    if (ctrl[1] != 0) fatal("dataflow executor: a workgroup timed out waiting for a producer (results are invalid)");
-    if (kernel_timing) {
-        float ms = 0;
-        hip_check(hipEventElapsedTime(&ms, ev_[0], ev_[1]), "elapsed");
-        stats.ms_blind_rotate += ms;      // fused kernel: blind rotations + key switches
-    }
-    for (const GateTask &t : tasks) {
-        if (t.kind == TASK_NOT) ++stats.linear_ops;
-        else { stats.blind_rotates += t.kind == TASK_MUX ? 2 : 1; ++stats.keyswitches; }
-    }
-    ++stats.br_launches;
-    stats.levels += (uint64_t)depth;
-    ++stats.flushes;
-    stats.ms_flush_wall += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
-}
-#endif  // TFHE_HIP_EXPERIMENTAL
 
 void Engine::run_bootstrap_woks(const DeviceKeyImage *key, const Torus32 *lin, int count, Torus32 *u_out, Torus32 *acc_out) {
+    ENGINE_DEVICE_SCOPE();
     wait_flight();
     const DevParams &dp = key->dp;
     // temporary "pool": count slots holding lin
@@ -895,6 +835,7 @@ void Engine::run_bootstrap_woks(const DeviceKeyImage *key, const Torus32 *lin, i
 }
 
 void Engine::run_keyswitch(const DeviceKeyImage *key, const Torus32 *u, int count, Torus32 *out) {
+    ENGINE_DEVICE_SCOPE();
     wait_flight();
     const DevParams &dp = key->dp;
     const int uw = dp.k * dp.N + 1;
@@ -917,6 +858,7 @@ void Engine::run_keyswitch(const DeviceKeyImage *key, const Torus32 *u, int coun
 }
 
 double Engine::run_lane_probe(const DeviceKeyImage *key, int lanes, int levels, int width, unsigned long long *wg_times) {
+    ENGINE_DEVICE_SCOPE();
     wait_flight();
     const DevParams &dp = key->dp;
     lanes = std::max(1, std::min(lanes, 8));
@@ -994,6 +936,7 @@ double Engine::run_lane_probe(const DeviceKeyImage *key, int lanes, int levels, 
 }
 
 void Engine::run_negacyclic(const DeviceKeyImage *key, const int32_t *ip, const Torus32 *tp, Torus32 *res, int count) {
+    ENGINE_DEVICE_SCOPE();
     wait_flight();
     DevParams dp = key->dp;
     // 2: through the split transforms; 3: first transpose through the cross-lane paths (N = 1024; same results);

@@ -3,6 +3,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 
+#include <atomic>
 #include <chrono>
 #include <cstdint>
 #include <string>
@@ -73,18 +74,14 @@ private:
 };
 
 struct LevelPlan {
-    // descriptors of the whole flush, ordered by (level, lane); group g = level_index * lanes + lane
+    // descriptors of the whole flush, ordered by level
     std::vector<RotDesc> rots;
     std::vector<KsDesc> kss;
     std::vector<NotDesc> nots;
-    int lanes = 1;
     int levels = 0;
-    std::vector<int32_t> rot_off, ks_off;   // size levels*lanes + 1; gates of level L (1-based): index (L-1)*lanes + lane
-    std::vector<int32_t> not_off;           // size (levels+1)*lanes + 1; NOTs riding on level L (0 = inputs): L*lanes + lane
-    std::vector<int32_t> max_rots;          // per lane: widest group (sizes the lane's extract buffer)
-    // lanes > 1: need[g * lanes + other] = 1 + the highest level of lane `other` whose results
-    // the gates of group g read (0 = none); g indexes like not_off (level L, lane)
-    std::vector<int32_t> need;
+    std::vector<int32_t> rot_off, ks_off;   // size levels + 1; gates of level L (1-based): index L - 1
+    std::vector<int32_t> not_off;           // size levels + 2; NOTs riding on level L (0 = inputs): index L
+    int32_t max_rots = 0;                   // widest level (sizes the extract buffer)
 };
 
 class Engine {
@@ -116,15 +113,13 @@ public:
     void sync_stream(const char *what); // everything enqueued on the engine's stream has completed
     void sync_io();                     // the stream-ordered transfers nobody waited for have completed
     void wait_all() { wait_flight(); sync_io(); }
+    void wait_event(hipEvent_t ev, const char *what);   // a caller's event, bounded like the waits above
+    bool pci_bus_id(char *out, int len);                // "0000:c1:00.0" of the engine's device
     // > 0: no host wait on the engine's stream lasts longer -- on expiry the process prints what it waited for and ends
     // with TFHE_HIP_EXIT_DEADLINE (tuning "sync_deadline_ms", env TFHE_HIP_SYNC_DEADLINE_MS); 0 = wait for ever
     long long sync_deadline_ms = 0;
     std::string diag_label;             // who waits, for the deadline message (tfhe_hip_set_diag_label: "rank 3 of 8")
     bool in_flight() const { return in_flight_; }
-#ifdef TFHE_HIP_EXPERIMENTAL
-    // run a whole DAG (tasks in topological priority order) as one dataflow launch
-    void execute_dataflow(const DeviceKeyImage *key, SlotPool *pool, const std::vector<GateTask> &tasks, int depth);
-#endif
     // raw test paths
     void run_bootstrap_woks(const DeviceKeyImage *key, const Torus32 *lin, int count, Torus32 *u_out, Torus32 *acc_out);
     void run_keyswitch(const DeviceKeyImage *key, const Torus32 *u, int count, Torus32 *out);
@@ -165,9 +160,6 @@ public:
     // (kernels.hip keyswitch_index_kernel; tiles of 16, 24 or 32): 60.8 ms per match against 105 ms of the LDS-strip form;
     // 1 = rows in registers, picked by scalar branches (keyswitch_branch_kernel): 73 ms; 0 = the LDS-strip form
     int ks_branch = 2;
-    // two-lane execution: 1 = the urgent lane's blind-rotate waves raise their issue priority
-    // (measured slower: the co-resident workgroups of the other lane become its stragglers)
-    int lane_prio = 0;
     // blind rotate: k > 0 = the two workgroups sharing a CU swap issue priority every 2^k shader
     // cycles (0 = off: the hardware's oldest-first issue runs one at full speed and leaves the
     // other to finish alone with one wave per SIMD; measured optimum 2^16..2^20, tools/wg_times.py)
@@ -189,9 +181,10 @@ public:
     // of at most 7 bits; split form: stage 0, and the first radix-4 step too where digits have at most 6
     // bits); 2 = split form: stage 0 only; 0 = multiplies (env TFHE_HIP_BR_TABLE, tuning "br_digit_table")
     int br_digit_table = 1;
-    // stream == nullptr: the engine's stream; lane selects the scratch buffer of the partial sums
+    // stream == nullptr: the engine's stream; `scratch_set` selects the scratch buffer of the partial sums (the lane probe
+    // runs several chains at once)
     void launch_ks(const DeviceKeyImage *key, const int32_t *u_buf, const KsDesc *descs, int count, int32_t *pool,
-                   hipStream_t stream = nullptr, int lane = 0);
+                   hipStream_t stream = nullptr, int scratch_set = 0);
     // returns true when the launch used the 8-wave form
     bool launch_br(const DeviceKeyImage *key, const int32_t *pool, const RotDesc *rots, int count, int32_t *u_buf,
                    int32_t *acc_dbg, hipStream_t stream = nullptr, int wave_prio = 0);
@@ -224,16 +217,14 @@ private:
     size_t slot_ring_pos_ = 0;
     int device_ = 0;
     int cu_count_ = 256;
-    bool inited_ = false;
+    std::atomic<bool> inited_{false};
     hipStream_t stream_ = nullptr;
     uint32_t *cu_arrivals_ = nullptr;
     unsigned long long *clock_acc_ = nullptr;           // kernel timing: shader-cycle / reference-tick sums (kernels.hpp)
     unsigned long long *wg_times_dbg_ = nullptr;        // set by the workgroup-time probe only
-    hipStream_t lane_stream_[2] = {nullptr, nullptr};   // lane 0 = stream_, lane 1 created on first use
-    std::vector<hipEvent_t> order_events_;              // cross-lane ordering, no timing
     size_t timing_used_ = 0;
     hipEvent_t next_timing_event();
-    std::vector<hipEvent_t> timing_events_;             // kernel_timing: 3 per (level, lane) + 1 base
+    std::vector<hipEvent_t> timing_events_;             // kernel_timing: up to 3 per level + 1 base
     hipEvent_t ev_[3] = {nullptr, nullptr, nullptr};
     std::vector<SlotPool *> pools_;
     std::vector<void *> scratch_ptr_;

@@ -8,13 +8,15 @@
 //         blind_rotate_split_kernel  eight wave64 per rotation, every transform as two half-size ones
 //                                 (default at N = 2048; selectable at N = 1024)
 //         blind_rotate_kernel     two wave64 per rotation (selectable, tested)
-//   K3/K4 keyswitch_tile_kernel   (u0 [+ u1] + const) -> LWE sample under the gate key, one pass
-//                                 over the KSK rows of a coefficient range serves 16 gates
+//   K3/K4 keyswitch_index_kernel  (u0 [+ u1] + const) -> LWE sample under the gate key (default for wide launches): one
+//                                 pass over the KSK rows of a coefficient range serves a tile of 16 gates; a thread's
+//                                 column of the staged rows sits in pinned VGPRs picked through the VGPR index mode
+//                                 by the wave-uniform digit (statements generated: ks_index_asm.inc)
+//         keyswitch_branch_kernel / keyswitch_tile_kernel  the scalar-branch and LDS-strip forms of the same tile
+//                                 (selectable with "ks_branch" 1 / 0, tested)
 //         keyswitch_kernel        per-gate form for narrow launches; ks_reduce_kernel adds the
 //                                 partial sums of the ranges
 //   K5    not_kernel              negation
-//         gate_dataflow_kernel    experimental (built with -DTFHE_HIP_EXPERIMENTAL only): a whole gate DAG in one
-//                                 persistent launch
 //         gather/scatter_slots    packed words <-> ciphertext pool (import, export, collectives)
 //
 // Restates (does not translate) tfhe's tfhe_bootstrap_woKS_FFT / tfhe_blindRotate_FFT
@@ -624,14 +626,14 @@ __device__ __forceinline__ void blind_rotate4_body(const DevParams &p, const Dev
         if (q == 0) {                                    // (two copies: register indices must be compile-time constants)
 #pragma unroll
             for (int r = 0; r < HALF; ++r) mx[r * 64 + lane] = (uint32_t)t[HALF + r];
-            lds_barrier();
+            LDS_BARRIER_ROLE("q=0");
 #pragma unroll
             for (int r = 0; r < HALF; ++r)
                 sh.acc.set(u, r * 64 + lane, sh.acc.get(u, r * 64 + lane) + crt_signed_to_torus(t[r], (int32_t)ox[r * 64 + lane]));
         } else {
 #pragma unroll
             for (int r = 0; r < HALF; ++r) mx[r * 64 + lane] = (uint32_t)t[r];
-            lds_barrier();
+            LDS_BARRIER_ROLE("q=1");
 #pragma unroll
             for (int r = 0; r < HALF; ++r)
                 sh.acc.set(u, (HALF + r) * 64 + lane,
@@ -1182,202 +1184,6 @@ __global__ __launch_bounds__(256) void negacyclic_split_kernel(const int32_t *__
     }
 }
 
-#ifdef TFHE_HIP_EXPERIMENTAL   // measured slower than per-level launches: off in build.sh
-// ---------------------------------------------------------------------------
-// Dataflow executor: ONE launch runs a whole recorded gate DAG.  `tasks` is sorted in a
-// topological priority order (scheduler.cpp); every workgroup repeatedly takes the next
-// index, waits until the producers of its operands have published, runs the gate entirely
-// inside the workgroup (prelude, blind rotation(s), sample extract, key switch with the
-// extracted sample still in LDS) and publishes a done flag.
-//  * No co-residency is assumed: a workgroup only ever waits for tasks with smaller indices,
-//    which were taken by workgroups that are already running, so any number of resident
-//    workgroups makes progress (no grid barrier, no deadlock).
-//  * Hand-off follows the agent-scope release/acquire recipe: every storing wave drains its
-//    stores, workgroup barrier, lane 0 release fence + drain + relaxed agent flag store;
-//    the consumer polls the flag relaxed, ONE acquire fence, drain, barrier, plain loads.
-//  * Every spin is bounded; on timeout the error word is set and all workgroups leave.
-// ---------------------------------------------------------------------------
-template <int LOGN>
-__device__ __forceinline__ void keyswitch_in_wg(const DevParams &p, const DevKey &key, Br4Lds<LOGN> &sh,
-                                                const uint32_t *lds_u, int32_t *__restrict__ dst, int tid) {
-    // 4 waves x a quarter of the input coefficients; a lane owns columns lane + 64 m of the row
-    constexpr int NCOL = LOGN == 10 ? 3 : 5;       // ceil(ct_stride/4 / 64) for n <= 767 / n <= 1279
-    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int lane = tid & 63;
-    const int nin = p.k * (1 << LOGN);
-    const int nvec = p.ct_stride >> 2;
-    const int t = p.ks_t, bb = p.ks_basebit;
-    const uint32_t mask = (1u << bb) - 1u;
-    const uint4 *ksk = reinterpret_cast<const uint4 *>(key.ksk);
-    const uint4 *zero_row = reinterpret_cast<const uint4 *>(key.ksk_zero);
-    uint4 acc[NCOL];
-#pragma unroll
-    for (int m = 0; m < NCOL; ++m) acc[m] = make_uint4(0, 0, 0, 0);
-    const int i0 = nin * wv / 4, i1 = nin * (wv + 1) / 4;
-    // KT digits of one coefficient are handled together: all their row loads are issued
-    // before the first subtraction, so 8 x NCOL 16-byte loads are in flight per lane
-    constexpr int KT = 8;
-    if (t == KT) {
-        for (int i = i0; i < i1; ++i) {
-            const uint32_t aibar = lds_u[i] + p.ks_prec_offset;
-            uint4 v[KT][NCOL];
-#pragma unroll
-            for (int j = 0; j < KT; ++j) {
-                const uint32_t aij = (aibar >> (32 - (j + 1) * bb)) & mask;
-                // digit 0 subtracts nothing: read a row of zeros instead of branching
-                const uint4 *row = aij ? ksk + ((size_t)(i * KT + j) * mask + (aij - 1)) * (size_t)nvec : zero_row;
-#pragma unroll
-                for (int m = 0; m < NCOL; ++m) {
-                    const int col = lane + 64 * m;
-                    v[j][m] = col < nvec ? row[col] : make_uint4(0, 0, 0, 0);
-                }
-            }
-#pragma unroll
-            for (int j = 0; j < KT; ++j)
-#pragma unroll
-                for (int m = 0; m < NCOL; ++m) {
-                    acc[m].x -= v[j][m].x; acc[m].y -= v[j][m].y; acc[m].z -= v[j][m].z; acc[m].w -= v[j][m].w;
-                }
-        }
-    } else {
-        for (int i = i0; i < i1; ++i) {
-            const uint32_t aibar = lds_u[i] + p.ks_prec_offset;
-            for (int j = 0; j < t; ++j) {
-                const uint32_t aij = (aibar >> (32 - (j + 1) * bb)) & mask;
-                if (aij == 0) continue;
-                const uint4 *row = ksk + ((size_t)(i * t + j) * mask + (aij - 1)) * (size_t)nvec;
-#pragma unroll
-                for (int m = 0; m < NCOL; ++m) {
-                    const int col = lane + 64 * m;
-                    if (col < nvec) {
-                        const uint4 r = row[col];
-                        acc[m].x -= r.x; acc[m].y -= r.y; acc[m].z -= r.z; acc[m].w -= r.w;
-                    }
-                }
-            }
-        }
-    }
-    uint4 *part = reinterpret_cast<uint4 *>(sh.scr(wv));       // >= ct_stride words per wave
-#pragma unroll
-    for (int m = 0; m < NCOL; ++m)
-        if (lane + 64 * m < nvec) part[lane + 64 * m] = acc[m];
-    __syncthreads();
-    for (int col = tid; col < nvec; col += 256) {
-        uint4 s = reinterpret_cast<const uint4 *>(sh.scr(0))[col];
-#pragma unroll
-        for (int w = 1; w < 4; ++w) {
-            const uint4 v = reinterpret_cast<const uint4 *>(sh.scr(w))[col];
-            s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
-        }
-        uint32_t o[4] = {s.x, s.y, s.z, s.w};
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-            const int wi = 4 * col + e;
-            if (wi == p.n) o[e] += lds_u[nin];
-            if (wi > p.n) o[e] = 0;
-        }
-        reinterpret_cast<uint4 *>(dst)[col] = make_uint4(o[0], o[1], o[2], o[3]);
-    }
-}
-
-template <int LOGN>
-__global__ __launch_bounds__(256, 1) void gate_dataflow_kernel(
-    DevParams p, DevKey key, int32_t *__restrict__ pool, const GateTask *__restrict__ tasks, int ntasks,
-    int32_t *__restrict__ done, int32_t *__restrict__ ctrl /* [0] next task, [1] error, [2..] debug */) {
-    constexpr int N = 1 << LOGN;
-    __shared__ __align__(16) Br4Lds<LOGN> sh;
-    __shared__ __align__(16) uint32_t lds_u[N + 8];           // extracted sample(s): kN mask words, body
-    __shared__ int32_t s_task;
-    const int tid = threadIdx.x;
-
-    // Loop shape matters: the condition is a scalar (readfirstlane) value, and the only
-    // single-lane block that touches the loop-carried state (publish + take the next task)
-    // sits between two barriers INSIDE the iteration.  With `if (tid == 0)` blocks on both
-    // sides of the back-edge the compiler's CFG structuriser parks lane 0 and sends the other
-    // lanes around the loop again (observed: the same task re-executed forever).
-    auto take_task = [&]() -> int32_t {
-        int32_t t = __hip_atomic_fetch_add(&ctrl[0], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        if (__hip_atomic_load(&ctrl[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) t = ntasks;
-        return t;
-    };
-    if (tid == 0) s_task = take_task();
-    __syncthreads();
-    int ti = __builtin_amdgcn_readfirstlane(s_task);
-    while (ti < ntasks) {
-        GateTask task;
-        {
-            const int32_t *tw = reinterpret_cast<const int32_t *>(tasks + ti);
-            int32_t *dw = reinterpret_cast<int32_t *>(&task);
-#pragma unroll
-            for (int f = 0; f < (int)(sizeof(GateTask) / 4); ++f) dw[f] = __builtin_amdgcn_readfirstlane(tw[f]);
-        }
-#ifdef TFHE_HIP_STAMPS   // progress words for the TFHE_HIP_DF_DEBUG watchdog (diagnostic build only)
-#define DF_MARK(code) do { if (tid == 0) __hip_atomic_store(&ctrl[4 + (blockIdx.x & 63)], (ti << 8) | (code), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); } while (0)
-#else
-#define DF_MARK(code)
-#endif
-        DF_MARK(1);
-
-        // ---- wait for the producers (tasks with smaller indices), then one acquire ----
-        if (tid == 0) {
-            const int32_t deps[3] = {task.dep_a, task.dep_b, task.dep_c};
-            for (int d = 0; d < 3; ++d) {
-                if (deps[d] < 0) continue;
-                unsigned spins = 0;
-                while (__hip_atomic_load(&done[deps[d]], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0) {
-                    __builtin_amdgcn_s_sleep(32);
-                    if (++spins > (1u << 22)) {                 // ~seconds: something is wrong, leave
-                        __hip_atomic_store(&ctrl[1], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                        break;
-                    }
-                }
-            }
-            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        }
-        __syncthreads();
-        DF_MARK(2);
-
-        int32_t *dst = pool + (size_t)task.dst_slot * p.ct_stride;
-        if (task.kind == TASK_NOT) {
-            const int32_t *src = pool + (size_t)task.slot_a * p.ct_stride;
-            for (int i = tid; i < p.ct_stride; i += 256) dst[i] = (int32_t)(0u - (uint32_t)src[i]);
-        } else {
-            // first (or only) blind rotation, sample extract into LDS
-            const RotDesc r0{task.slot_a, task.slot_b, task.sa, task.sb, task.c0, 0};
-            blind_rotate4_body<LOGN>(p, key, pool, r0, sh, tid);
-            DF_MARK(3);
-            for (int j = tid; j < N; j += 256) lds_u[j] = j == 0 ? sh.acc.get(0, 0) : 0u - sh.acc.get(0, N - j);
-            if (tid == 0) lds_u[N] = sh.acc.get(1, 0);
-            __syncthreads();
-            if (task.kind == TASK_MUX) {
-                // tfhe bootsMUX: second rotation on (-1/8 - a + c), then u1 + u2 + (0, 1/8)
-                const RotDesc r1{task.slot_a, task.slot_c, -1, 1, task.c0, 0};
-                blind_rotate4_body<LOGN>(p, key, pool, r1, sh, tid);
-                for (int j = tid; j < N; j += 256) lds_u[j] += j == 0 ? sh.acc.get(0, 0) : 0u - sh.acc.get(0, N - j);
-                if (tid == 0) lds_u[N] += sh.acc.get(1, 0) + (uint32_t)p.mu;
-                __syncthreads();
-            }
-            DF_MARK(4);
-            keyswitch_in_wg<LOGN>(p, key, sh, lds_u, dst, tid);
-            DF_MARK(5);
-        }
-
-        // ---- publish, and take the next task in the same single-lane block ----
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();
-        if (tid == 0) {
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            __hip_atomic_store(&done[ti], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            s_task = take_task();
-        }
-        __syncthreads();
-        ti = __builtin_amdgcn_readfirstlane(s_task);
-    }
-}
-
-#endif  // TFHE_HIP_EXPERIMENTAL
 
 // ---------------------------------------------------------------------------
 // K3/K4: key switch (tfhe lweKeySwitchTranslate_fromArray).  grid = gates.
@@ -2020,17 +1826,6 @@ void launch_blind_rotate4(hipStream_t s, const DevParams &p, const DevKey &key, 
 #undef BR4
 }
 
-#ifdef TFHE_HIP_EXPERIMENTAL
-void launch_gate_dataflow(hipStream_t s, const DevParams &p, const DevKey &key, int32_t *pool, const GateTask *tasks,
-                          int ntasks, int32_t *done, int32_t *ctrl, int max_blocks) {
-    if (ntasks <= 0) return;
-    const int grid = ntasks < max_blocks ? ntasks : max_blocks;
-    if (p.N == 2048)
-        hipLaunchKernelGGL(gate_dataflow_kernel<11>, dim3(grid), dim3(256), 0, s, p, key, pool, tasks, ntasks, done, ctrl);
-    else
-        hipLaunchKernelGGL(gate_dataflow_kernel<10>, dim3(grid), dim3(256), 0, s, p, key, pool, tasks, ntasks, done, ctrl);
-}
-#endif
 
 void launch_keyswitch(hipStream_t s, const DevParams &p, const DevKey &key, const int32_t *u_buf,
                       const KsDesc *descs, int count, int32_t *pool, int splits, int32_t *partial, int tile, bool atomic,

@@ -101,6 +101,10 @@ __device__ __forceinline__ void wave_lds_fence() { asm volatile("" ::: "memory")
 // requested just before) running while the wave waits for its siblings.  Nothing in the blind-rotate loop stores to
 // global memory, so there is nothing else for the barrier to order.
 __device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+// The same barrier inside a branch only SOME waves of a workgroup take (`if (q == 0) ... else ...`), with a comment that
+// rides into the assembly listing: tools/isa_mix.py counts the instructions of one blind-rotate step per wave from that
+// listing and needs to know which branches exclude each other.  A comment: the code object is byte for byte the same.
+#define LDS_BARRIER_ROLE(tag) asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier ; isa_mix role " tag ::: "memory")
 
 __device__ __forceinline__ void ct_bfly(int32_t &a, int32_t &b, uint32_t w, const PrimeCtx &c) {
     const int32_t t = mont_mul(b, w, c.P, c.pinv);

@@ -14,38 +14,6 @@ struct HeapItem {
 };
 }  // namespace
 
-#ifdef TFHE_HIP_EXPERIMENTAL   // orders for the experimental executors (dataflow launch, two lanes)
-void priority_order(const std::vector<PendingOp> &ops, const std::vector<int32_t> &lvl,
-                    const std::vector<int32_t> &alap, std::vector<int32_t> &order) {
-    const int n = (int)ops.size();
-    order.resize(n);
-    for (int i = 0; i < n; ++i) order[i] = i;
-    std::stable_sort(order.begin(), order.end(), [&](int32_t x, int32_t y) {
-        if (lvl[x] != lvl[y]) return lvl[x] < lvl[y];
-        const bool nx = ops[x].kind == OP_NOT, ny = ops[y].kind == OP_NOT;
-        if (nx != ny) return ny;                 // gates of a level before the NOTs riding on it
-        if (alap[x] != alap[y]) return alap[x] < alap[y];
-        return x < y;
-    });
-}
-
-void assign_lanes(const std::vector<PendingOp> &ops, const std::vector<int32_t> &alap, int tight_slack,
-                  std::vector<uint8_t> &lanes_out) {
-    const int n = (int)ops.size();
-    lanes_out.assign(n, 0);
-    std::unordered_map<int32_t, int32_t> producer;
-    producer.reserve((size_t)n * 2);
-    for (int i = 0; i < n; ++i) {
-        if (ops[i].kind == OP_NOT) {
-            auto it = producer.find(ops[i].a);
-            lanes_out[i] = it == producer.end() ? 0 : lanes_out[it->second];
-        } else {
-            lanes_out[i] = (alap[i] - ops[i].level) <= tight_slack ? 0 : 1;
-        }
-        producer.emplace(ops[i].dst, i);
-    }
-}
-#endif  // TFHE_HIP_EXPERIMENTAL
 
 int schedule_levels(const std::vector<PendingOp> &ops, int asap_depth, bool balance, int unit,
                     std::vector<int32_t> &lvl, std::vector<int32_t> *alap_out) {

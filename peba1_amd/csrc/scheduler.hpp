@@ -33,23 +33,5 @@ inline int op_rotations(const PendingOp &op) { return op.kind == OP_NOT ? 0 : (o
 int schedule_levels(const std::vector<PendingOp> &ops, int asap_depth, bool balance, int unit,
                     std::vector<int32_t> &lvl, std::vector<int32_t> *alap_out = nullptr);
 
-#ifdef TFHE_HIP_EXPERIMENTAL
-// Execution order for the dataflow executor: a topological order of the DAG in which
-// more urgent gates come first (balanced level, then ALAP level, then recording order;
-// a NOT directly after the gates of its level).  order[k] = index into ops.
-void priority_order(const std::vector<PendingOp> &ops, const std::vector<int32_t> &lvl,
-                    const std::vector<int32_t> &alap, std::vector<int32_t> &order);
-
-// Two execution lanes (HIP streams) for a levelised DAG.  Level-synchronous execution leaves
-// a bubble at every level boundary (all workgroups of a launch start and end together, then
-// the key switch runs alone).  Cutting the gates into two sets that each run their own
-// level sequence, ordered against each other only where a gate really needs a result of the
-// other set, lets the boundaries of one lane fall inside the launches of the other.
-// lane 0 ("urgent"): gates whose slack (ALAP - ASAP level) is at most tight_slack -- the
-// critical chains; lane 1: the rest.  A NOT rides in the lane of the gate that produces its
-// operand (lane 0 when that is already materialised).  lanes_out[i] in {0, 1}.
-void assign_lanes(const std::vector<PendingOp> &ops, const std::vector<int32_t> &alap, int tight_slack,
-                  std::vector<uint8_t> &lanes_out);
-#endif  // TFHE_HIP_EXPERIMENTAL
 
 }  // namespace tfhe_hip

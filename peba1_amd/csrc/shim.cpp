@@ -105,11 +105,6 @@ struct Recorder {
     Rng enc_secret = Rng::secure(), enc_mask = Rng::secure();
     bool enc_seeded = false;
     bool balance_levels = true;   // slack-aware level filling (scheduler.hpp)
-#ifdef TFHE_HIP_EXPERIMENTAL      // executors that measured slower than per-level launches
-    bool dataflow = false;        // opt-in: one dataflow launch per flush instead of per-level launches
-    int lanes = 1;                // 2: urgent gates and the rest on two streams (scheduler.hpp assign_lanes)
-    int tight_slack = 64;         // lane 0 takes the gates with at most this much slack
-#endif
     std::unordered_map<int32_t, int32_t> not_origin;   // pending NOT output slot -> its operand slot
     // Pending gates by (kind, operand slots): a gate recorded again with the same operands before
     // the flush is the same function of the same ciphertexts, so its result slot is shared
@@ -139,11 +134,6 @@ Recorder &rec() {
     static Recorder r;
     static bool init = [] {
         if (const char *e = std::getenv("TFHE_HIP_DEFERRED")) r.deferred = std::atoi(e) != 0;
-#ifdef TFHE_HIP_EXPERIMENTAL
-        if (const char *e = std::getenv("TFHE_HIP_DATAFLOW")) r.dataflow = std::atoi(e) != 0;
-        if (const char *e = std::getenv("TFHE_HIP_LANES")) r.lanes = std::atoi(e) > 1 ? 2 : 1;
-        if (const char *e = std::getenv("TFHE_HIP_TIGHT_SLACK")) r.tight_slack = std::atoi(e);
-#endif
         return true;
     }();
     (void)init;
@@ -350,82 +340,26 @@ int flush_locked(bool wait) {
             std::fclose(f);
         }
     }
-#ifdef TFHE_HIP_EXPERIMENTAL
-    if (r.dataflow) {
-        // one launch for the whole DAG: tasks in topological priority order, each naming the
-        // tasks that produce its operands
-        std::vector<int32_t> order;
-        priority_order(r.ops, lvl, alap, order);
-        std::unordered_map<int32_t, int32_t> task_of_slot;
-        task_of_slot.reserve(r.ops.size() * 2);
-        std::vector<GateTask> tasks(r.ops.size());
-        const int32_t mu = 1 << 29;
-        auto dep = [&](int32_t slot) {
-            if (slot < 0) return (int32_t)-1;
-            auto it = task_of_slot.find(slot);
-            return it == task_of_slot.end() ? (int32_t)-1 : it->second;
-        };
-        for (size_t k = 0; k < order.size(); ++k) {
-            const PendingOp &op = r.ops[order[k]];
-            GateTask t{};
-            t.dst_slot = op.dst;
-            t.slot_a = op.a; t.slot_b = op.b >= 0 ? op.b : op.a; t.slot_c = op.c >= 0 ? op.c : op.a;
-            t.dep_a = dep(op.a); t.dep_b = dep(op.b); t.dep_c = dep(op.c);
-            if (op.kind == OP_NOT) { t.kind = TASK_NOT; }
-            else if (op.kind == OP_MUX) { t.kind = TASK_MUX; t.sa = 1; t.sb = 1; t.c0 = -mu; }
-            else { const GateLin &gl = GATE_LIN[op.kind]; t.kind = TASK_GATE2; t.sa = gl.sa; t.sb = gl.sb; t.c0 = gl.c8 * mu; }
-            tasks[k] = t;
-            task_of_slot.emplace(op.dst, (int32_t)k);
-        }
-        Engine::get().execute_dataflow(r.key->bk->dev, pool, tasks, levels);
-        for (const PendingOp &op : r.ops) {
-            pool->level[op.dst] = 0;
-            pool->pending[op.dst] = 0;
-            pool->release(op.dst);
-            pool->release(op.a);
-            if (op.b >= 0) pool->release(op.b);
-            if (op.c >= 0) pool->release(op.c);
-        }
-        r.ops.clear();
-        r.not_origin.clear();
-        r.pending_gate.clear();
-        r.pending_mux.clear();
-        r.max_level = 0;
-        return levels;
-    }
-#endif  // TFHE_HIP_EXPERIMENTAL
-    // execution lanes: urgent gates (little slack) and the rest run as two level sequences on
-    // two streams, ordered against each other only where the DAG says so (scheduler.hpp)
-    int K = 1;
-    std::vector<uint8_t> lane;
-#ifdef TFHE_HIP_EXPERIMENTAL
-    if (r.lanes > 1 && levels > 2) {
-        assign_lanes(r.ops, alap, r.tight_slack, lane);
-        for (uint8_t l : lane) if (l) { K = 2; break; }
-    }
-#endif
-    if (K == 1) lane.assign(r.ops.size(), 0);
     LevelPlan plan;
-    plan.lanes = K;
     plan.levels = levels;
-    // counting sort by (level, lane)
-    const size_t ngroups = (size_t)levels * K, nnotgroups = ((size_t)levels + 1) * K;
+    // counting sort by level: gates of level L (1-based) in group L - 1, NOTs riding on level L (0 = inputs) in group L
+    const size_t ngroups = (size_t)levels, nnotgroups = (size_t)levels + 1;
     std::vector<int32_t> nrot(ngroups + 1, 0), nks(ngroups + 1, 0), nnot(nnotgroups + 1, 0);
     for (size_t i = 0; i < r.ops.size(); ++i) {
         const PendingOp &op = r.ops[i];
-        if (op.kind == OP_NOT) { ++nnot[(size_t)lvl[i] * K + lane[i]]; continue; }
-        const size_t g = (size_t)(lvl[i] - 1) * K + lane[i];
+        if (op.kind == OP_NOT) { ++nnot[(size_t)lvl[i]]; continue; }
+        const size_t g = (size_t)(lvl[i] - 1);
         nrot[g] += op.kind == OP_MUX ? 2 : 1;
         ++nks[g];
     }
     plan.rot_off.assign(ngroups + 1, 0);
     plan.ks_off.assign(ngroups + 1, 0);
     plan.not_off.assign(nnotgroups + 1, 0);
-    plan.max_rots.assign(K, 0);
+    plan.max_rots = 0;
     for (size_t g = 0; g < ngroups; ++g) {
         plan.rot_off[g + 1] = plan.rot_off[g] + nrot[g];
         plan.ks_off[g + 1] = plan.ks_off[g] + nks[g];
-        plan.max_rots[g % K] = std::max(plan.max_rots[g % K], nrot[g]);
+        plan.max_rots = std::max(plan.max_rots, nrot[g]);
     }
     for (size_t g = 0; g < nnotgroups; ++g) plan.not_off[g + 1] = plan.not_off[g] + nnot[g];
     plan.rots.resize(plan.rot_off[ngroups]);
@@ -434,31 +368,14 @@ int flush_locked(bool wait) {
     std::vector<int32_t> rpos(plan.rot_off.begin(), plan.rot_off.end() - 1);   // cursor per group
     std::vector<int32_t> kpos(plan.ks_off.begin(), plan.ks_off.end() - 1);
     std::vector<int32_t> npos(plan.not_off.begin(), plan.not_off.end() - 1);
-    // cross-lane needs: which level of the other lane must be complete before a group starts
-    std::unordered_map<int32_t, int32_t> producer;
-    if (K > 1) {
-        plan.need.assign(nnotgroups * K, 0);
-        producer.reserve(r.ops.size() * 2);
-        for (size_t i = 0; i < r.ops.size(); ++i) producer.emplace(r.ops[i].dst, (int32_t)i);
-    }
-    auto note_need = [&](size_t i, int32_t slot) {
-        if (slot < 0) return;
-        auto it = producer.find(slot);
-        if (it == producer.end() || (size_t)it->second >= i) return;     // materialised before this flush
-        const int32_t pi = it->second;
-        if (lane[pi] == lane[i]) return;
-        int32_t &w = plan.need[((size_t)lvl[i] * K + lane[i]) * K + lane[pi]];
-        w = std::max(w, lvl[pi] + 1);
-    };
     const int32_t mu = 1 << 29;
     for (size_t i = 0; i < r.ops.size(); ++i) {
         const PendingOp &op = r.ops[i];
-        if (K > 1) { note_need(i, op.a); note_need(i, op.b); note_need(i, op.c); }
         if (op.kind == OP_NOT) {
-            plan.nots[npos[(size_t)lvl[i] * K + lane[i]]++] = NotDesc{op.a, op.dst};
+            plan.nots[npos[(size_t)lvl[i]]++] = NotDesc{op.a, op.dst};
             continue;
         }
-        const size_t g = (size_t)(lvl[i] - 1) * K + lane[i];
+        const size_t g = (size_t)(lvl[i] - 1);
         const int32_t base = plan.rot_off[g];
         if (op.kind == OP_MUX) {
             // tfhe bootsMUX: u1 = BR(-1/8 + a + b), u2 = BR(-1/8 - a + c), KS(u1 + u2 + 1/8)
@@ -896,7 +813,10 @@ static int export_impl(const LweSample *samples, int32_t count, const TFheGateBo
         }
         return 0;
     }
-    if (!r.ops.empty()) flush_locked();
+    // the stream-ordered form (wait == false) only ENQUEUES the pending gates' launches: the gather below, and whatever
+    // the caller puts on the stream after it (a collective), follow them in stream order with no host wait (ADVICE r4:
+    // a synchronous flush here made every rank of a sharded match sit out its whole local phase on the host)
+    if (!r.ops.empty()) flush_locked(wait);
     std::vector<int32_t> slots(count);
     for (int32_t i = 0; i < count; ++i) slots[i] = ensure_slot(&samples[i], pool);
     Engine::get().read_slots_packed(pool, slots.data(), count, out, device_dst, wait);
@@ -1006,6 +926,21 @@ int tfhe_hip_stream_sync(void) {
         return 0;
     });
 }
+int tfhe_hip_wait_event(void *event, const char *what) {
+    if (!event) { set_error("tfhe_hip_wait_event: null event"); return -1; }
+    return guarded_rc([&] {
+        Engine::get().ensure_init();
+        Engine::get().wait_event(static_cast<hipEvent_t>(event), what && *what ? what : "tfhe_hip_wait_event");
+        return 0;
+    });
+}
+int tfhe_hip_device_pci_bus_id(char *out, int len) {
+    if (!out || len < 16) { set_error("tfhe_hip_device_pci_bus_id: buffer of at least 16 bytes needed"); return -1; }
+    return guarded_rc([&] {
+        Engine::get().ensure_init();
+        return Engine::get().pci_bus_id(out, len) ? 0 : -1;
+    });
+}
 void tfhe_hip_set_diag_label(const char *label) {
     std::lock_guard<std::recursive_mutex> g(rec().mtx);
     Engine::get().diag_label = label ? std::string(label).substr(0, 127) : std::string();
@@ -1031,14 +966,6 @@ int tfhe_hip_test_form_admissible(int form, int32_t N, int32_t l, int32_t Bgbit,
     return br_form_admissible(form, N, l, Bgbit, tables) ? 1 : 0;
 }
 
-int tfhe_hip_has_experimental(void) {
-#ifdef TFHE_HIP_EXPERIMENTAL
-    return 1;
-#else
-    return 0;
-#endif
-}
-
 int tfhe_hip_set_tuning(const char *name, int64_t value) {
     if (name && std::strcmp(name, "br4_max_rotations") == 0) { Engine::get().br4_max_rotations = (int)value; return 0; }
     if (name && std::strcmp(name, "ks_target_blocks") == 0) { Engine::get().ks_target_blocks = (int)value; return 0; }
@@ -1060,11 +987,6 @@ int tfhe_hip_set_tuning(const char *name, int64_t value) {
     if (name && std::strcmp(name, "eliminate_dead") == 0) { rec().eliminate_dead = value != 0; return 0; }
     if (name && std::strcmp(name, "balance_levels") == 0) { rec().balance_levels = value != 0; return 0; }
     if (name && std::strcmp(name, "sync_deadline_ms") == 0) { Engine::get().sync_deadline_ms = value > 0 ? (long long)value : 0; return 0; }
-#ifdef TFHE_HIP_EXPERIMENTAL
-    if (name && std::strcmp(name, "lanes") == 0) { rec().lanes = value > 1 ? 2 : 1; return 0; }
-    if (name && std::strcmp(name, "tight_slack") == 0) { rec().tight_slack = (int)value; return 0; }
-    if (name && std::strcmp(name, "dataflow") == 0) { rec().dataflow = value != 0; return 0; }
-#endif
     set_error(std::string("tfhe_hip_set_tuning: unknown name ") + (name ? name : "(null)"));
     return -1;
 }
@@ -1109,18 +1031,6 @@ int tfhe_hip_test_schedule(const int32_t *ops5, int32_t count, int32_t unit, int
     return d;
 }
 
-#ifdef TFHE_HIP_EXPERIMENTAL
-int tfhe_hip_test_assign_lanes(const int32_t *ops5, int32_t count, int32_t unit, int32_t tight_slack, int32_t *lanes_out) {
-    std::vector<PendingOp> ops;
-    const int depth = test_build_ops(ops5, count, ops);
-    std::vector<int32_t> lvl, alap;
-    const int d = schedule_levels(ops, depth, true, unit, lvl, &alap);
-    std::vector<uint8_t> lane;
-    assign_lanes(ops, alap, tight_slack, lane);
-    for (int32_t i = 0; i < count; ++i) lanes_out[i] = lane[i];
-    return d;
-}
-#endif
 
 double tfhe_hip_test_lane_probe(const TFheGateBootstrappingCloudKeySet *bk, int32_t lanes, int32_t levels, int32_t width) {
     if (!bk || !bk->bk) { set_error("lane_probe: null keyset"); return -1.0; }

@@ -73,6 +73,10 @@ def load():
         D.peba1_dist_set_host_bcast.argtypes = [V, _BCAST_FN]
         D.peba1_dist_broadcast_samples.argtypes = [V, V, I, V, I]
         D.peba1_dist_set_timeout.argtypes = [V, C.c_double]
+        D.peba1_dist_rccl_version.argtypes = []
+        D.peba1_dist_transport.argtypes = [V]
+        D.peba1_dist_counters.restype = None
+        D.peba1_dist_counters.argtypes = [V, C.POINTER(C.c_uint64)]
         D.peba1_dist_inject_failure.restype = None
         D.peba1_dist_inject_failure.argtypes = [V, I]
         _dlib = D
@@ -171,6 +175,13 @@ class Comm:
         if self.ptr:
             load().peba1_dist_destroy(self.ptr)
             self.ptr = None
+
+    def counters(self):
+        """What this communicator has done so far (peba1_dist_counters)."""
+        out = (C.c_uint64 * 4)()
+        load().peba1_dist_counters(self.ptr, out)
+        return {"status_word_exchanges": int(out[0]), "gathers": int(out[1]), "broadcasts": int(out[2]),
+                "payload_bytes_sent": int(out[3]), "transport": "rccl" if load().peba1_dist_transport(self.ptr) else "host"}
 
     def set_timeout(self, seconds):
         """Bound of every host wait behind a collective (peba1_dist_set_timeout; default PEBA1_DIST_TIMEOUT_S or 600 s)."""

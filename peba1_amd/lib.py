@@ -97,6 +97,7 @@ SIGNATURES = {
     "tfhe_hip_clear_error": (None, []),
     "tfhe_hip_set_device": (C.c_int, [C.c_int]),
     "tfhe_hip_get_device": (C.c_int, []),
+    "tfhe_hip_device_pci_bus_id": (C.c_int, [C.c_char_p, C.c_int]),
     "tfhe_hip_new_parameters": (PS, [C.c_int32] * 7 + [C.c_double] * 3),
     "tfhe_hip_new_p2048_parameters": (PS, []),
     "tfhe_hip_new_secret_keyset_seeded": (SK, [PS, C.c_uint64]),
@@ -123,10 +124,10 @@ SIGNATURES = {
     "tfhe_hip_flush_async": (C.c_int, []),
     "tfhe_hip_wait": (C.c_int, []),
     "tfhe_hip_stream_sync": (C.c_int, []),
+    "tfhe_hip_wait_event": (C.c_int, [C.c_void_p, C.c_char_p]),
     "tfhe_hip_set_diag_label": (None, [C.c_char_p]),
     "tfhe_hip_gate_batch": (C.c_int, [C.c_int, LS, LS, LS, C.c_int32, CK]),
     "tfhe_hip_set_tuning": (C.c_int, [C.c_char_p, C.c_int64]),
-    "tfhe_hip_has_experimental": (C.c_int, []),
     "tfhe_hip_test_form_admissible": (C.c_int, [C.c_int, C.c_int32, C.c_int32, C.c_int32, C.c_int]),
     "tfhe_hip_get_stats": (None, [C.POINTER(Stats)]),
     "tfhe_hip_reset_stats": (None, []),
@@ -138,11 +139,6 @@ SIGNATURES = {
 }
 for _g in _GATE2:
     SIGNATURES[_g] = (None, [LS, LS, LS, CK])
-# declared only under -DTFHE_HIP_EXPERIMENTAL (off in build.sh): bound when the library carries them
-EXPERIMENTAL_SIGNATURES = {
-    "tfhe_hip_test_assign_lanes": (C.c_int, [I32P, C.c_int32, C.c_int32, C.c_int32, I32P]),
-}
-
 _lib = None
 
 
@@ -159,15 +155,6 @@ def load():
             f = getattr(L, name)   # AttributeError if the library does not export a declared symbol
             f.restype = res
             f.argtypes = args
-        if L.tfhe_hip_has_experimental():
-            for name, (res, args) in EXPERIMENTAL_SIGNATURES.items():
-                f = getattr(L, name)
-                f.restype = res
-                f.argtypes = args
         _lib = L
     return _lib
 
-
-def experimental():
-    """True when libtfhe-hip.so was built with -DTFHE_HIP_EXPERIMENTAL (dataflow launch, two-lane execution)."""
-    return bool(load().tfhe_hip_has_experimental())

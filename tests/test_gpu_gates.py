@@ -252,40 +252,6 @@ print("OK", api.stats()["flushes"])
     assert out.returncode == 0 and "OK" in out.stdout, out.stdout + out.stderr
 
 
-def test_dataflow_executor_gives_identical_ciphertexts(p128_keys, oracle):
-    """The opt-in dataflow executor (one persistent launch, in-workgroup key switch, done-flag
-    hand-off between workgroups) against the default per-level executor: a multiplier plus a
-    comparator with MUXes and a NOT, word for word."""
-    from peba1_amd import api, circuits, lib
-    if not lib.experimental():
-        pytest.skip("the dataflow executor is built only with TFHE_HIP_DEFS=-DTFHE_HIP_EXPERIMENTAL")
-    pp, ks, oks = p128_keys
-    L = lib.load()
-    results = []
-    for dataflow in (1, 0):
-        api.set_tuning("dataflow", dataflow)
-        L.tfhe_hip_set_encrypt_seed(91)
-        a = circuits.encrypt_number(pp, 9, 9, ks)
-        b = circuits.encrypt_number(pp, 14, 9, ks)
-        prod = api.CiphertextArray(pp, 24)
-        mn = api.CiphertextArray(pp, 4)
-        bit = api.CiphertextArray(pp, 4)
-        neg = api.CiphertextArray(pp, 1)
-        api.set_deferred(True)
-        try:
-            circuits.load().peba1_multiply(prod.ptr, a.ptr, b.ptr, 4, ks.cloud)
-            circuits.load().peba1_minimum(mn.ptr, bit.ptr, a.ptr, b.ptr, 4, ks.cloud)
-            L.bootsNOT(neg.at(0), bit.at(0), ks.cloud)
-            api.flush()
-        finally:
-            api.set_deferred(False)
-            api.set_tuning("dataflow", 0)
-        results.append(np.concatenate([prod.words(), mn.words(), bit.words(), neg.words()]))
-        assert circuits.decrypt_number(prod, ks, 23) == 9 * 14
-        assert circuits.decrypt_number(mn, ks) == 9 and bit.decrypt(ks)[0] == 0 and neg.decrypt(ks)[0] == 1
-    assert (results[0] == results[1]).all()
-
-
 def test_random_gate_sweep_matches_oracle(p128_keys, oracle):
     """256 random gate instances over all ten two-input gate types, inputs that are fresh
     encryptions, trivial constants and previous gate outputs: every output word equals the oracle's."""

@@ -392,17 +392,11 @@ def test_sharded_match_in_two_processes_reproduces_the_oracle_digest(tmp_path):
     assert out.returncode == 0 and "TWO-PROCESS-OK" in out.stdout, out.stdout[-1500:] + out.stderr[-3000:]
 
 
-def test_bench_multi_process_default_mode_rehearsal():
-    """What the driver's `bench.py --gpus N` runs at N > 1 -- mode auto = sharded: slots partitioned
-    over the ranks, one gather, rank 0 combines, barrier + max-over-ranks timing, one JSON line from
-    rank 0 -- rehearsed with two processes on one GPU (--backend gloo), 8 slots.  A rehearsal of the
-    code path, not a measurement."""
+def _check_rehearsal_line(out):
     import json
-    out = _torchrun(2, ["bench.py", "--gpus", "2", "--backend", "gloo", "--steps", "1", "--warmup", "0", "--slots", "8",
-                        "--no-cpu-baseline"], 29643)
     assert out.returncode == 0, out.stdout[-1500:] + out.stderr[-3000:]
-    line = [l for l in out.stdout.splitlines() if l.startswith("{")][-1]
-    j = json.loads(line)
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    j = json.loads(lines[-1])
     assert j["n_gpus"] == 2 and j["scaling"] == "strong" and j["config"]["mode"] == "sharded"
     assert j["value"] > 0 and j["roofline"]["frac"] > 0
     # all ranks' rotations are counted: 8 slots of the reference's loop, one adder on rank 0, the comparator
@@ -414,3 +408,39 @@ def test_bench_multi_process_default_mode_rehearsal():
     assert w["n_gpus"] == 2 and w["matches_per_gpu"] == 8 and w["scaling"] == "weak"
     per_match = w["gates_per_s_all_ranks"] * w["seconds"] / 16
     assert 8 * 1683 <= per_match <= 8 * 1683 + 400, per_match
+    # the same match once more with SURVEY 8(e)'s combine on rank 0 (ripple-adder tree + bit-serial comparator)
+    r = j["reference_order_combine"]
+    assert r["match_ms"] > 0 and 8 * 1683 <= r["blind_rotates_all_ranks"] <= 8 * 1683 + 1000
+    # who took part: two ranks, each naming the device libtfhe-hip ran on; on the one GPU of a test box
+    # both name the same bus id and the line says so
+    d = j["dist"]
+    assert d["world"] == 2 and len(d["devices"]) == 2 and all(d["devices"]) and d["transport"] == "host"
+    assert d["distinct_devices"] == 1 and d["one_gpu_per_rank"] is False
+    assert d["status_word_collectives"] >= 3 and d["data_collectives"]["gathers"] >= 3       # 1 step + reference leg + match bits
+    assert [e["rank"] for e in d["ranks"]] == [0, 1] and d["ranks"][0]["pid"] != d["ranks"][1]["pid"]
+    return j
+
+
+def test_bench_multi_process_default_mode_rehearsal():
+    """What the driver's `bench.py --gpus N` runs at N > 1 -- mode auto = sharded: slots partitioned
+    over the ranks, one gather, rank 0 combines, barrier + max-over-ranks timing, one JSON line from
+    rank 0 -- rehearsed with two processes on one GPU (--backend gloo), 8 slots.  A rehearsal of the
+    code path, not a measurement."""
+    out = _torchrun(2, ["bench.py", "--gpus", "2", "--backend", "gloo", "--steps", "1", "--warmup", "0", "--slots", "8",
+                        "--no-cpu-baseline"], 29643)
+    _check_rehearsal_line(out)
+
+
+def test_bench_launches_its_own_ranks_when_called_without_a_launcher():
+    """`python bench.py --gpus 2` with no WORLD_SIZE in the environment -- how the driver calls it at
+    N = 1 -- must produce the N = 2 line by itself: the parent starts one fresh process per rank (it never touches the GPU),
+    relays rank 0's JSON line as its own last stdout line and exits 0."""
+    import subprocess
+    import sys
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env["PEBA1_ROOT"] = ROOT
+    out = subprocess.run([sys.executable, "bench.py", "--gpus", "2", "--backend", "gloo", "--steps", "1", "--warmup", "0",
+                          "--slots", "8", "--no-cpu-baseline"], env=env, capture_output=True, text=True, timeout=400, cwd=ROOT)
+    j = _check_rehearsal_line(out)
+    assert out.stdout.rstrip().splitlines()[-1].startswith("{")           # the line is the LAST thing on stdout
+    assert j["dist"]["torch_backend"] == "gloo"

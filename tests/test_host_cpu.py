@@ -159,10 +159,6 @@ def test_product_modswitch_helpers(oracle):
 def _declared_symbols(header):
     txt = open(os.path.join(ROOT, "include", header)).read()
     txt = re.sub(r"/\*.*?\*/", "", txt, flags=re.S)
-    # declarations of the experimental executors exist only under -DTFHE_HIP_EXPERIMENTAL (off in build.sh)
-    from peba1_amd import lib
-    if not lib.experimental():
-        txt = re.sub(r"#ifdef TFHE_HIP_EXPERIMENTAL.*?#endif", "", txt, flags=re.S)
     return set(re.findall(r"\b((?:boots|new_|delete_|export_|import_|tfhe_hip_|modSwitch|peba1_)\w*)\s*\(", txt))
 
 

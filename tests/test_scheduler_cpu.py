@@ -112,33 +112,3 @@ def test_small_flushes_keep_asap_levels():
     ops = [(2, 10, 0, 1, -1), (4, 11, 10, 1, -1), (NOT, 12, 11, -1, -1), (MUX, 13, 12, 0, 1)]
     d, lvl = schedule(ops, 256, True)
     assert d == 3 and list(lvl) == [1, 2, 2, 3]
-
-
-def test_lane_assignment_separates_the_critical_chain():
-    """Two-lane execution (experimental): a long dependent chain is the urgent lane 0, a crowd of
-    independent gates with slack the background lane 1; a NOT stays with the gate that feeds it."""
-    from peba1_amd import lib
-    if not lib.experimental():
-        pytest.skip("two-lane execution is built only with TFHE_HIP_DEFS=-DTFHE_HIP_EXPERIMENTAL")
-    ops, slot = [], 100
-    chain_idx, crowd_idx, not_idx = [], [], []
-    prev = 0
-    for _ in range(300):                                   # chain: 300 dependent gates
-        ops.append((4, slot, prev, 1, -1)); chain_idx.append(len(ops) - 1)
-        prev = slot; slot += 1
-    for k in range(3000):                                  # crowd: independent gates, used only at the very end
-        ops.append((2, slot, 2, 3, -1)); crowd_idx.append(len(ops) - 1)
-        if k % 100 == 0:
-            ops.append((NOT, slot + 1, slot, -1, -1)); not_idx.append((len(ops) - 1, len(ops) - 2))
-            slot += 1
-        slot += 1
-    ops.append((1, slot, prev, slot - 1, -1))              # joins chain and crowd
-    a = np.ascontiguousarray(np.array(ops, dtype=np.int32).reshape(-1, 5))
-    lanes = np.zeros(len(a), dtype=np.int32)
-    depth = lib.load().tfhe_hip_test_assign_lanes(a.ctypes.data_as(lib.I32P), len(a), 64, 8,
-                                                  lanes.ctypes.data_as(lib.I32P))
-    assert depth == 301
-    assert (lanes[chain_idx] == 0).all() and lanes[-1] == 0
-    assert (lanes[crowd_idx] == 1).mean() > 0.95            # all but the few needed right at the join
-    for n, g in not_idx:
-        assert lanes[n] == lanes[g]
