@@ -218,3 +218,31 @@ def test_libpeba1_dist_exports_every_declared_symbol():
     out = subprocess.check_output(["nm", "-D", "--defined-only", os.path.join(ROOT, "peba1_amd", "libpeba1-dist.so")]).decode()
     exported = {line.split()[-1] for line in out.splitlines() if line.strip()}
     assert len(declared) >= 12 and not (declared - exported), declared - exported
+
+
+def test_bench_launcher_parent_reports_failed_ranks_and_never_loads_the_gpu_library(built):
+    """`python bench.py --gpus 2` with no launcher starts its own ranks.  Here (no GPU) both ranks end in
+    libtfhe-hip's "no HIP device" abort: the parent must come back non-zero with no JSON line, and must itself never have
+    loaded the HIP library (a process that has touched the GPU may not start another one on this pool)."""
+    import subprocess
+    import sys
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    out = subprocess.run([sys.executable, "bench.py", "--gpus", "2", "--backend", "gloo", "--steps", "1", "--warmup", "0",
+                          "--slots", "2", "--no-cpu-baseline"], env=env, capture_output=True, text=True, timeout=300, cwd=ROOT)
+    assert out.returncode != 0
+    assert not [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert "no HIP device" in out.stderr
+    # the parent's own modules: import bench and run the launcher's argument handling in-process, then look at what is loaded
+    code = ("import sys, os; sys.argv = ['bench.py', '--gpus', '2']; sys.path.insert(0, %r)\n"
+            "import bench, subprocess\n"
+            "class P:\n"
+            "    stdout = iter(())\n"
+            "    def wait(self): return 7\n"
+            "subprocess.Popen = lambda *a, **k: P()\n"
+            "rc = bench.self_launch(2)\n"
+            "maps = open('/proc/self/maps').read()\n"
+            "assert rc == 7, rc\n"
+            "assert 'libtfhe-hip' not in maps and 'libamdhip64' not in maps and 'torch' not in sys.modules, 'the launcher touched the GPU stack'\n"
+            "print('PARENT-CLEAN')\n" % ROOT)
+    out = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=120, cwd=ROOT)
+    assert out.returncode == 0 and "PARENT-CLEAN" in out.stdout, out.stdout + out.stderr

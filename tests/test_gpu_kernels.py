@@ -142,17 +142,49 @@ def test_keyswitch_matches_oracle(p128_keys, oracle, ks_blocks):
         assert (got[c] == oks.keyswitch(u[c])).all(), f"sample {c}"
 
 
-@pytest.mark.parametrize("tile,count", [(16, 32), (16, 45), (24, 48), (24, 61), (32, 64), (32, 77)])
-def test_tiled_keyswitch_matches_oracle(p128_keys, oracle, tile, count):
-    """a17, wide launches: one pass over a range's KSK rows serves a tile of gates; full and
-    ragged last tiles, all-zero and all-three digits, against the oracle and the per-gate kernel."""
+@pytest.fixture(scope="module")
+def keys_by_set(oracle, p128_keys):
+    """(parameter set, product keys on the device, oracle keys) of P128 (the session's), P80 and P2048, made on first use."""
     from peba1_amd import api
-    pp, ks, oks = p128_keys
-    rng = np.random.default_rng(1000 + count)
-    u = rng.integers(-2**31, 2**31, (count, pp.N + 1), dtype=np.int64).astype(np.int32)
+    made = {"P128": p128_keys}
+    own = []
+
+    def get(pname):
+        if pname not in made:
+            seed = {"P80": 0x80, "P2048": 0x2048}[pname]
+            pp = api.ParameterSet(80) if pname == "P80" else api.ParameterSet(p2048=True)
+            ks = api.SecretKeySet(pp, seed, device=True)
+            own.append(ks)
+            made[pname] = (pp, ks, oracle.KeySet(oracle.params(pname), seed))
+        return made[pname]
+    yield get
+    for ks in own:
+        ks.close()
+
+
+def _oracle_rows(fn, rows):
+    """fn over the rows on the host's threads (ctypes releases the GIL; the oracle is re-entrant)"""
+    from concurrent.futures import ThreadPoolExecutor
+    with ThreadPoolExecutor(min(16, os.cpu_count() or 4)) as ex:
+        return np.stack(list(ex.map(fn, rows)))
+
+
+@pytest.mark.parametrize("pname,tile,count", [("P128", 16, 32), ("P128", 16, 45), ("P128", 24, 48), ("P128", 24, 61), ("P128", 32, 64),
+                                              ("P128", 32, 77), ("P80", 16, 45), ("P80", 24, 61), ("P80", 32, 77),
+                                              ("P2048", 16, 45), ("P2048", 24, 61), ("P2048", 32, 77)])
+def test_tiled_keyswitch_matches_oracle(keys_by_set, oracle, pname, tile, count):
+    """a17, wide launches: one pass over a range's KSK rows serves a tile of gates; full and ragged last tiles, all-zero and
+    all-three digits.  EVERY row of every form against the oracle, for the three parameter sets -- the
+    index form of the key switch has one instantiation per row width (128, 192, 320 threads: P80, P128, P2048) and tile
+    (16, 24, 32), and names physical registers: all nine are launched here on random words."""
+    from peba1_amd import api
+    pp, ks, oks = keys_by_set(pname)
+    rng = np.random.default_rng(1000 + count + pp.n)
+    u = rng.integers(-2**31, 2**31, (count, pp.k * pp.N + 1), dtype=np.int64).astype(np.int32)
     u[0, :] = 0
     u[1, :-1] = -1
     u[count - 1, :-1] = 0x40000000   # digit 1 at the first position only
+    want = _oracle_rows(oks.keyswitch, u)
     api.set_tuning("ks_tile", tile)
     api.set_tuning("ks_pipe", 0)                 # the round-2 form first: sixteen reads, one wait
     narrow_default, pipe_default, branch_default = 0, 1, 2
@@ -161,12 +193,12 @@ def test_tiled_keyswitch_matches_oracle(p128_keys, oracle, tile, count):
         forms = {}
         for narrow in (0, 1):                    # a thread per 4 words of the row (default) / per 2 words (round 4, selectable)
             api.set_tuning("ks_narrow", narrow)
-            forms[narrow, 0] = api.kernel_keyswitch(ks, u)
+            forms["strips", narrow, 0] = api.kernel_keyswitch(ks, u)
             api.set_tuning("ks_atomic", 1)       # ranges accumulate in place: no partial sums, no reduce launch
-            forms[narrow, 1] = api.kernel_keyswitch(ks, u)
+            forms["strips", narrow, 1] = api.kernel_keyswitch(ks, u)
             api.set_tuning("ks_atomic", 0)
-        got, in_place = forms[0, 0], forms[0, 1]
-        api.set_tuning("ks_pipe", 1)             # strip reads a pair of gates ahead of the subtractions (tile 16; the default)
+        api.set_tuning("ks_narrow", 0)
+        api.set_tuning("ks_pipe", 1)             # strip reads a pair of gates ahead of the subtractions (tile 16)
         forms["pipe", 0] = api.kernel_keyswitch(ks, u)
         api.set_tuning("ks_atomic", 1)
         forms["pipe", 1] = api.kernel_keyswitch(ks, u)
@@ -174,39 +206,79 @@ def test_tiled_keyswitch_matches_oracle(p128_keys, oracle, tile, count):
         api.set_tuning("ks_pipe", 0)
         api.set_tuning("ks_branch", 1)           # rows in registers, picked by scalar branches on the digit
         forms["branch"] = api.kernel_keyswitch(ks, u)
-        api.set_tuning("ks_branch", 2)           # rows in pinned registers, picked through the VGPR index mode (tile 16)
+        api.set_tuning("ks_branch", 2)           # rows in pinned registers, picked through the VGPR index mode: the default
         forms["index"] = api.kernel_keyswitch(ks, u)
         api.set_tuning("ks_branch", 0)
         api.set_tuning("ks_tile", 0)
         api.set_tuning("ks_atomic", 1)
-        per_gate_in_place = api.kernel_keyswitch(ks, u)
+        forms["per gate, in place"] = api.kernel_keyswitch(ks, u)
         api.set_tuning("ks_atomic", 0)
-        per_gate = api.kernel_keyswitch(ks, u)
+        forms["per gate"] = api.kernel_keyswitch(ks, u)
     finally:
         api.set_tuning("ks_tile", 16)
         api.set_tuning("ks_atomic", 0)
         api.set_tuning("ks_narrow", narrow_default)
         api.set_tuning("ks_pipe", pipe_default)
         api.set_tuning("ks_branch", branch_default)
-    assert (got == per_gate).all() and (in_place == per_gate).all() and (per_gate_in_place == per_gate).all()
-    assert (forms["branch"] == per_gate).all() and (forms["index"] == per_gate).all()
-    assert (forms[1, 0] == per_gate).all() and (forms[1, 1] == per_gate).all()
-    assert (forms["pipe", 0] == per_gate).all() and (forms["pipe", 1] == per_gate).all()
-    for c in list(range(4)) + [count // 2, count - 2, count - 1]:
-        assert (got[c] == oks.keyswitch(u[c])).all(), f"sample {c}"
+    for name, got in forms.items():
+        bad = np.argwhere((got != want).any(axis=1)).ravel()
+        assert bad.size == 0, f"{pname} tile {tile}, form {name}: rows {bad[:8]} differ from the oracle"
+
+
+@pytest.mark.parametrize("pname,rotations,switches", [("P128", 512, 1024), ("P80", 256, 1024), ("P2048", 64, 256)])
+def test_random_input_parity_soak_in_every_launch_form(keys_by_set, oracle, pname, rotations, switches):
+    """SURVEY section 4 tier 4 inside the driver-run suite (the long form is tools/parity_soak.py ->
+    profiles/): uniformly random LWE inputs rotated in each of the five launch forms a default build can take -- the wide
+    launch with and without its tail round on the 8-wave form, launches of 256 (the 8-wave form at N = 1024), the 4-wave
+    form without digit tables, the split form -- and EVERY word of every extracted sample (a signed permutation of the
+    whole accumulator) compared with the oracle, whose exact product runs over one 64-bit prime: arithmetic independent of
+    the kernels' two 27-bit primes + signed CRT.  The circuit digests see a rotation only through later gates' modulus
+    switches, which hide low bits; this does not.  Then random extracted samples through the default key switch (pinned
+    registers, VGPR index mode) at tiles 16 / 24 / 32 and through the scalar-branch and LDS-strip forms."""
+    from peba1_amd import api
+    pp, ks, oks = keys_by_set(pname)
+    rng = np.random.default_rng(pp.N + rotations)
+    lin = rng.integers(-2**31, 2**31, (rotations, pp.words), dtype=np.int64).astype(np.int32)
+    want = _oracle_rows(oks.bootstrap_woks, lin)
+    defaults = {"br_tail8": 1, "br_variant": -1, "br_digit_table": 1, "br8_max_rotations": 1 << 30}
+    wide = rotations if pp.N == 2048 else max(rotations, 600)      # N = 1024: 600 > 2 x 256 CUs, so the wide launch has a tail round
+    pad = np.concatenate([lin, lin[:wide - rotations]]) if wide > rotations else lin
+    forms = [("default wide launch", {}, pad, wide),
+             ("one launch per level (br_tail8 = 0)", {"br_tail8": 0}, pad, wide),
+             ("launches of at most 256", {}, lin, 256),
+             ("4-wave form, no digit table", {"br_variant": 0, "br_digit_table": 0, "br8_max_rotations": 0}, lin, rotations),
+             ("split form", {"br_variant": 2}, lin, rotations)]
+    try:
+        for label, tunings, inputs, chunk in forms:
+            for k, v in tunings.items():
+                api.set_tuning(k, v)
+            got = np.concatenate([api.kernel_bootstrap_woks(ks, inputs[i:i + chunk]) for i in range(0, len(inputs), chunk)])[:rotations]
+            bad = np.argwhere((got != want).any(axis=1)).ravel()
+            assert bad.size == 0, f"{pname}, {label}: rotations {bad[:8]} differ from the oracle"
+            for k in tunings:
+                api.set_tuning(k, defaults[k])
+    finally:
+        for k, v in defaults.items():
+            api.set_tuning(k, v)
+    u = rng.integers(-2**31, 2**31, (switches, pp.k * pp.N + 1), dtype=np.int64).astype(np.int32)
+    want_ks = _oracle_rows(oks.keyswitch, u)
+    try:
+        for tile, branch in ((16, 2), (24, 2), (32, 2), (16, 1), (16, 0)):
+            api.set_tuning("ks_tile", tile)
+            api.set_tuning("ks_branch", branch)
+            got = api.kernel_keyswitch(ks, u)
+            bad = np.argwhere((got != want_ks).any(axis=1)).ravel()
+            assert bad.size == 0, f"{pname}, key switch tile {tile} register form {branch}: rows {bad[:8]} differ from the oracle"
+    finally:
+        api.set_tuning("ks_tile", 16)
+        api.set_tuning("ks_branch", 2)
 
 
 # ---------------------------------------------------------------- BASELINE configs[4]: N = 2048
 @pytest.fixture(scope="module")
-def p2048_keys(oracle):
-    """High-security set (N=2048, Bg=2^6, l=3; n=1024, ks 8x2 bit fixed by this repo)."""
-    from peba1_amd import api
-    seed = 0x2048
-    pp = api.ParameterSet(p2048=True)
-    ks = api.SecretKeySet(pp, seed, device=True)
-    oks = oracle.KeySet(oracle.params("P2048"), seed)
-    yield pp, ks, oks
-    ks.close()
+def p2048_keys(keys_by_set):
+    """High-security set (N=2048, Bg=2^6, l=3; n=1024, ks 8x2 bit fixed by this repo): one keyset per module."""
+    return keys_by_set("P2048")
 
 
 def test_p2048_negacyclic_and_gates(p2048_keys, oracle):

@@ -339,6 +339,41 @@ def test_index_keyswitch_statements_are_current_and_fit_their_registers(kernels_
             assert not copies, copies[:3]
 
 
+def test_isa_mix_summary_is_what_the_built_kernels_give(kernels_isa, tmp_path):
+    """profiles/isa_mix.json (the static VALU instruction mix of one blind-rotate step, which bench.py prices into
+    `roofline.valu_issue`) is what tools/isa_mix.py finds in the assembly of THIS build, under the hash of everything the
+    kernels are built from; and the step of the headline kernel is the one the SQ counters measured (1,719 VALU
+    instructions per wave and step, profiles/r04_set_profile_P128.json: the static count of the feasible path must be
+    within a few instructions of any such measurement, whichever round it is from)."""
+    import importlib.util
+    import json
+    from peba1_amd.kernel_id import KERNEL_FILES, kernels_sha16
+    spec = importlib.util.spec_from_file_location("isa_mix", os.path.join(ROOT, "tools", "isa_mix.py"))
+    mix = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mix)
+    with open(os.path.join(ROOT, "profiles", "isa_mix.json")) as f:
+        committed = json.load(f)
+    assert committed["kernels_sha16"] == kernels_sha16(), "profiles/isa_mix.json is stale: run __graft_entry__.build()"
+    lines = kernels_isa.split("\n")
+    for needle, (report, _what, _roles) in mix.KERNELS.items():
+        now = mix.analyse(lines, needle, 2 if report.endswith("false>") else 3)
+        assert json.loads(json.dumps(now)) == committed["kernels"][report], report
+    head = committed["kernels"]["blind_rotate4_kernel<10,0,true>"]["roles"]
+    assert len(head) == 1 and len(head[0]["variants"]) == 1          # q = 0 and q = 1 run the same counts
+    v = head[0]["variants"][0]
+    assert v["barriers"] == 3 and v["mul"] + v["three_operand"] + v["two_operand"] == v["valu"]
+    assert 1500 < v["valu"] < 1800 and v["mul"] >= 11 * 16 * 4 * 3 // 4      # >= the radix-4 steps' multiplies of 3 + 1 transforms
+    a, b = [r["variants"][0] for r in committed["kernels"]["blind_rotate8_kernel<10,true>"]["roles"]]
+    assert a["valu"] - b["valu"] == pytest.approx(380, abs=40)      # wave A transforms one gadget row more than wave B at l = 3
+    # the hash covers the generated key-switch statements, the form table and the flags (ADVICE r4)
+    assert {"ks_index_asm.inc", "kernels.hpp", "br_forms.hpp", "build.sh"} <= set(KERNEL_FILES)
+    import bench
+    assert bench.kernel_source_hash() == kernels_sha16()
+    blk = bench.valu_issue_block({"P128": {"ms_blind_rotate": 36.77, "shader_clock_ghz": 2.369}}, None)
+    assert blk["kernels_sha16"] == kernels_sha16() and 0.8 < blk["frac"] < 1.0          # round-4 launch time: ~0.88
+    assert blk["model_cycles_per_simd_step"] == pytest.approx(2 * (v["mul"] * 5.4 + v["three_operand"] * 5.2 + v["two_operand"] * 3.0))
+
+
 def test_parity_kit_files_are_what_the_oracle_produces():
     """tests/golden/parity_kit: the committed raw-word fixtures are exactly what make_kit.py
     regenerates from the oracle (schoolbook and two-prime evaluators agree inside it), and the product's seeded key
