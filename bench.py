@@ -283,6 +283,60 @@ def self_launch(n):
     return rc
 
 
+def make_comm(pd, api, dist, torch, pp, args, xdev, rank, world):
+    """The communicator of the exchange, agreed on by every rank.  --transport auto (default): libpeba1-dist's own RCCL
+    communicator, the collectives enqueued on the library's stream ("cuda"); made, then tried with ONE one-sample gather
+    before anything is timed.  If any rank cannot make it or the trial fails (the ranks agree through the torch group),
+    every rank falls back to the host transport of the same C library carried by torch's own RCCL communicator
+    ("torch-cuda": device tensors through torch.distributed) -- slower per exchange (a host wait, two copies), the same
+    ciphertexts -- and the line says which one ran (`dist.transport`).  A first contact with an 8-GPU node must produce a
+    measurement either way.  gloo rehearsals use the host transport on host tensors ("cpu")."""
+    if xdev == "cpu" and args.transport != "torch":
+        return pd.Comm(dist, torch, "cpu"), "host callbacks over torch.distributed (gloo)", None
+
+    def attempt(kind):
+        comm, why = None, None
+        try:
+            comm = pd.Comm(dist, torch, kind)
+            comm.set_timeout(120)                               # a trial that hangs ends the job with a message, soon
+            mine = api.CiphertextArray(pp, 1)
+            everyone = api.CiphertextArray(pp, world) if rank == 0 else None
+            pd.gather_samples(comm, everyone.ptr if rank == 0 else None, mine.ptr, 1, pp.ptr)
+            api.wait()
+            if rank == 0:
+                assert (everyone.words() == mine.words()[0]).all(), "the trial gather moved the wrong words"
+            comm.set_timeout(float(os.environ.get("PEBA1_DIST_TIMEOUT_S", "600")))
+        except Exception as e:                                  # noqa: BLE001 -- any failure of the trial means "not this transport"
+            why = f"rank {rank}: {type(e).__name__}: {e}"
+        ok = torch.tensor([0 if why else 1], dtype=torch.int32, device="cuda")
+        dist.all_reduce(ok, op=dist.ReduceOp.MIN)
+        if int(ok.item()) == 1:
+            return comm, None
+        reasons = [None] * world
+        dist.all_gather_object(reasons, why)
+        if comm is not None:
+            try:
+                comm.close()
+            except Exception:                                   # noqa: BLE001
+                pass
+        return None, "; ".join(r for r in reasons if r) or "a rank reported failure"
+    if args.transport in ("auto", "rccl"):
+        comm, why = attempt("cuda")
+        if comm is not None:
+            return comm, "rccl: libpeba1-dist's own communicator, collectives on the library's stream", None
+        if args.transport == "rccl":
+            raise SystemExit(f"--transport rccl: {why}")
+        if rank == 0:
+            print(f"bench.py: libpeba1-dist's own RCCL communicator is not usable here ({why}); falling back to torch's", file=sys.stderr)
+        fallback_reason = why
+    else:
+        fallback_reason = "--transport torch"
+    comm, why = attempt("torch-cuda")
+    if comm is None:
+        raise SystemExit(f"no usable transport: {why}")
+    return comm, "torch.distributed device tensors (torch's RCCL communicator) behind libpeba1-dist's host transport", fallback_reason
+
+
 def dist_evidence(dist, L, comm, args, world, rank, local_rank):
     """Who took part: every rank's PCI bus id as libtfhe-hip reports it for the device it runs on (all-gathered), the RCCL
     version libpeba1-dist opened, what the communicator has done.  N ranks on N distinct bus ids = N GPUs."""
@@ -304,7 +358,7 @@ def dist_evidence(dist, L, comm, args, world, rank, local_rank):
             "rccl_version": pd.load().peba1_dist_rccl_version() if args.backend == "nccl" else None,
             "devices": ids, "distinct_devices": len(set(ids)), "one_gpu_per_rank": len(set(ids)) == world,
             "status_word_collectives": c0.get("status_word_exchanges"), "data_collectives": {k: c0.get(k) for k in ("gathers", "broadcasts")},
-            "transport": c0.get("transport"), "ranks": everyone}
+            "library_transport": c0.get("transport"), "ranks": everyone}
 
 
 def main():
@@ -340,6 +394,10 @@ def main():
                          "matches, 256-slot match, Hamming, optimised DAG); 0 = skip")
     ap.add_argument("--force-dist", action="store_true",
                     help="initialise the RCCL process group even at world size 1 (exercises the N>1 code path)")
+    ap.add_argument("--transport", choices=["auto", "rccl", "torch"], default="auto",
+                    help="--backend nccl: auto (default) = libpeba1-dist's own RCCL communicator with its collectives on the "
+                         "library's stream, tried once before the timed steps, else torch's communicator behind the library's "
+                         "host transport; rccl / torch force one")
     ap.add_argument("--backend", choices=["nccl", "gloo"], default="nccl",
                     help="nccl (= RCCL, one GPU per rank; the default and what the driver runs) or gloo: the exchange "
                          "goes through host buffers and every rank uses GPU `LOCAL_RANK mod device count`, so the N>1 "
@@ -414,11 +472,11 @@ def main():
     api.set_tuning("eliminate_dead", 0)     # likewise: gates whose result nothing can observe are executed too
 
     checked = None          # what the in-run check of the timed work was
-    comm = None
+    comm, transport, transport_fallback = None, None, None
     if mode == "match":
         tmpl_vals = base if rank == 0 else identify.synthetic_template(base, rank)
         tmpl = circuits.EncryptedVector(pp, tmpl_vals, bitsize, ks).to_device()
-        comm = pd.Comm(dist, torch, xdev) if use_dist else None
+        comm, transport, transport_fallback = make_comm(pd, api, dist, torch, pp, args, xdev, rank, world) if use_dist else (None, None, None)
         all_bits = api.CiphertextArray(pp, world) if use_dist and rank == 0 else None
 
         def step():
@@ -458,7 +516,7 @@ def main():
         tmpl = circuits.EncryptedVector(pp, tmpl_vals, bitsize, ks).to_device()
         S = [a.ptr for a in probe.slots]
         T = [a.ptr for a in tmpl.slots]
-        comm = pd.Comm(dist, torch, xdev) if use_dist else None
+        comm, transport, transport_fallback = make_comm(pd, api, dist, torch, pp, args, xdev, rank, world) if use_dist else (None, None, None)
         phase_ms = {"ranks": [], "combine": []}
 
         def step():
@@ -582,6 +640,9 @@ def main():
                            "checked": "decrypted match bit == plaintext rule"}
 
     evidence = dist_evidence(dist, L, comm, args, world, rank, local_rank) if use_dist else None
+    if evidence is not None:
+        evidence["transport"] = transport
+        evidence["transport_fallback_reason"] = transport_fallback
 
     if rank == 0:
         a_br, a_ks, ct = algorithmic_bytes(pp)

@@ -129,25 +129,39 @@ class Comm:
     (device="cpu": the group's gather, through host tensors, is the library's callback)."""
 
     def __init__(self, dist, torch, device="cuda"):
+        """device: "cuda" = libpeba1-dist's own RCCL communicator (one GPU per rank, a torch.distributed group of any backend
+        carries the 128-byte unique id); "cpu" = host transport, the group's collectives on host tensors (gloo);
+        "torch-cuda" = host transport, the group's collectives on DEVICE tensors (a "nccl" group cannot move host tensors):
+        the exchange then runs over torch's own RCCL communicator -- the fallback bench.py takes when the library's own
+        communicator cannot be made."""
         D = load()
         self.rank, self.world = dist.get_rank(), dist.get_world_size()
         self._keep = None
+        self.transport = device
         if device == "cuda":
             ident = [None]
             if self.rank == 0:
                 buf = C.create_string_buffer(128)
-                _check(D.peba1_dist_unique_id(buf), "peba1_dist_unique_id")
-                ident[0] = buf.raw
+                # (a failure here must still reach the broadcast below, or the other ranks wait in it for ever)
+                ident[0] = buf.raw if D.peba1_dist_unique_id(buf) == 0 else ("error", D.peba1_dist_last_error().decode())
             dist.broadcast_object_list(ident, src=0)
+            if not isinstance(ident[0], bytes):
+                raise RuntimeError("cannot create the communicator: rank 0 has no RCCL unique id: " + str(ident[0]))
             self.ptr = D.peba1_dist_init_rccl(ident[0], self.world, self.rank)
         else:
+            stage = (lambda t: t.cuda()) if device == "torch-cuda" else (lambda t: t)
+
             def gather(_ctx, send, recv, nbytes, root):
                 try:
-                    mine = torch.from_numpy(np.ctypeslib.as_array(C.cast(send, C.POINTER(C.c_uint8)), shape=(nbytes,)).copy())
-                    out = [torch.empty_like(mine) for _ in range(self.world)] if self.rank == root else None
-                    dist.gather(mine, out, dst=root)
+                    mine = stage(torch.from_numpy(np.ctypeslib.as_array(C.cast(send, C.POINTER(C.c_uint8)), shape=(nbytes,)).copy()))
+                    if device == "torch-cuda":          # all_gather: the one collective every backend has on device tensors
+                        out = [torch.empty_like(mine) for _ in range(self.world)]
+                        dist.all_gather(out, mine)
+                    else:
+                        out = [torch.empty_like(mine) for _ in range(self.world)] if self.rank == root else None
+                        dist.gather(mine, out, dst=root)
                     if self.rank == root:
-                        whole = torch.cat(out).contiguous().numpy()          # named: must outlive the copy below
+                        whole = torch.cat(out).contiguous().cpu().numpy()    # named: must outlive the copy below
                         C.memmove(recv, whole.ctypes.data, nbytes * self.world)
                     return 0
                 except Exception:      # never unwind through the C frame
@@ -155,10 +169,10 @@ class Comm:
             def bcast(_ctx, buf, nbytes, root):
                 try:
                     view = np.ctypeslib.as_array(C.cast(buf, C.POINTER(C.c_uint8)), shape=(nbytes,))
-                    t = torch.from_numpy(view.copy())
+                    t = stage(torch.from_numpy(view.copy()))
                     dist.broadcast(t, src=root)
                     if self.rank != root:
-                        whole = t.contiguous().numpy()
+                        whole = t.contiguous().cpu().numpy()
                         C.memmove(buf, whole.ctypes.data, nbytes)
                     return 0
                 except Exception:      # never unwind through the C frame

@@ -392,7 +392,7 @@ def test_sharded_match_in_two_processes_reproduces_the_oracle_digest(tmp_path):
     assert out.returncode == 0 and "TWO-PROCESS-OK" in out.stdout, out.stdout[-1500:] + out.stderr[-3000:]
 
 
-def _check_rehearsal_line(out):
+def _check_rehearsal_line(out, transport="gloo"):
     import json
     assert out.returncode == 0, out.stdout[-1500:] + out.stderr[-3000:]
     lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
@@ -414,7 +414,7 @@ def _check_rehearsal_line(out):
     # who took part: two ranks, each naming the device libtfhe-hip ran on; on the one GPU of a test box
     # both name the same bus id and the line says so
     d = j["dist"]
-    assert d["world"] == 2 and len(d["devices"]) == 2 and all(d["devices"]) and d["transport"] == "host"
+    assert d["world"] == 2 and len(d["devices"]) == 2 and all(d["devices"]) and d["library_transport"] == "host" and transport in d["transport"]
     assert d["distinct_devices"] == 1 and d["one_gpu_per_rank"] is False
     assert d["status_word_collectives"] >= 3 and d["data_collectives"]["gathers"] >= 3       # 1 step + reference leg + match bits
     assert [e["rank"] for e in d["ranks"]] == [0, 1] and d["ranks"][0]["pid"] != d["ranks"][1]["pid"]
@@ -429,6 +429,17 @@ def test_bench_multi_process_default_mode_rehearsal():
     out = _torchrun(2, ["bench.py", "--gpus", "2", "--backend", "gloo", "--steps", "1", "--warmup", "0", "--slots", "8",
                         "--no-cpu-baseline"], 29643)
     _check_rehearsal_line(out)
+
+
+def test_bench_fallback_transport_moves_the_same_ciphertexts():
+    """The transport bench.py falls back to when libpeba1-dist's own RCCL communicator cannot be made on a node (first
+    contact with several GPUs happens in the driver's run, not here): the library's host transport carried by the torch
+    group's collectives on DEVICE tensors.  Rehearsed over gloo (two ranks cannot share one GPU under RCCL); the same checks
+    as the default rehearsal -- match bit, rotation counts, gathered match bits, both combines."""
+    out = _torchrun(2, ["bench.py", "--gpus", "2", "--backend", "gloo", "--transport", "torch", "--steps", "1", "--warmup", "0",
+                        "--slots", "8", "--no-cpu-baseline"], 29645)
+    j = _check_rehearsal_line(out, transport="torch.distributed device tensors")
+    assert j["dist"]["transport_fallback_reason"] == "--transport torch"
 
 
 def test_bench_launches_its_own_ranks_when_called_without_a_launcher():
