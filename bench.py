@@ -86,18 +86,22 @@ def committed_counters():
 
 def committed_set_profile(name):
     """The rocprofv3 summary of 4,096 independent gates under parameter set `name` (tools/gpu_profile_sets.sh ->
-    profiles/r04_set_profile_<name>.json): HBM-side traffic, VALU share, wave-cycle shares.  Quoted only while it was
+    profiles/r05_set_profile_<name>.json): HBM-side traffic, VALU share, wave-cycle shares.  Quoted only while it was
     measured on exactly the kernel sources running now."""
-    path = os.path.join(ROOT, "profiles", f"r04_set_profile_{name}.json")
-    if not os.path.exists(path):
-        return None
-    with open(path) as f:
-        j = json.load(f)
-    if j.get("kernels_sha16") != kernel_source_hash():
+    j = None
+    for rnd in ("r05", "r04"):                       # the newest summary measured on the kernels running now
+        path = os.path.join(ROOT, "profiles", f"{rnd}_set_profile_{name}.json")
+        if os.path.exists(path):
+            with open(path) as f:
+                cand = json.load(f)
+            if cand.get("kernels_sha16") == kernel_source_hash():
+                j = dict(cand, source_file=f"profiles/{rnd}_set_profile_{name}.json")
+                break
+    if j is None:
         return None
     keep = ("kernel", "avg_launch_ms", "hbm_bytes_per_launch", "hbm_side_GBps", "hbm_side_frac_of_8TBps", "traffic_over_algorithmic",
             "valu_insts_per_wave_step", "valu_busy_frac", "wave_cycles_issuing", "wave_cycles_issue_stalled", "wave_cycles_parked",
-            "wave_cycles_lds_issue_stalled", "lds_conflict_share_of_active", "kernels_sha16")
+            "wave_cycles_lds_issue_stalled", "lds_conflict_share_of_active", "kernels_sha16", "source_file")
     return {k: j[k] for k in keep if k in j}
 
 

@@ -497,12 +497,6 @@ __device__ unsigned long long g_stamps[4][8];
 // a transform runs; from the end of its inverse transform to the step's last barrier it carries the residues of the
 // half its CRT partner recombines -- nobody else touches it in between) and the partial sums it sends to the wave of
 // the other input polynomial.  MERGED_BUFFERS: both are one buffer (one more barrier per step, blind_rotate4_body).
-// BR4_PAIR_SYNC=1 (measurement build, round 5): the barrier in front of the CRT orders only the two
-// waves (0, u) and (1, u) that swap residues -- replace the 4-wave s_barrier there by a step counter in LDS that each
-// of the two publishes after its stores and polls on its partner.  Measured: see DESIGN.md section 5.
-#ifndef BR4_PAIR_SYNC
-#define BR4_PAIR_SYNC 0
-#endif
 template <int LOGN, int V = 0>
 struct Br4Lds {
     using NTT = WaveNtt<LOGN>;
@@ -517,9 +511,6 @@ struct Br4Lds {
     // twiddles (one per lane)
     uint4 ft1[LTW ? 2 : 1][LTW ? (64 >> NTT::LC) : 1][NTT::FwdTw1::IMAGE16];
     uint4 ft2[LTW ? 2 : 1][LTW ? 64 : 1][NTT::FwdTw2::IMAGE16];
-#if BR4_PAIR_SYNC
-    uint32_t flag[4];                              // experiment (round 5): step counters of the pairwise CRT hand-off
-#endif
     __device__ __forceinline__ uint32_t *scr(int wv) { return buf0[wv]; }
     __device__ __forceinline__ uint32_t *x1(int wv) { return MERGED ? buf0[wv] : buf1[wv]; }
     __device__ __forceinline__ uint32_t *x2(int wv) { return buf0[wv]; }
@@ -545,9 +536,6 @@ __device__ __forceinline__ void blind_rotate4_body(const DevParams &p, const Dev
     const int n = p.n;
 
     prelude_modswitch<LOGN, 256>(p, rd, pool, sh.bar, tid);
-#if BR4_PAIR_SYNC
-    if (tid < 4) sh.flag[tid] = 0u;
-#endif
     if constexpr (TAB) {
         // the two waves of prime q (tid bits 6 and 7 = q and u) fill that prime's table
         NTT::build_digit_table(sh.dtab[q], c, p.Bgbit, (u << 6) | lane, 128);
@@ -632,37 +620,23 @@ __device__ __forceinline__ void blind_rotate4_body(const DevParams &p, const Dev
         NTT::template inverse<TR::EARLY_TW>(t, c, scr, lane, t2);  // signed residues, |t| < P: recombined as they are
         STAMP(4);
 
-#if BR4_PAIR_SYNC
-        // publish "my residues of step i are in LDS" (LDS executes a wave's operations in order: the counter lands behind
-        // the stores), then wait for the partner's counter.  The step's last barrier (all four waves) separates this
-        // step's counters from the next step's, and keeps every other buffer's hazards as they were.
-#define CRT_HANDOFF(tag)                                                                                     \
-        do {                                                                                                  \
-            typedef __attribute__((address_space(3))) uint32_t lds_u32;     /* LDS accesses, not flat ones */    \
-            volatile lds_u32 *fl = (volatile lds_u32 *)sh.flag;                                               \
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");                                            \
-            if (lane == 0) fl[wv] = (uint32_t)(i + 1);                                                        \
-            while (__builtin_amdgcn_readfirstlane((int)fl[wv ^ 1]) != i + 1) {}                               \
-            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");                                            \
-            asm volatile("; isa_mix role " tag ::: "memory");                                                 \
-        } while (0)
-#else
-#define CRT_HANDOFF(tag) LDS_BARRIER_ROLE(tag)
-#endif
         // CRT of output poly u is split with wave (1-q,u): wave q recombines registers [q*HALF, (q+1)*HALF)
+        // (the barrier in front of it orders only that pair; a pairwise hand-off through an LDS step counter instead of the
+        // 4-wave s_barrier was built and measured in round 5: 38.11 against 38.14 ms per 4,096 rotations -- nothing;
+        // profiles/r05_ab_kernel_variants.txt)
         const uint32_t *ox = sh.x2(wv ^ 1);
         uint32_t *mx = sh.x2(wv);
         if (q == 0) {                                    // (two copies: register indices must be compile-time constants)
 #pragma unroll
             for (int r = 0; r < HALF; ++r) mx[r * 64 + lane] = (uint32_t)t[HALF + r];
-            CRT_HANDOFF("q=0");
+            LDS_BARRIER_ROLE("q=0");
 #pragma unroll
             for (int r = 0; r < HALF; ++r)
                 sh.acc.set(u, r * 64 + lane, sh.acc.get(u, r * 64 + lane) + crt_signed_to_torus(t[r], (int32_t)ox[r * 64 + lane]));
         } else {
 #pragma unroll
             for (int r = 0; r < HALF; ++r) mx[r * 64 + lane] = (uint32_t)t[r];
-            CRT_HANDOFF("q=1");
+            LDS_BARRIER_ROLE("q=1");
 #pragma unroll
             for (int r = 0; r < HALF; ++r)
                 sh.acc.set(u, (HALF + r) * 64 + lane,
