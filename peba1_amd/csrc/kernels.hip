@@ -740,7 +740,6 @@ struct Br8Lds {
     // per prime: LDS copies of the forward transforms' second- and third-pass twiddles (as in Br4Lds)
     uint4 ft1[2][64 >> NTT::LC][NTT::FwdTw1::IMAGE16];
     uint4 ft2[2][64][NTT::FwdTw2::IMAGE16];
-    uint32_t handoff[4];                           // per (q, u): step counter of wave A's hand-off to wave B (shared middle row)
 };
 
 template <int LOGN, bool TAB>
@@ -767,7 +766,6 @@ __global__ __launch_bounds__(512, 2) void blind_rotate8_kernel(
     clk.begin(p);
 
     prelude_modswitch<LOGN, 512>(p, rd, pool, sh.bar, tid);
-    if (tid < 4) sh.handoff[tid] = 0u;
     if constexpr (TAB) {
         // the four waves of prime q fill that prime's table
         NTT::build_digit_table(sh.dtab[q], c, p.Bgbit, ((wv >> 1) << 6) | lane, 256);
@@ -794,24 +792,12 @@ __global__ __launch_bounds__(512, 2) void blind_rotate8_kernel(
     }
     __syncthreads();
 
-    // Which gadget rows a wave transforms.  Round 5: rows [0, l/2) go to wave A and rows [(l+1)/2, l) to
-    // wave B; for odd l the middle row is SHARED -- A runs the first pass of its transform (digits, table step, the rest of
-    // the first pass: a third of a row) FIRST in the step and scatters the result into B's own-output row buffer, which B
-    // writes only at the end of its forward phase; B, after its own rows, picks the rows up there, runs the second and third
-    // pass and multiplies into its sums.  The transpose between the passes goes through LDS in any case, only its reader
-    // changes.  At l = 3 wave A then issues 543 and wave B 667 vector instructions in the forward phase where rows 0..l-2
-    // against the last row were 795 against 415 -- and whatever one wave of a SIMD runs alone, it runs at the lone-wave
-    // issue rate (v_mad_i64_i32: 10-11 cycles against 5.9 shared, profiles/valu_issue_costs.json).  BR8_HANDOFF=0 builds
-    // the round-3 assignment for A/B measurements.  Same integers either way: a sum of the same products.
-#ifndef BR8_HANDOFF
-#define BR8_HANDOFF 1
-#endif
-    const int l = p.l;
-#if BR8_HANDOFF
-    const int a_end = l >> 1, b_begin = (l + 1) >> 1, mid = (l & 1) ? (l >> 1) : -1;
-#else
-    const int a_end = l - 1, b_begin = l - 1, mid = -1;
-#endif
+    // (Round 5 built the balanced assignment -- rows [0, l/2) to A, [(l+1)/2, l) to B, the middle row of an odd l shared: A its
+    // transform's first pass, B the rest, 940 / 1,010 vector instructions per step instead of 1,144 / 764 -- and measured it
+    // SLOWER, 3.21 against 2.82 ms per rotation: the two waves of a SIMD are arbitrated by age, the older wave A runs at the
+    // pace of a lone wave and B fills its bubbles, which 764 instructions just about do; a balanced pair leaves B to finish
+    // alone.  profiles/r05_ab_kernel_variants.txt)
+    const int last = p.l - 1;
     typename NTT::FwdTw0 t0;
     t0.load(c, lane);
     for (int i = 0; i < n; ++i) {
@@ -819,59 +805,16 @@ __global__ __launch_bounds__(512, 2) void blind_rotate8_kernel(
         if (abar == 0) continue;
         {
             int64_t acc0[REGS], acc1[REGS];             // output poly u, output poly 1-u
-            if (!role_b) {
-                ISA_MIX_ROLE("w=A");
-                if (mid >= 0) {
-                    // the shared row's first pass, before this wave's own rows: in LDS long before wave B asks for it
-                    ISA_MIX_ROLE("mid=1");
-                    uint32_t D[REGS];
-                    sh.acc.template rotated_difference<REGS>(D, u, lane, abar, p.decomp_offset);
-                    int32_t x[REGS];
-                    NTT::template forward_digits_first_pass<TAB>(x, D, 32 - (mid + 1) * p.Bgbit, p.Bgbit, c, t0);
-                    NTT::scatter_first_pass(x, sh.pb0[base], lane);
-                    // (LDS executes a wave's operations in order: the counter lands behind the stores; the fence is for
-                    // the compiler only)
-                    wave_lds_fence();
-                    typedef __attribute__((address_space(3))) uint32_t lds_u32;
-                    if (lane == 0) ((volatile lds_u32 *)sh.handoff)[base] = (uint32_t)(i + 1);
-                }
+            if (!role_b)
                 forward_poly<LOGN, true, true, true, TAB, int64_t, int64_t, true>(p, key, c, sh.acc, scr, lane, q, i, u, abar, u != 0,
-                                                                                acc0, acc1, t0, 0, a_end);
-            } else {
-                ISA_MIX_ROLE("w=B");
-                // the shared row's key image, requested before this wave's own rows
-                const uint4 *bp = reinterpret_cast<const uint4 *>(
-                                      key.bk_img + ((size_t)((size_t)i * p.kpl + (u * l + (mid >= 0 ? mid : 0))) * 2 + q) * 2 * N) + lane;
-                const int o0 = (u != 0) ? N / 4 : 0, o1 = N / 4 - o0;
+                                                                                acc0, acc1, t0, 0, last);
+            else
                 forward_poly<LOGN, true, true, true, TAB, int64_t, int64_t, true>(p, key, c, sh.acc, scr, lane, q, i, u, abar, u != 0,
-                                                                                acc0, acc1, t0, b_begin, l);
-                if (mid >= 0) {
-                    ISA_MIX_ROLE("mid=1");
-                    constexpr int G4 = REGS / 4;
-                    uint4 b0[G4], b1[G4];
-#pragma unroll
-                    for (int g = 0; g < G4; ++g) { b0[g] = bp[o0 + g * 64]; b1[g] = bp[o1 + g * 64]; }
-                    typedef __attribute__((address_space(3))) uint32_t lds_u32;
-                    while (__builtin_amdgcn_readfirstlane((int)((volatile lds_u32 *)sh.handoff)[base]) != i + 1) {}
-                    wave_lds_fence();
-                    int32_t x[REGS];
-                    NTT::forward_from_first_pass(x, c, sh.pb0[base], scr, lane);
-#pragma unroll
-                    for (int g = 0; g < G4; ++g) {
-                        const int32_t bb0[4] = {(int32_t)b0[g].x, (int32_t)b0[g].y, (int32_t)b0[g].z, (int32_t)b0[g].w};
-                        const int32_t bb1[4] = {(int32_t)b1[g].x, (int32_t)b1[g].y, (int32_t)b1[g].z, (int32_t)b1[g].w};
-#pragma unroll
-                        for (int e = 0; e < 4; ++e) {
-                            acc0[4 * g + e] += (int64_t)x[4 * g + e] * bb0[e];
-                            acc1[4 * g + e] += (int64_t)x[4 * g + e] * bb1[e];
-                        }
-                    }
-                }
-            }
+                                                                                acc0, acc1, t0, last, last + 1);
             int32_t s0[REGS], s1[REGS];
 #pragma unroll
             for (int r = 0; r < REGS; ++r) {
-                s0[r] = mont_redc(acc0[r], c.P, c.pinv);                // at most (l+1)/2 rows: |.| < 0.93P at l = 3
+                s0[r] = mont_redc(acc0[r], c.P, c.pinv);                // at most l-1 rows: |.| < 0.93P
                 s1[r] = mont_redc(acc1[r], c.P, c.pinv);
             }
             NTT::write_row(s0, role_b ? sh.pb0[base] : sh.pa0[base], lane);

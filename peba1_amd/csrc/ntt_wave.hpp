@@ -105,8 +105,6 @@ __device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(
 // rides into the assembly listing: tools/isa_mix.py counts the instructions of one blind-rotate step per wave from that
 // listing and needs to know which branches exclude each other.  A comment: the code object is byte for byte the same.
 #define LDS_BARRIER_ROLE(tag) asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier ; isa_mix role " tag ::: "memory")
-// the comment alone, at the head of a branch that has no barrier of its own (no instruction, no operand, no clobber)
-#define ISA_MIX_ROLE(tag) asm volatile("; isa_mix role " tag)
 
 __device__ __forceinline__ void ct_bfly(int32_t &a, int32_t &b, uint32_t w, const PrimeCtx &c) {
     const int32_t t = mont_mul(b, w, c.P, c.pinv);
@@ -572,64 +570,6 @@ struct WaveNtt {
         if constexpr (!EARLY) get2();
         fwd_pass(x, c, t2);
     }
-    // ---- a forward transform of gadget digits cut after its FIRST pass (8-wave form, round 5) -------------------
-    // One wave runs the first pass (from the digits: the table step or the plain steps) and leaves its output in LDS the way
-    // forward_tail's first scatter does; ANOTHER wave picks the rows up there and runs the second and third pass.  The
-    // transpose goes through LDS either way -- only the reader changes -- so the cut costs no traffic; what it buys is a
-    // unit of work smaller than a gadget row to balance two waves with (kernels.hip blind_rotate8_kernel).
-    template <bool TABLE>
-    static __device__ __forceinline__ void forward_digits_first_pass(int32_t (&x)[REGS], const uint32_t (&D)[REGS], int shift, int width,
-                                                                     const PrimeCtx &c, const FwdTw0 &t0) {
-        if constexpr (!TABLE) {
-#pragma unroll
-            for (int r = 0; r < REGS; ++r) x[r] = __builtin_amdgcn_sbfe((int32_t)D[r], shift, width);
-            fwd_pass(x, c, t0);
-        } else {
-            static_assert(FwdTw0::PAIR && FwdTw0::CNT == 1 && BR_TAB_PAIRS, "the first step is a radix-4 step with one block, paired tables");
-            constexpr int RBIT = rbit_of(0), h = 1 << RBIT, l = h >> 1;
-            const uint32_t mask4 = ((1u << width) - 1u) << 2, mask8 = mask4 << 1;
-            const int sh = shift - 2, sh8 = shift - 3;
-            const char *tab = reinterpret_cast<const char *>(c.dtab);
-            const char *tab1 = tab + DIGIT_TAB * 4, *tab3 = tab + 3 * DIGIT_TAB * 4;
-#pragma unroll
-            for (int r = 0; r < REGS; ++r)
-                if (!(r & (h | l))) {
-                    const int32_t x0 = __builtin_amdgcn_sbfe((int32_t)D[r], shift, width);
-                    const uint32_t i1 = (D[r | l] >> sh8) & mask8, i2 = (D[r | h] >> sh) & mask4, i3 = (D[r | h | l] >> sh8) & mask8;
-                    const int32_t A = (int32_t)*reinterpret_cast<const uint32_t *>(tab + i2);
-                    const uint2 p1 = *reinterpret_cast<const uint2 *>(tab1 + i1), p3 = *reinterpret_cast<const uint2 *>(tab3 + i3);
-                    const int32_t S = (int32_t)p1.x + (int32_t)p3.x;
-                    const int32_t T = (int32_t)p1.y + (int32_t)p3.y;
-                    const int32_t u = x0 + A, v = x0 - A;
-                    x[r] = u + S; x[r | l] = u - S; x[r | h] = v + T; x[r | h | l] = v - T;
-                }
-            if constexpr (RB > 2) fwd_pass(x, c, t0.rest);
-        }
-    }
-    // the first pass's output into `dst` (any ROW_WORDS buffer), where the second pass reads rows
-    static __device__ __forceinline__ void scatter_first_pass(const int32_t (&x)[REGS], uint32_t *dst, int lane) {
-#pragma unroll
-        for (int r = 0; r < REGS; ++r) dst[t1_l0_addr(lane, r)] = (uint32_t)x[r];
-    }
-    // second and third pass from rows another wave scattered into `src`; own transposes through `scr`.  The twiddles come
-    // from the workgroup's LDS images (c.fw1, c.fw2)
-    static __device__ __forceinline__ void forward_from_first_pass(int32_t (&x)[REGS], const PrimeCtx &c, const uint32_t *src,
-                                                                   uint32_t *scr, int lane) {
-        FwdTw1 t1;
-        t1.from_image(static_cast<const uint4 *>(c.fw1));
-        read_row(x, src, lane);
-        wave_lds_fence();
-        fwd_pass(x, c, t1);
-        FwdTw2 t2;
-        t2.from_image(static_cast<const uint4 *>(c.fw2));
-#pragma unroll
-        for (int r = 0; r < REGS; ++r) scr[t2_l1_addr(lane, r)] = (uint32_t)x[r];
-        wave_lds_fence();
-        read_row(x, scr, lane);
-        wave_lds_fence();
-        fwd_pass(x, c, t2);
-    }
-
     // fills this prime's digit table for digits of `width` bits (threads tid, tid + nthreads, ... of
     // the workgroup); entry f of a row is for the digit whose two's-complement bit field is f
     static __device__ __forceinline__ void build_digit_table(uint32_t *tab, const PrimeCtx &c, int width, int tid, int nthreads) {

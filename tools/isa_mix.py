@@ -43,11 +43,8 @@ KERNELS = {
                                            [("wave", lambda l: l, 2)]),
     "blind_rotate4_kernelILi10ELi0ELb0E": ("blind_rotate4_kernel<10,0,false>", "4-wave form, no digit table (P80)",
                                            [("wave", lambda l: l, 2)]),
-    # 8-wave form: wave A transforms rows [0, l/2) and, for odd l, the first pass of the middle row; wave B rows
-    # [(l+1)/2, l) and the rest of the middle row; the two arms carry "isa_mix role w=A" / "w=B" comments and the blocks of
-    # the shared row "mid=1" (kernels.hip ISA_MIX_ROLE): a path of an odd-l step crosses one of each
     "blind_rotate8_kernelILi10ELb1E": ("blind_rotate8_kernel<10,true>", "8-wave latency form (narrow launches)",
-                                       [("A", lambda l: l // 2, 1, {"w": "A"}), ("B", lambda l: l - (l + 1) // 2, 1, {"w": "B"})]),
+                                       [("A", lambda l: l - 1, 1), ("B", lambda l: 1, 1)]),
     "blind_rotate_split_kernelILi11ELi2E": ("blind_rotate_split_kernel<11,2>", "split form (P2048, BASELINE configs[4])",
                                             [("wave", lambda l: l, 2)]),
 }
@@ -85,9 +82,6 @@ def parse_kernel(lines, needle):
                 cur["parent"] = ".L" + h.group(1)
             continue
         s = raw.strip()
-        if s.startswith("; isa_mix role "):
-            cur["ins"].append(s)                            # a role mark without an instruction (ISA_MIX_ROLE): keep the text
-            continue
         if s.startswith(";"):
             # continuation lines of a block's loop note: "; Parent Loop BB20_41 Depth=1", "; =>This Inner Loop Header: Depth=2"
             h = re.search(r"Parent Loop (BB\d+_\d+) Depth=(\d+)", s)
@@ -118,8 +112,6 @@ def block_counts(ins):
         if op.startswith("v_"):
             c["valu"] += 1
             c[classify(op)] += 1
-            if op == "v_bfe_i32":
-                c["digits"] += 1
         elif op.startswith("ds_"):
             c["lds"] += 1
         elif op.startswith(("global_", "buffer_", "flat_")):
@@ -156,10 +148,8 @@ def successors(blocks, order, name):
 
 
 def is_row_body(c):
-    """A whole gadget row of the forward phase: the extraction of its digits (signed bit fields: v_bfe_i32), a transform's
-    multiplies, no barrier.  (The 8-wave form's shared middle row is no row body in either wave: the one that extracts the
-    digits runs a quarter of the multiplies, the other extracts nothing.)"""
-    return c["mul"] >= 150 and c["digits"] >= 1 and c["barrier"] == 0
+    """A gadget row of the forward phase: a transform's multiplies and the loads of the row's key image, no barrier."""
+    return c["mul"] >= 150 and c["vmem"] >= 8 and c["barrier"] == 0
 
 
 def analyse(lines, needle, l):
@@ -231,8 +221,7 @@ def analyse(lines, needle, l):
     role_keys = {k for t in node_tags.values() for k in t}
 
     out_roles = []
-    for name, rows_of, per_simd, *want in roles:
-        want = want[0] if want else {}
+    for name, rows_of, per_simd in roles:
         rows = rows_of(l)
         found = {}
         for p in paths:
@@ -242,8 +231,6 @@ def analyse(lines, needle, l):
                 for k, v in node_tags.get(node, {}).items():
                     seen_tags[k].add(v)
             if any(len(seen_tags[k]) != 1 for k in role_keys):
-                continue
-            if any(seen_tags[k] != {v} for k, v in want.items()):
                 continue
             fixed = sum(1 for node in p if not is_loop[node] and is_row_body(node_cost[node]))
             loops = [node for node in p if is_loop[node] and is_row_body(node_cost[node])]
