@@ -178,9 +178,9 @@ int tfhe_hip_gate_batch(int gate, LweSample *result, const LweSample *a, const L
  * "ks_atomic": 1 = the ranges of a split key switch add their partial sums into the zeroed destination
  * slot with 32-bit atomic adds (no partial-sum buffer, no reduce launch); 0 (default) = partial sums + reduce;
  * env TFHE_HIP_KS_ATOMIC.  Integer adds commute: the same words either way.
- * "br_fair": k > 0 (default 18, env TFHE_HIP_BR_FAIR) = in launches that put two blind-rotate
- * workgroups on a CU, the two swap wave issue priority every 2^k shader cycles so that both
- * finish together; 0 = leave it to the hardware's oldest-first arbitration.
+ * "br_fair": k > 0 (env TFHE_HIP_BR_FAIR) = in launches that put two blind-rotate workgroups on a CU, the two swap
+ * wave issue priority every 2^k shader cycles; 0 (default since round 5) = the kernel's own progress priority alone (a
+ * wave's issue priority follows its progress through the blind-rotate step; measured faster than the time slices).
  * "reuse_gates": 1 (default) = in deferred mode a gate recorded again with the same operand
  * samples before the flush shares the pending gate's result instead of being evaluated again
  * (same function of the same ciphertexts, so the same words); 0 = evaluate every call.

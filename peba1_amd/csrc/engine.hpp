@@ -160,10 +160,12 @@ public:
     // (kernels.hip keyswitch_index_kernel; tiles of 16, 24 or 32): 60.8 ms per match against 105 ms of the LDS-strip form;
     // 1 = rows in registers, picked by scalar branches (keyswitch_branch_kernel): 73 ms; 0 = the LDS-strip form
     int ks_branch = 2;
-    // blind rotate: k > 0 = the two workgroups sharing a CU swap issue priority every 2^k shader
-    // cycles (0 = off: the hardware's oldest-first issue runs one at full speed and leaves the
-    // other to finish alone with one wave per SIMD; measured optimum 2^16..2^20, tools/wg_times.py)
-    int br_fair = 18;
+    // blind rotate, 4-wave form: k > 0 = the workgroups sharing a CU swap issue priority every 2^k shader cycles
+    // (rounds 1-4: default 18; without anything the hardware's oldest-first issue runs one at full speed and leaves the
+    // other to finish alone).  Round 5: the kernel sets a wave's priority by its progress through the step
+    // (kernels.hip blind_rotate4_body), which measured 3-4 % faster than the time slices and loses that with the
+    // slices on top: default 0; env TFHE_HIP_BR_FAIR, tuning "br_fair"
+    int br_fair = 0;
     // which form of the blind-rotate kernel runs wide launches (kernels.hip): -1 = the fastest measured
     // for the ring size, 0 = 4-wave wide at N = 1024 (D and 64-bit partial sums in registers, two
     // workgroups per CU) / 4-wave lean at N = 2048, 1 = 4-wave lean at N = 1024 (three per CU),

@@ -287,7 +287,10 @@ struct AccLds {
 // t0: the twiddles of the transforms' first pass -- lane-uniform and the same for every row and step, so the caller
 // loads them ONCE per kernel (they then live in scalar registers; round 3: -1.4 % of a wide launch against loading
 // them per row, and 12 fewer vector registers)
-template <int LOGN, bool FRESH, bool KEEP_D, bool EARLY_TW, bool TABLE, typename Acc0T, typename Acc1T, bool LDSTW = false>
+// PROGRESS (4-wave form): the wave's issue priority follows its progress through the step -- 0 for the first gadget row,
+// 1 for the second, 2 from the third (blind_rotate4_body raises it to 3 for the step's tail).
+template <int LOGN, bool FRESH, bool KEEP_D, bool EARLY_TW, bool TABLE, typename Acc0T, typename Acc1T, bool LDSTW = false,
+          bool PROGRESS = false>
 __device__ __forceinline__ void forward_poly(const DevParams &p, const DevKey &key, const PrimeCtx &c,
                                              const AccLds<LOGN> &lds_acc, uint32_t *scr,
                                              int lane, int q, int i, int u, int abar, bool swap_outputs,
@@ -370,7 +373,13 @@ __device__ __forceinline__ void forward_poly(const DevParams &p, const DevKey &k
     if (jend < 0) jend = p.l;
     row(jbegin, std::integral_constant<bool, FRESH>{});
 #pragma unroll 1
-    for (int jj = jbegin + 1; jj < jend; ++jj) row(jj, std::false_type{});
+    for (int jj = jbegin + 1; jj < jend; ++jj) {
+        if constexpr (PROGRESS) {
+            if (jj == jbegin + 1) __builtin_amdgcn_s_setprio(1);
+            else __builtin_amdgcn_s_setprio(2);
+        }
+        row(jj, std::false_type{});
+    }
 }
 
 // sample extract at index 0 (tfhe tLweExtractLweSampleIndex) + optional raw accumulator dump
@@ -569,6 +578,16 @@ __device__ __forceinline__ void blind_rotate4_body(const DevParams &p, const Dev
     typename NTT::FwdTw0 t0;                 // first-pass twiddles of every forward transform: loaded once (forward_poly)
     t0.load(c, lane);
 
+    // Issue priority by PROGRESS (round 5).  The workgroups that share a CU put one wave each on every SIMD, and the SIMD
+    // arbitrates their issue by priority, then age: left alone, the older workgroup runs at the pace of a lone wave and the
+    // younger gets the leftover slots, then finishes alone.  Rounds 1-4 let them take turns by time slices of 2^18 cycles
+    // ("br_fair").  Now a wave's priority follows its progress through the step: 0 in the first gadget row, 1 in the second,
+    // 2 from the third, 3 from the first barrier to the last (the inverse transform, the CRT, the accumulator update -- the
+    // part of a step in which four waves wait for each other three times).  Whichever workgroup is further along wins, gets
+    // through its barriers at full pace, drops to 0 for its next step and becomes the filler of the other's bubbles: they
+    // leapfrog step by step.  Measured, variants interleaved on one box (profiles/r05_ab_kernel_variants.txt): 4,096
+    // rotations 36.97 -> 35.41 ms (-4.2 %), 512 rotations 5.37 -> 5.22 ms, P80 23.59 -> 22.53 ms; with fewer levels, other
+    // points, or the time slices on top of it: less or nothing.  "br_fair" > 0 still selects the time slices (default 0 now).
     for (int i = 0; i < n; ++i) {
         if (p.fair_shift > 0) {
             // time slices of 2^fair_shift shader cycles: the workgroups of a CU read the same clock,
@@ -586,8 +605,8 @@ __device__ __forceinline__ void blind_rotate4_body(const DevParams &p, const Dev
         using Acc1T = typename std::conditional<TR::WIDE_SEND, int64_t, int32_t>::type;
         Acc0T acc0[REGS];
         Acc1T acc1[REGS];
-        forward_poly<LOGN, true, TR::KEEP_D, TR::EARLY_TW, TAB, Acc0T, Acc1T, TR::LDS_TWIDDLES>(p, key, c, sh.acc, scr, lane, q, i, u,
-                                                                                               abar, u != 0, acc0, acc1, t0);
+        forward_poly<LOGN, true, TR::KEEP_D, TR::EARLY_TW, TAB, Acc0T, Acc1T, TR::LDS_TWIDDLES, true>(p, key, c, sh.acc, scr, lane, q, i, u,
+                                                                                                     abar, u != 0, acc0, acc1, t0);
         STAMP(1);
 
         int32_t t[REGS];
@@ -607,6 +626,7 @@ __device__ __forceinline__ void blind_rotate4_body(const DevParams &p, const Dev
         t2.load(c, lane);
         STAMP(2);
         lds_barrier();
+        __builtin_amdgcn_s_setprio(3);                    // the step's tail (above: progress priority)
         STAMP(3);
         {
             int32_t other[REGS];
@@ -643,6 +663,7 @@ __device__ __forceinline__ void blind_rotate4_body(const DevParams &p, const Dev
                            sh.acc.get(u, (HALF + r) * 64 + lane) + crt_signed_to_torus((int32_t)ox[r * 64 + lane], t[HALF + r]));
         }
         STAMP(5);
+        __builtin_amdgcn_s_setprio(0);
         lds_barrier();
         STAMP(6);
     }
@@ -724,6 +745,9 @@ __device__ __forceinline__ uint32_t split_finish(int h, int32_t a0, int32_t a1, 
 #ifndef BR8_INV_LAYOUT_H
 #define BR8_INV_LAYOUT_H false
 #endif
+// (round 5: wave B raising its issue priority in the step's tail -- before the half inverse, behind it, or for the last phase
+// only, as the split form's younger half does -- measured slower here, 2.81-2.82 against 2.76 ms per rotation: in this form the
+// older wave A is also the one with more work, and age is the right order; profiles/r05_ab_kernel_variants.txt)
 template <int LOGN>
 struct Br8Lds {
     using NTT = WaveNtt<LOGN>;
@@ -895,6 +919,14 @@ __global__ __launch_bounds__(512, 2) void blind_rotate8_kernel(
 //           sums of up to seven of them stay small: below 3.5P + 2^11 after the step, 9.7P after the transform.
 //           Digits of at most SPLIT_TAB2_BITS bits (the N = 2048 set: 11 KB of tables).
 constexpr int SPLIT_TAB2_BITS = 6;
+// Issue priority inside a SIMD (round 5).  The two waves of a SIMD, (q, u, h = 0) and (q, u, h = 1), run the same program
+// between the same barriers, and the hardware arbitrates their issue by AGE: the older half runs each phase at the pace of a
+// lone wave, the younger fills its bubbles and finishes the phase alone while the older waits at the barrier.  The younger
+// half therefore raises its priority when it starts its SECOND gadget row and keeps it to the end of the step: the older
+// half, ahead by then, fills ITS bubbles, and the two reach the barriers together.  Measured on one box, variants
+// interleaved (profiles/r05_ab_kernel_variants.txt): N = 2048, 4,096 rotations 145.3 -> 142.2 ms, one rotation 9.01 -> 8.73
+// ms; raising it at the third row, dropping it at the first barrier, for the middle row only, or by time slices of 2^11 ..
+// 2^15 cycles all measured between the two.
 template <int LOGN, int TM>
 struct BrSplitLds {
     using SUB = WaveNtt<LOGN - 1>;
@@ -1099,7 +1131,10 @@ __global__ __launch_bounds__(512, (LOGN == 10 ? 4 : 2)) void blind_rotate_split_
         // (a loop on purpose: with the rows in line the compiler overlaps them and runs out of registers --
         // measured 4 % slower at N = 2048 and 20 % at N = 1024)
 #pragma unroll 1
-        for (int jj = 1; jj < p.l; ++jj) row(jj, std::false_type{});
+        for (int jj = 1; jj < p.l; ++jj) {
+            if (h == 1 && jj == 1) __builtin_amdgcn_s_setprio(1);     // the younger half, from its second row (above)
+            row(jj, std::false_type{});
+        }
 
         int32_t t[RS];
         {
@@ -1138,6 +1173,7 @@ __global__ __launch_bounds__(512, (LOGN == 10 ? 4 : 2)) void blind_rotate_split_
                 sh.acc.set(u, M + jl, sh.acc.get(u, M + jl) + split_finish(1, va0, va1, vb0, vb1, iw1_0, iw1_1));
             }
         }
+        if (h == 1) __builtin_amdgcn_s_setprio(0);          // the younger half kept the priority through the step's tail
         lds_barrier();
     }
     extract_sample<LOGN, 512>(p, rd, sh.acc, u_buf, acc_dbg, tid);

@@ -1,6 +1,7 @@
 #!/bin/bash
 # Round 5 A/B on ONE box, variants interleaved (tools/diag/build_variants.sh builds the variant libraries first):
 #   gpurun --timeout 1200 -- 'bash tools/diag/r5_ab.sh <tag> "default pair" [sizes P128] [p80 p2048]'
+# PARITY_VARS="a b" limits the parity runs to those variants (priority-only variants compute the same integers by construction).
 # Per variant first a short parity run THROUGH that library (a measurement build that computes wrong words is not timed),
 # each under its own timeout; then the launch times of independent gates, three rounds, variants alternating.
 set -o pipefail
@@ -9,9 +10,10 @@ OUT=gpurun_out/$TAG; mkdir -p $OUT
 export TMPDIR=/tmp
 AB=$PWD/tools/diag/_ab
 # a variant is a library built by build_variants.sh, "default", or NAME=value: the default library under that environment setting
-libof() { case "$1" in default|*=*) echo "";; *) echo "$AB/libtfhe-hip-$1.so";; esac; }
-envof() { case "$1" in *=*) echo "$1";; *) echo "PEBA1_AB_NOTHING=1";; esac; }
-for v in $VARS; do
+# ... or lib@NAME=value: that library under that setting
+libof() { case "$1" in *@*) echo "$AB/libtfhe-hip-${1%%@*}.so";; default|*=*) echo "";; *) echo "$AB/libtfhe-hip-$1.so";; esac; }
+envof() { case "$1" in *@*) echo "${1#*@}";; *=*) echo "$1";; *) echo "PEBA1_AB_NOTHING=1";; esac; }
+for v in ${PARITY_VARS-$VARS}; do
   env $(envof $v) PEBA1_TFHE_HIP_LIB=$(libof $v) timeout -k 10 240 python -m pytest -x -q -m gpu -p no:cacheprovider \
       "tests/test_gpu_kernels.py::test_blind_rotate_matches_oracle" "tests/test_gpu_kernels.py::test_every_selectable_kernel_form_is_bit_exact" \
       "tests/test_gpu_kernels.py::test_random_input_parity_soak_in_every_launch_form" > $OUT/parity_$v.log 2>&1 \
