@@ -215,10 +215,10 @@ void Engine::note_async_io() {
 }
 // a caller's own event (libpeba1-dist: the status words of a collective, on a stream of their own), bounded like every
 // other host wait of the library.  Takes no engine state: safe beside a flush in flight.
-void Engine::wait_event(hipEvent_t ev, const char *what) {
+void Engine::wait_event(hipEvent_t ev, const char *what, long long deadline_ms, const std::string &label) {
     ENGINE_DEVICE_SCOPE();
-    if (sync_deadline_ms <= 0) hip_check(hipEventSynchronize(ev), what);
-    else bounded_wait([&] { return hipEventQuery(ev); }, what, sync_deadline_ms, diag_label);
+    if (deadline_ms <= 0) hip_check(hipEventSynchronize(ev), what);
+    else bounded_wait([&] { return hipEventQuery(ev); }, what, deadline_ms, label);
 }
 
 bool Engine::pci_bus_id(char *out, int len) {

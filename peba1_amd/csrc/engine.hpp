@@ -113,7 +113,8 @@ public:
     void sync_stream(const char *what); // everything enqueued on the engine's stream has completed
     void sync_io();                     // the stream-ordered transfers nobody waited for have completed
     void wait_all() { wait_flight(); sync_io(); }
-    void wait_event(hipEvent_t ev, const char *what);   // a caller's event, bounded like the waits above
+    // a caller's event, bounded like the waits above (deadline and label passed in: read by the caller under the recorder lock)
+    void wait_event(hipEvent_t ev, const char *what, long long deadline_ms, const std::string &label);
     bool pci_bus_id(char *out, int len);                // "0000:c1:00.0" of the engine's device
     // > 0: no host wait on the engine's stream lasts longer -- on expiry the process prints what it waited for and ends
     // with TFHE_HIP_EXIT_DEADLINE (tuning "sync_deadline_ms", env TFHE_HIP_SYNC_DEADLINE_MS); 0 = wait for ever

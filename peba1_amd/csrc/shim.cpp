@@ -928,9 +928,18 @@ int tfhe_hip_stream_sync(void) {
 }
 int tfhe_hip_wait_event(void *event, const char *what) {
     if (!event) { set_error("tfhe_hip_wait_event: null event"); return -1; }
-    return guarded_rc([&] {
+    // the deadline and the label are read under the recorder lock (tfhe_hip_set_tuning / tfhe_hip_set_diag_label write them
+    // there); the wait itself holds no lock -- it may last until a peer process arrives, and other threads go on recording
+    long long deadline_ms;
+    std::string label;
+    {
+        std::lock_guard<std::recursive_mutex> g(rec().mtx);
         Engine::get().ensure_init();
-        Engine::get().wait_event(static_cast<hipEvent_t>(event), what && *what ? what : "tfhe_hip_wait_event");
+        deadline_ms = Engine::get().sync_deadline_ms;
+        label = Engine::get().diag_label;
+    }
+    return guarded_rc([&] {
+        Engine::get().wait_event(static_cast<hipEvent_t>(event), what && *what ? what : "tfhe_hip_wait_event", deadline_ms, label);
         return 0;
     });
 }
@@ -967,6 +976,7 @@ int tfhe_hip_test_form_admissible(int form, int32_t N, int32_t l, int32_t Bgbit,
 }
 
 int tfhe_hip_set_tuning(const char *name, int64_t value) {
+    std::lock_guard<std::recursive_mutex> g(rec().mtx);      // the launchers read the tunings under the same lock (flushes)
     if (name && std::strcmp(name, "br4_max_rotations") == 0) { Engine::get().br4_max_rotations = (int)value; return 0; }
     if (name && std::strcmp(name, "ks_target_blocks") == 0) { Engine::get().ks_target_blocks = (int)value; return 0; }
     if (name && std::strcmp(name, "ks_tile") == 0) {

@@ -53,7 +53,7 @@ KERNELS = {
 def classify(op):
     if op in MUL:
         return "mul"
-    if op in THREE or op.rstrip("_e64") in THREE:
+    if op in THREE or (op.endswith("_e64") and op[:-4] in THREE):
         return "three_operand"
     return "two_operand"
 
