@@ -473,7 +473,7 @@ __global__ __launch_bounds__(128) void blind_rotate_kernel(DevParams p, DevKey k
 #ifdef TFHE_HIP_STAMPS
 // Diagnostic build only (tools/diag/build_stamps.sh): per-phase shader-cycle sums of
 // the 4-wave kernel, lane 0 of each wave, accumulated into a buffer nothing else reads.
-__device__ unsigned long long g_stamps[4][8];
+__device__ unsigned long long g_stamps[8][8];      // [wave][phase]; the 4-wave kernel uses waves 0-3
 #define STAMP_DECL unsigned long long st_prev = __builtin_amdgcn_s_memtime(), st_sum[8] = {0, 0, 0, 0, 0, 0, 0, 0}
 #define STAMP(k)                                                             \
     do {                                                                     \
@@ -745,9 +745,10 @@ __device__ __forceinline__ uint32_t split_finish(int h, int32_t a0, int32_t a1, 
 #ifndef BR8_INV_LAYOUT_H
 #define BR8_INV_LAYOUT_H false
 #endif
-// (round 5: wave B raising its issue priority in the step's tail -- before the half inverse, behind it, or for the last phase
-// only, as the split form's younger half does -- measured slower here, 2.81-2.82 against 2.76 ms per rotation: in this form the
-// older wave A is also the one with more work, and age is the right order; profiles/r05_ab_kernel_variants.txt)
+// (round 5: wave B raising its issue priority -- in the step's tail before the half inverse, behind it, inside it, for the last
+// phase only, or for the reductions in front of the first barrier, where the phase stamps show it 700 cycles behind wave A --
+// measured slower in all eight combinations, 2.80-2.84 against 2.76 ms per rotation; profiles/r05_ab_kernel_variants.txt,
+// profiles/r05_stamps_8wave.txt)
 template <int LOGN>
 struct Br8Lds {
     using NTT = WaveNtt<LOGN>;
@@ -824,9 +825,11 @@ __global__ __launch_bounds__(512, 2) void blind_rotate8_kernel(
     const int last = p.l - 1;
     typename NTT::FwdTw0 t0;
     t0.load(c, lane);
+    STAMP_DECL;
     for (int i = 0; i < n; ++i) {
         const int abar = __builtin_amdgcn_readfirstlane((int)sh.bar[i]);
         if (abar == 0) continue;
+        STAMP(0);
         {
             int64_t acc0[REGS], acc1[REGS];             // output poly u, output poly 1-u
             if (!role_b)
@@ -835,6 +838,7 @@ __global__ __launch_bounds__(512, 2) void blind_rotate8_kernel(
             else
                 forward_poly<LOGN, true, true, true, TAB, int64_t, int64_t, true>(p, key, c, sh.acc, scr, lane, q, i, u, abar, u != 0,
                                                                                 acc0, acc1, t0, last, last + 1);
+            STAMP(1);
             int32_t s0[REGS], s1[REGS];
 #pragma unroll
             for (int r = 0; r < REGS; ++r) {
@@ -846,7 +850,9 @@ __global__ __launch_bounds__(512, 2) void blind_rotate8_kernel(
         }
         typename SUB::InvTw2 t2;                            // requested before the barrier, in flight across it
         t2.load(ch, lane);
+        STAMP(2);
         lds_barrier();
+        STAMP(3);
         {
             // Half h of the summed spectrum of output polynomial u, in the half transform's layout: slot 8 lane + reg of
             // the half is slot 16 (32 h + lane / 2) + 8 (lane & 1) + reg of the full-size rows the forward phase wrote
@@ -868,7 +874,9 @@ __global__ __launch_bounds__(512, 2) void blind_rotate8_kernel(
 #pragma unroll
             for (int r = 0; r < RS; ++r) scr[r * 64 + lane] = (uint32_t)t[r];
         }
+        STAMP(4);
         lds_barrier();
+        STAMP(5);
         {
             // the four waves of output polynomial u take a quarter of the register rows each and finish coefficients
             // j and j + N/2 of it, for both primes (split_finish: last inverse stage, CRT)
@@ -883,8 +891,11 @@ __global__ __launch_bounds__(512, 2) void blind_rotate8_kernel(
                 sh.acc.set(u, M + jl, sh.acc.get(u, M + jl) + split_finish(1, va0, va1, vb0, vb1, iw1_0, iw1_1));
             }
         }
+        STAMP(6);
         lds_barrier();
+        STAMP(7);
     }
+    STAMP_FLUSH;
     extract_sample<LOGN, 512>(p, rd, sh.acc, u_buf, acc_dbg, tid);
     clk.end(p);
 }
@@ -1854,8 +1865,8 @@ void launch_blind_rotate_split(hipStream_t s, const DevParams &p, const DevKey &
 
 #ifdef TFHE_HIP_STAMPS
 void read_stamps(unsigned long long *out, bool reset) {
-    (void)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_stamps), sizeof(unsigned long long) * 32);
-    if (reset) { unsigned long long z[32] = {0}; (void)hipMemcpyToSymbol(HIP_SYMBOL(g_stamps), z, sizeof z); }
+    (void)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_stamps), sizeof(unsigned long long) * 64);
+    if (reset) { unsigned long long z[64] = {0}; (void)hipMemcpyToSymbol(HIP_SYMBOL(g_stamps), z, sizeof z); }
 }
 #endif
 

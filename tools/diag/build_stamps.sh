@@ -4,7 +4,7 @@
 set -euo pipefail
 ROOT=$(cd "$(dirname "$0")/../.." && pwd)
 S=$ROOT/peba1_amd/csrc
-O=${1:-/tmp/stamps}
+O=${1:-$ROOT/tools/diag/_stamps}
 mkdir -p $O
 ROCM=${ROCM_PATH:-/opt/rocm}
 F="-O3 -std=c++17 -fPIC -ffp-contract=off -DTFHE_HIP_STAMPS"
