@@ -374,6 +374,25 @@ def test_isa_mix_summary_is_what_the_built_kernels_give(kernels_isa, tmp_path):
     assert blk["model_cycles_per_simd_step"] == pytest.approx(2 * (v["mul"] * 5.4 + v["three_operand"] * 5.2 + v["two_operand"] * 3.0))
 
 
+def test_kernel_id_hashes_every_file_the_kernels_are_built_from():
+    """`kernels_sha16` keys the committed rocprof summaries to the code that is running (bench.py quotes them only on a
+    match): it must cover every local file kernels.hip pulls in, transitively, and the build script with its flags."""
+    import re
+    from peba1_amd.kernel_id import CSRC, KERNEL_FILES, kernels_sha16
+    seen, todo = set(), ["kernels.hip"]
+    while todo:
+        name = todo.pop()
+        if name in seen:
+            continue
+        seen.add(name)
+        for inc in re.findall(r'^\s*#\s*include\s+"([^"]+)"', open(os.path.join(CSRC, name)).read(), flags=re.M):
+            if os.path.exists(os.path.join(CSRC, inc)):
+                todo.append(inc)
+    assert seen <= set(KERNEL_FILES), f"not hashed: {sorted(seen - set(KERNEL_FILES))}"
+    assert "build.sh" in KERNEL_FILES and "br_forms.hpp" in KERNEL_FILES
+    assert len(kernels_sha16()) == 16 and kernels_sha16() == kernels_sha16()
+
+
 def test_parity_kit_files_are_what_the_oracle_produces():
     """tests/golden/parity_kit: the committed raw-word fixtures are exactly what make_kit.py
     regenerates from the oracle (schoolbook and two-prime evaluators agree inside it), and the product's seeded key
