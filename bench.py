@@ -19,18 +19,23 @@ gate for gate), TFHE default 128-bit parameters (n=630, N=1024, k=1, l=3, Bg=2^7
             no data-path collective, "scaling": "weak".
 
 `--mode auto` (default) = match at --gpus 1, sharded at --gpus N > 1, so that the driver's
-`bench.py --gpus N` measures the split north_star names.
+`bench.py --gpus N` measures the split north_star names: ONE curve, "scaling": "strong" -- its N = 1
+point is one rank holding every slot, which is the reference's unsplit Function_f (the line says so);
+`weak_scaling` (independent matches per GPU) rides beside it at every N.
 
 Inputs (probe, template, threshold ciphertexts) and the evaluation keys are resident in HBM
 before the timed region.  Prints ONE JSON line on rank 0.  `value` counts executed blind
 rotations (a MUX is two) of ALL ranks per second of the slowest rank.
 
     python bench.py --gpus 1 --steps 3 --warmup 1
-    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+    python bench.py --gpus N ...            starts its own N ranks (a child `torch.distributed.run`; the parent never
+                                            touches the GPU) and relays rank 0's line
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...      the same, launched by hand
+The N > 1 line carries `dist` (who took part: RCCL version, every rank's PCI bus id, the collectives run, the transport)
+and `roofline.valu_issue` (the roofline that binds, from profiles/isa_mix.json and profiles/valu_issue_costs.json).
 """
 import argparse
 import ctypes
-import hashlib
 import json
 import os
 import sys
