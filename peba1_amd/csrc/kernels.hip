@@ -826,6 +826,10 @@ __global__ __launch_bounds__(512, 2) void blind_rotate8_kernel(
     typename NTT::FwdTw0 t0;
     t0.load(c, lane);
     STAMP_DECL;
+    // wave A -- the older wave of its SIMD and the one with more work -- also holds the higher issue priority for the whole
+    // rotation: explicit priority instead of age alone measured 2.74 against 2.77 ms per rotation, 3.18 against 3.24 ms per
+    // 256 (profiles/r05_ab_kernel_variants.txt); dropping it for the step's tail: 2.88
+    if (!role_b) __builtin_amdgcn_s_setprio(1);
     for (int i = 0; i < n; ++i) {
         const int abar = __builtin_amdgcn_readfirstlane((int)sh.bar[i]);
         if (abar == 0) continue;
