@@ -349,13 +349,15 @@ void peba1_dist_destroy(Peba1Comm *c) {
     if (c->rccl) {
         DeviceScope on_provider_device;
         stream_sync();
+        // (every status exchange was waited for when it was made: nothing is in flight on the status stream; the wait is a formality)
+        if (c->st_stream) (void)hipStreamSynchronize(c->st_stream);
+        if (c->own && c->nccl) (void)g_rccl.CommDestroy(c->nccl);
         if (c->send) (void)hipFree(c->send);
         if (c->recv) (void)hipFree(c->recv);
         if (c->st_dev) (void)hipFree(c->st_dev);
         if (c->st_host) (void)hipHostFree(c->st_host);
         if (c->st_event) (void)hipEventDestroy(c->st_event);
-        if (c->st_stream) { (void)hipStreamSynchronize(c->st_stream); (void)hipStreamDestroy(c->st_stream); }
-        if (c->own && c->nccl) (void)g_rccl.CommDestroy(c->nccl);
+        if (c->st_stream) (void)hipStreamDestroy(c->st_stream);
     }
     delete c;
 }
