@@ -205,7 +205,7 @@ typedef struct TfheHipStats {
     double   ms_keyswitch;
     double   ms_flush_wall;     /* host wall time inside flush */
     double   ms_blind_rotate_busy; /* time during which at least one blind-rotate launch was running
-                                      (== ms_blind_rotate with one lane; less when two lanes overlap) */
+                                      (== ms_blind_rotate: a flush is one level sequence on one stream) */
     uint64_t reused_gates;      /* recorded gates served by an identical pending gate ("reuse_gates") */
     /* of the blind-rotate totals above, the part run by the 8-wave form (launches of at most one
      * workgroup per CU); the rest is the 4-wave kernel */
