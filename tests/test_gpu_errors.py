@@ -200,3 +200,39 @@ def test_gadget_outside_every_kernel_form_is_refused_at_key_upload():
     L.tfhe_hip_clear_error()
     with pytest.raises(RuntimeError, match="every blind-rotate kernel form"):
         api.SecretKeySet(pp, 7, device=True)
+
+
+def test_device_identity_and_bounded_event_wait(p128_keys):
+    """Round 5 entry points: the PCI bus id of the device the library runs on (what bench.py prints per rank as evidence of N
+    distinct GPUs) and the bounded wait on a caller's own HIP event (what libpeba1-dist reads the status words of a
+    collective back with).  The library binds the calling thread to its device only for the duration of a call: the
+    caller's current device is the same before and after."""
+    import ctypes as C
+    import re
+    import torch
+    from peba1_amd import api, lib
+    pp, ks, _ = p128_keys
+    L = lib.load()
+    before = torch.cuda.current_device()
+    buf = C.create_string_buffer(64)
+    assert L.tfhe_hip_device_pci_bus_id(buf, 64) == 0
+    assert re.fullmatch(r"[0-9a-fA-F]{4}:[0-9a-fA-F]{2}:[0-9a-fA-F]{2}\.[0-9a-fA-F]", buf.value.decode()), buf.value
+    assert L.tfhe_hip_device_pci_bus_id(buf, 4) == -1 and "16 bytes" in _err()
+    # an event of the caller's own, recorded behind work on the library's stream
+    a = api.CiphertextArray(pp, 64).encrypt([1] * 64, ks)
+    r = api.CiphertextArray(pp, 64)
+    api.set_deferred(True)
+    try:
+        for i in range(64):
+            L.bootsAND(r.at(i), a.at(i), a.at(i), ks.cloud)
+        api.flush_async()                                         # enqueued, not waited for
+        stream = torch.cuda.ExternalStream(L.tfhe_hip_stream())
+        ev = torch.cuda.Event()
+        ev.record(stream)
+        assert L.tfhe_hip_wait_event(C.c_void_p(ev.cuda_event), b"test event") == 0
+        assert ev.query()                                         # the wait returned because the event had completed
+        assert L.tfhe_hip_wait_event(None, b"null") == -1
+    finally:
+        api.set_deferred(False)
+    assert list(r.decrypt(ks)) == [1] * 64
+    assert torch.cuda.current_device() == before
