@@ -703,6 +703,9 @@ def main():
                          # of every launch (the same launch is ~15 % slower at the ~2.0 GHz of a cold or power-limited
                          # chip than at ~2.37 GHz) -- explains run-to-run and box-to-box differences
                          "shader_clock_ghz": 0.1 * st["clk_shader_cycles"] / st["clk_ref_ticks"] if st["clk_ref_ticks"] else None,
+                         # `value` per GHz of that clock: what compares runs on different boxes (round 5 saw 2.22-2.34 GHz: 103-110k
+                         # gates/s for the same code, 46.6-46.8k per GHz; the driver's round-4 line: 44.6k per GHz)
+                         "gates_per_s_per_shader_ghz": value / (0.1 * st["clk_shader_cycles"] / st["clk_ref_ticks"]) if st["clk_ref_ticks"] else None,
                          "other_blind_rotate_kernel": {"kernel": "blind_rotate4_kernel" if dom8 else "blind_rotate8_kernel",
                                                        "launches": int(on), "avg_launch_ms": oms / max(1, on),
                                                        "rotations_per_launch": orot / max(1, on)},
