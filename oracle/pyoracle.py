@@ -82,6 +82,9 @@ def lib():
         L.orc_not.argtypes = [C.POINTER(OrcParams), i32p, i32p]
         L.orc_constant.argtypes = [C.POINTER(OrcParams), i32p, C.c_int32]
         L.orc_gate2_batch.argtypes = [C.POINTER(OrcKeySet), C.c_int, i32p, i32p, i32p, C.c_int32, C.c_int32]
+        # fft_standin.c (use_ntt = 4): the AVX2 + FMA fp64-FFT stand-in for upstream's CPU path, not an oracle mode
+        L.orc_fft4_available.restype = C.c_int
+        L.orc_fft4_negacyclic.argtypes = [i32p, i32p, i32p, C.c_int32]
         _LIB = L
     return _LIB
 

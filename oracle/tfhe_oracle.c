@@ -17,6 +17,7 @@
  * tests/test_host_cpu.py checks that all three give the same words.
  */
 #include "tfhe_oracle.h"
+#include "fft_standin.h"
 
 #include <math.h>
 #include <pthread.h>
@@ -532,7 +533,7 @@ OrcKeySet *orc_keygen(const OrcParams *p, uint64_t seed) {
 
 void orc_keyset_free(OrcKeySet *ks) {
     if (!ks) return;
-    free(ks->lwe_key); free(ks->tlwe_key); free(ks->bk); free(ks->ksk); free(ks->bk_ntt); free(ks->bk_fast); free(ks->bk_fft);
+    free(ks->lwe_key); free(ks->tlwe_key); free(ks->bk); free(ks->ksk); free(ks->bk_ntt); free(ks->bk_fast); free(ks->bk_fft); free(ks->bk_fft4);
     free(ks);
 }
 
@@ -714,9 +715,14 @@ void orc_blind_rotate(const OrcKeySet *ks, const int32_t *bara, int32_t barb,
     memset(acc, 0, sizeof(Torus32) * (size_t)k * N);
     if (barb != 0) mul_xai(acc + (size_t)k * N, 2 * N - barb, tv, N);
     else memcpy(acc + (size_t)k * N, tv, sizeof(Torus32) * N);
-    for (int32_t i = 0; i < n; ++i) {
-        if (bara[i] == 0) continue;
-        orc_cmux_rotate(ks, i, bara[i], acc, use_ntt);
+    if (use_ntt == 4) use_ntt = orc_fft4_available() ? 4 : 3;
+    if (use_ntt == 4) {
+        orc_fft4_blind_rotate_steps(ks, bara, acc);      /* the AVX2 + FMA stand-in (fft_standin.c), not an oracle mode */
+    } else {
+        for (int32_t i = 0; i < n; ++i) {
+            if (bara[i] == 0) continue;
+            orc_cmux_rotate(ks, i, bara[i], acc, use_ntt);
+        }
     }
     free(tv);
 }

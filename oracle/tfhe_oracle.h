@@ -71,6 +71,7 @@ typedef struct OrcKeySet {
     uint64_t *bk_ntt;    /* [n][(k+1)l][k+1][N]  Goldilocks NTT image of bk  */
     uint32_t *bk_fast;   /* [n][(k+1)l][k+1][2][N] two-prime Montgomery image  */
     double   *bk_fft;    /* [n][(k+1)l][k+1][re N/2 | im N/2] fp64 FFT image (use_ntt = 3 only) */
+    double   *bk_fft4;   /* the same image in the order of fft_standin.c's AVX2 transform, times 2/N; built on the first use of use_ntt = 4 */
 } OrcKeySet;
 
 OrcKeySet *orc_keygen(const OrcParams *p, uint64_t seed);
@@ -91,7 +92,9 @@ Torus32 orc_modswitch_to_torus(int32_t mu, int32_t Msize);
  * 3 = fp64 FFT, the way upstream TFHE multiplies (folded N/2-point complex transform):
  * APPROXIMATE, NOT the oracle -- low-order noise bits differ from the exact modes; it exists
  * only as a cost-faithful stand-in for upstream's CPU path in bench.py's cpu_baseline note
- * and is checked at decrypt level. */
+ * and is checked at decrypt level.
+ * 4 = the same fp64 FFT in AVX2 + FMA (fft_standin.c; what upstream's spqlios-fma flavour
+ * costs): APPROXIMATE, NOT the oracle; on a host without AVX2/FMA it runs as 3. */
 /* exact negacyclic product res = ip * tp mod (X^N+1) mod 2^32, schoolbook */
 void orc_negacyclic_schoolbook(Torus32 *res, const int32_t *ip, const Torus32 *tp, int32_t N);
 /* same product through the Goldilocks NTT (must equal the schoolbook)      */

@@ -107,6 +107,36 @@ def test_oracle_truth_tables_small_params(oracle):
     assert ks.decrypt(ks.constant(1))[0] == 1 and ks.decrypt(ks.constant(0))[0] == 0
 
 
+def test_avx2_fft_standin_decrypts_like_the_exact_evaluator(oracle, oks):
+    """use_ntt = 4 (oracle/fft_standin.c) is what bench.py times as the CPU comparator: an AVX2 + FMA fp64 FFT the way
+    upstream's spqlios-fma flavour multiplies.  It is NOT an oracle mode (approximate by construction); this pins it at the
+    level it is used at: the negacyclic product within rounding distance of the exact one at every ring size the bench
+    uses, and 1,024 P128 gates (four gate types) decrypting exactly like the two-prime evaluator, phases a hair apart."""
+    L = oracle.lib()
+    if not L.orc_fft4_available():
+        pytest.skip("host CPU without AVX2 + FMA: use_ntt = 4 runs as the scalar fp64 evaluator (3)")
+    rng = np.random.default_rng(11)
+    for N, half_bg in ((64, 64), (1024, 64), (1024, 512), (2048, 32)):
+        ip = rng.integers(-half_bg, half_bg, N, dtype=np.int32)
+        tp = rng.integers(-2**31, 2**31, N, dtype=np.int64).astype(np.int32)
+        exact, approx = np.zeros(N, np.int32), np.zeros(N, np.int32)
+        L.orc_negacyclic_schoolbook(oracle._p(exact), oracle._p(ip), oracle._p(tp), N)
+        L.orc_fft4_negacyclic(oracle._p(approx), oracle._p(ip), oracle._p(tp), N)
+        d = (exact.astype(np.int64) - approx.astype(np.int64) + 2**31) % 2**32 - 2**31
+        assert np.abs(d).max() <= 4, (N, half_bg, int(np.abs(d).max()))
+    r = oracle.Rng(29)
+    per_gate = 256
+    truth = {"AND": lambda a, b: a & b, "NAND": lambda a, b: 1 - (a & b), "XOR": lambda a, b: a ^ b, "OR": lambda a, b: a | b}
+    for name, f in truth.items():
+        ba, bb = rng.integers(0, 2, per_gate), rng.integers(0, 2, per_gate)
+        ca, cb = oks.encrypt(r, ba), oks.encrypt(r, bb)
+        fast = oks.gate_batch(name, ca, cb, nthreads=8, use_ntt=4)
+        exact = oks.gate_batch(name, ca, cb, nthreads=8, use_ntt=2)
+        assert (oks.decrypt(fast) == oks.decrypt(exact)).all() and (oks.decrypt(exact) == f(ba, bb)).all(), name
+        worst = max(abs(int(oks.phase(x)) - int(oks.phase(y))) for x, y in zip(fast[:32], exact[:32]))
+        assert worst < 2**12, (name, worst)
+
+
 def test_oracle_p128_gate_noise_margin(oracle, oks):
     """A P128 gate output is a fresh-looking encryption: phase within 1/16 of +-1/8."""
     r = oracle.Rng(17)
