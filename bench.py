@@ -45,141 +45,9 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
-HBM_PEAK_GBPS = 8000.0   # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E peak 8.0 TB/s (spec)
-
-
-def algorithmic_bytes(pp):
-    """bytes per blind rotate / key switch / ciphertext, no cross-gate reuse,
-    bootstrapping key counted at 8 B per coefficient (the density this engine stores: two
-    32-bit residues)."""
-    kpl = (pp.k + 1) * pp.l
-    a_br = pp.n * kpl * (pp.k + 1) * pp.N * 8
-    a_ks = pp.N * pp.k * pp.ks_t * (1.0 - 2.0 ** (-pp.ks_basebit)) * (pp.n + 1) * 4
-    ct = (pp.n + 1) * 4
-    return a_br, a_ks, ct
-
-
-def kernel_source_hash():
-    """Identifies the kernels a committed counter summary was measured on: every file kernels.hip is built from, the
-    generated key-switch statements and build.sh with its compile flags (peba1_amd/kernel_id.py)."""
-    from peba1_amd.kernel_id import kernels_sha16
-    return kernels_sha16()
-
-
-def committed_counters():
-    """HBM-side bytes per blind-rotate launch (separate --pmc FETCH_SIZE / WRITE_SIZE passes,
-    tools/pmc_summary.py) and the VALU-issue share of the blind-rotate kernel (SQ counters,
-    tools/sq_summary.py -> profiles/valu_blind_rotate.json).  Hardware counters cannot be read inside
-    this process, so the committed summaries are quoted -- and only when they were measured on
-    exactly the kernel sources that are running now; otherwise null."""
-    now = kernel_source_hash()
-    traffic, valu = None, None
-    for name in ("pmc_blind_rotate.json", "valu_blind_rotate.json"):
-        path = os.path.join(ROOT, "profiles", name)
-        if not os.path.exists(path):
-            continue
-        with open(path) as f:
-            j = json.load(f)
-        if j.get("kernels_sha16") != now:
-            continue
-        if name.startswith("pmc"):
-            traffic = j.get("hbm_bytes_per_launch")
-        else:
-            valu = {k: j[k] for k in ("valu_busy_frac", "valu_insts_per_wave_step", "source") if k in j}
-    return traffic, valu, now
-
-
-def committed_set_profile(name):
-    """The rocprofv3 summary of 4,096 independent gates under parameter set `name` (tools/gpu_profile_sets.sh ->
-    profiles/r05_set_profile_<name>.json): HBM-side traffic, VALU share, wave-cycle shares.  Quoted only while it was
-    measured on exactly the kernel sources running now."""
-    j = None
-    for rnd in ("r05", "r04"):                       # the newest summary measured on the kernels running now
-        path = os.path.join(ROOT, "profiles", f"{rnd}_set_profile_{name}.json")
-        if os.path.exists(path):
-            with open(path) as f:
-                cand = json.load(f)
-            if cand.get("kernels_sha16") == kernel_source_hash():
-                j = dict(cand, source_file=f"profiles/{rnd}_set_profile_{name}.json")
-                break
-    if j is None:
-        return None
-    keep = ("kernel", "avg_launch_ms", "hbm_bytes_per_launch", "hbm_side_GBps", "hbm_side_frac_of_8TBps", "traffic_over_algorithmic",
-            "valu_insts_per_wave_step", "valu_busy_frac", "wave_cycles_issuing", "wave_cycles_issue_stalled", "wave_cycles_parked",
-            "wave_cycles_lds_issue_stalled", "lds_conflict_share_of_active", "kernels_sha16", "source_file")
-    return {k: j[k] for k in keep if k in j}
-
-
-MI355X_CUS = 256        # /opt/skills/guides/MI355X_MICROARCH.md: 8 XCDs x 32 CUs, 4 SIMDs per CU
-
-
-def valu_issue_model():
-    """The roofline that binds: cycles one SIMD needs just to ISSUE the vector instructions of one
-    blind-rotate step, from two tracked files -- profiles/isa_mix.json (static instruction mix per wave and step of the
-    kernels as built, tools/isa_mix.py at build() time; quoted only while its kernels_sha16 is the running one) priced
-    with profiles/valu_issue_costs.json (measured issue cost per instruction class, tools/valu_rates*.hip).
-    Returns {kernel: {...}} or None."""
-    try:
-        with open(os.path.join(ROOT, "profiles", "isa_mix.json")) as f:
-            mix = json.load(f)
-        with open(os.path.join(ROOT, "profiles", "valu_issue_costs.json")) as f:
-            costs = json.load(f)["classes"]
-    except (OSError, ValueError, KeyError):
-        return None
-    if mix.get("kernels_sha16") != kernel_source_hash():
-        return None
-    out = {}
-    for name, k in mix["kernels"].items():
-        cycles, per_role, resident = 0.0, [], 0
-        for role in k["roles"]:
-            v = role["variants"][0]                         # the heaviest variant of the role (they differ in scalar code only)
-            resident += role["waves_per_simd"]
-        for role in k["roles"]:
-            v = role["variants"][0]
-            rate = "two_waves_per_simd" if resident >= 2 else "one_wave_per_simd"
-            c = sum(v[cls] * costs[cls][rate] for cls in ("mul", "three_operand", "two_operand"))
-            cycles += c * role["waves_per_simd"]
-            per_role.append({"role": role["role"], "waves_per_simd": role["waves_per_simd"], "gadget_rows": role["gadget_rows"],
-                             "valu": v["valu"], "mul": v["mul"], "three_operand": v["three_operand"], "two_operand": v["two_operand"],
-                             "lds": v["lds"], "barriers": v["barriers"], "issue_cycles_per_wave_step": c})
-        out[name] = {"l": k["l"], "insts_per_wave_step": per_role, "model_cycles_per_simd_step": cycles}
-    return out
-
-
-def valu_issue_block(gates4096, sweep):
-    """`roofline.valu_issue`: the model above beside what a step takes -- launch time x shader clock / rounds / steps of
-    the 4,096-gate launches (4-wave form: two workgroups per CU, 8 rounds; split form at N = 2048: one per CU, 16 rounds)
-    and of the 256-gate launch of the batch sweep (8-wave form: one round).  frac = model / measured <= 1: the share of a
-    step's cycles that the SIMD's vector issue port is busy by the issue-cost model; the rest is LDS issue, waits and
-    barrier skew."""
-    model = valu_issue_model()
-    if model is None:
-        return None
-    blk = {"files": ["profiles/isa_mix.json", "profiles/valu_issue_costs.json"], "kernels_sha16": kernel_source_hash(),
-           "costs_cycles_per_wave_instruction_two_waves_per_simd": {"mul": 5.4, "three_operand": 5.2, "two_operand": 3.0},
-           "kernels": model, "frac": None}
-
-    def measured(entry, name, n_steps, per_cu, gates):
-        if not entry or name not in model or not entry.get("shader_clock_ghz"):
-            return
-        rounds = -(-gates // (per_cu * MI355X_CUS))
-        cyc = entry["ms_blind_rotate"] * 1e-3 * entry["shader_clock_ghz"] * 1e9 / rounds / n_steps
-        m = model[name]
-        m.update({"measured_cycles_per_simd_step": cyc, "measured_on": f"{gates} independent gates, {rounds} round(s) of {per_cu} "
-                  f"workgroup(s) per CU, {n_steps} steps, {entry['ms_blind_rotate']:.3f} ms at {entry['shader_clock_ghz']:.3f} GHz",
-                  "frac": m["model_cycles_per_simd_step"] / cyc})
-    if gates4096:
-        measured(gates4096.get("P128"), "blind_rotate4_kernel<10,0,true>", 630, 2, 4096)
-        measured(gates4096.get("P80"), "blind_rotate4_kernel<10,0,false>", 500, 2, 4096)
-        measured(gates4096.get("P2048"), "blind_rotate_split_kernel<11,2>", 1024, 1, 4096)
-    if sweep:
-        measured(sweep.get("256"), "blind_rotate8_kernel<10,true>", 630, 1, 256)
-    head = model.get("blind_rotate4_kernel<10,0,true>", {})
-    blk["frac"] = head.get("frac")
-    blk["insts_per_wave_step"] = head.get("insts_per_wave_step")
-    blk["model_cycles_per_simd_step"] = head.get("model_cycles_per_simd_step")
-    blk["measured_cycles_per_simd_step"] = head.get("measured_cycles_per_simd_step")
-    return blk
+# everything that is not the timed region or the CPU baseline lives in benchkit/ (roofline models and committed counter
+# summaries; the N > 1 launcher, the transport negotiation, the evidence of who took part; the untimed extra workloads)
+from benchkit.roofline import HBM_PEAK_GBPS, algorithmic_bytes, committed_counters, valu_issue_block   # noqa: E402
 
 
 def host_cpu_width():
@@ -264,117 +132,6 @@ def cpu_baseline(seed):
                     "parity oracle.  exact_port_value = the parity oracle (exact two-prime NTT, scalar C)."}
 
 
-def self_launch(n):
-    """The parent of `python bench.py --gpus N` (N > 1, no WORLD_SIZE in the environment): starts
-    `python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py <same arguments>` as a CHILD process
-    (subprocess; no exec, and this process never initialises the GPU), rendezvous on the loopback address at a free port,
-    relays the children's output (rank 0's JSON line last, on stdout) and returns the launcher's exit code -- non-zero
-    if any rank failed."""
-    import socket
-    import subprocess
-    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as sock:
-        sock.bind(("127.0.0.1", 0))
-        port = sock.getsockname()[1]
-    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
-    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")          # dmabuf IPC: what RCCL needs on this driver
-    env.setdefault("OMP_NUM_THREADS", "1")
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}",
-           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
-    proc = subprocess.Popen(cmd, env=env, cwd=ROOT, stdout=subprocess.PIPE, text=True, bufsize=1)
-    line_json = None
-    for line in proc.stdout:
-        if line.startswith("{") and line.rstrip().endswith("}"):
-            line_json = line
-        else:
-            sys.stderr.write(line)                              # launcher chatter, other ranks' prints
-    rc = proc.wait()
-    if line_json is not None:
-        sys.stdout.write(line_json)
-        sys.stdout.flush()
-    if rc == 0 and line_json is None:
-        sys.stderr.write("bench.py: the ranks exited cleanly but rank 0 printed no JSON line\n")
-        rc = 1
-    return rc
-
-
-def make_comm(pd, api, dist, torch, pp, args, xdev, rank, world):
-    """The communicator of the exchange, agreed on by every rank.  --transport auto (default): libpeba1-dist's own RCCL
-    communicator, the collectives enqueued on the library's stream ("cuda"); made, then tried with ONE one-sample gather
-    before anything is timed.  If any rank cannot make it or the trial fails (the ranks agree through the torch group),
-    every rank falls back to the host transport of the same C library carried by torch's own RCCL communicator
-    ("torch-cuda": device tensors through torch.distributed) -- slower per exchange (a host wait, two copies), the same
-    ciphertexts -- and the line says which one ran (`dist.transport`).  A first contact with an 8-GPU node must produce a
-    measurement either way.  gloo rehearsals use the host transport on host tensors ("cpu")."""
-    if xdev == "cpu" and args.transport != "torch":
-        return pd.Comm(dist, torch, "cpu"), "host callbacks over torch.distributed (gloo)", None
-
-    def attempt(kind):
-        comm, why = None, None
-        try:
-            comm = pd.Comm(dist, torch, kind)
-            comm.set_timeout(120)                               # a trial that hangs ends the job with a message, soon
-            mine = api.CiphertextArray(pp, 1)
-            everyone = api.CiphertextArray(pp, world) if rank == 0 else None
-            pd.gather_samples(comm, everyone.ptr if rank == 0 else None, mine.ptr, 1, pp.ptr)
-            api.wait()
-            if rank == 0:
-                assert (everyone.words() == mine.words()[0]).all(), "the trial gather moved the wrong words"
-            comm.set_timeout(float(os.environ.get("PEBA1_DIST_TIMEOUT_S", "600")))
-        except Exception as e:                                  # noqa: BLE001 -- any failure of the trial means "not this transport"
-            why = f"rank {rank}: {type(e).__name__}: {e}"
-        ok = torch.tensor([0 if why else 1], dtype=torch.int32, device="cuda")
-        dist.all_reduce(ok, op=dist.ReduceOp.MIN)
-        if int(ok.item()) == 1:
-            return comm, None
-        reasons = [None] * world
-        dist.all_gather_object(reasons, why)
-        if comm is not None:
-            try:
-                comm.close()
-            except Exception:                                   # noqa: BLE001
-                pass
-        return None, "; ".join(r for r in reasons if r) or "a rank reported failure"
-    if args.transport in ("auto", "rccl"):
-        comm, why = attempt("cuda")
-        if comm is not None:
-            return comm, "rccl: libpeba1-dist's own communicator, collectives on the library's stream", None
-        if args.transport == "rccl":
-            raise SystemExit(f"--transport rccl: {why}")
-        if rank == 0:
-            print(f"bench.py: libpeba1-dist's own RCCL communicator is not usable here ({why}); falling back to torch's", file=sys.stderr)
-        fallback_reason = why
-    else:
-        fallback_reason = "--transport torch"
-    comm, why = attempt("torch-cuda")
-    if comm is None:
-        raise SystemExit(f"no usable transport: {why}")
-    return comm, "torch.distributed device tensors (torch's RCCL communicator) behind libpeba1-dist's host transport", fallback_reason
-
-
-def dist_evidence(dist, L, comm, args, world, rank, local_rank):
-    """Who took part: every rank's PCI bus id as libtfhe-hip reports it for the device it runs on (all-gathered), the RCCL
-    version libpeba1-dist opened, what the communicator has done.  N ranks on N distinct bus ids = N GPUs."""
-    import socket
-    buf = ctypes.create_string_buffer(64)
-    L.tfhe_hip_device_pci_bus_id(buf, 64)
-    mine = {"rank": rank, "local_rank": local_rank, "device": int(L.tfhe_hip_get_device()), "pci_bus_id": buf.value.decode(),
-            "host": socket.gethostname(), "pid": os.getpid(),
-            "collectives": comm.counters() if comm is not None else None}
-    everyone = [None] * world
-    dist.all_gather_object(everyone, mine)
-    if rank != 0:
-        return None
-    from peba1_amd import dist as pd
-    ids = [e["pci_bus_id"] for e in everyone]
-    c0 = everyone[0]["collectives"] or {}
-    return {"backend": "rccl" if args.backend == "nccl" else "gloo (host-memory rehearsal on shared GPUs; not a measurement)",
-            "torch_backend": dist.get_backend(), "world": world,
-            "rccl_version": pd.load().peba1_dist_rccl_version() if args.backend == "nccl" else None,
-            "devices": ids, "distinct_devices": len(set(ids)), "one_gpu_per_rank": len(set(ids)) == world,
-            "status_word_collectives": c0.get("status_word_exchanges"), "data_collectives": {k: c0.get(k) for k in ("gathers", "broadcasts")},
-            "library_transport": c0.get("transport"), "ranks": everyone}
-
-
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -422,6 +179,7 @@ def main():
         # `python bench.py --gpus N` with no launcher: THIS process becomes the launcher and nothing else -- it has not
         # loaded libtfhe-hip, torch.cuda or any HIP library and never will (a process that has touched the GPU must not
         # start or become another one on this pool), starts one fresh process per GPU and relays rank 0's line
+        from benchkit.launch import self_launch       # (imports nothing that touches the GPU)
         raise SystemExit(self_launch(args.gpus))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -458,6 +216,8 @@ def main():
 
     from peba1_amd import api, circuits, identify, lib
     from peba1_amd import dist as pd
+    from benchkit.extras import extras, weak_scaling_leg
+    from benchkit.launch import dist_evidence, make_comm
     L = lib.load()
     L.tfhe_hip_set_device(local_rank)
     seed = 0x5EBA2
@@ -490,7 +250,7 @@ def main():
     if mode == "match":
         tmpl_vals = base if rank == 0 else identify.synthetic_template(base, rank)
         tmpl = circuits.EncryptedVector(pp, tmpl_vals, bitsize, ks).to_device()
-        comm, transport, transport_fallback = make_comm(pd, api, dist, torch, pp, args, xdev, rank, world) if use_dist else (None, None, None)
+        comm, transport, transport_fallback = make_comm(pd, api, dist, torch, pp, args, xdev, rank, world, local_rank) if use_dist else (None, None, None)
         all_bits = api.CiphertextArray(pp, world) if use_dist and rank == 0 else None
 
         def step():
@@ -530,7 +290,7 @@ def main():
         tmpl = circuits.EncryptedVector(pp, tmpl_vals, bitsize, ks).to_device()
         S = [a.ptr for a in probe.slots]
         T = [a.ptr for a in tmpl.slots]
-        comm, transport, transport_fallback = make_comm(pd, api, dist, torch, pp, args, xdev, rank, world) if use_dist else (None, None, None)
+        comm, transport, transport_fallback = make_comm(pd, api, dist, torch, pp, args, xdev, rank, world, local_rank) if use_dist else (None, None, None)
         phase_ms = {"ranks": [], "combine": []}
 
         def step():
@@ -720,7 +480,11 @@ def main():
                          "ms_blind_rotate_per_step": st["ms_blind_rotate"] / steps,
                          "ms_keyswitch_per_step": st["ms_keyswitch"] / steps},
         }
-        out["roofline"]["valu_issue"] = valu_issue_block(None, None)      # the model alone; the single-GPU extras add the measured side
+        # the binding roofline, for the kernel that dominates THIS run: at N = 1 the single-GPU extras below add the measured
+        # side of the 4-wave kernel (4,096 independent gates); where the 8-wave kernel dominates (N > 1: every level of a rank's
+        # share is narrow) the measured side is that kernel's launches of the timed steps themselves -- one round each
+        clock = 0.1 * st["clk_shader_cycles"] / st["clk_ref_ticks"] if st["clk_ref_ticks"] else None
+        out["roofline"]["valu_issue"] = valu_issue_block(None, None, {"ms": ms8, "launches": n8, "shader_clock_ghz": clock} if dom8 else None)
         if mode == "sharded" and world == 1 and phase_ms["combine"]:
             # what the same phases would take with one GPU per rank: the slowest rank's partial sum, then
             # rank 0's combine (the gather of 24 x 2.5 KB per rank is microseconds) -- a projection from
@@ -757,274 +521,6 @@ def main():
         dist.barrier()
         dist.destroy_process_group()
     ks.close()
-
-
-def weak_scaling_leg(api, circuits, identify, dist, torch, pp, ks, probe, bound, base, bitsize, rank, world, M, group, xdev,
-                     plain_bit, comm):
-    """Every rank: M independent matches of the probe against templates of its own, `group` per (pipelined) flush --
-    libpeba1-dist's peba1_identify, which also gathers the match bits to rank 0.  Same tunings as the timed steps (every
-    recorded gate executed).  Returns rank 0's summary (None elsewhere)."""
-    tv = [identify.synthetic_template(base, rank * M + m + 1) for m in range(M)]
-    if rank == 0:
-        tv[M // 2] = base                                   # the genuine template: the only match bit 0
-    templates = [circuits.EncryptedVector(pp, t, bitsize, ks).to_device() for t in tv]
-    all_bits = api.CiphertextArray(pp, world * M) if rank == 0 else None
-    # ONE encrypted probe: rank 0's ciphertexts reach every rank (peba1_dist_broadcast_samples: 128 x 8 samples, 2.6 MB)
-    from peba1_amd import dist as pd
-    pd.broadcast_vector(comm, pp, ks, probe, root=0)
-    identify.identify(pp, ks, probe, templates[:min(group, M)], bound, bitsize, group=group)       # warm-up group
-    api.wait()
-    dist.barrier()
-    if xdev == "cuda":
-        torch.cuda.synchronize()
-    api.reset_stats()
-    t0 = time.perf_counter()
-    bits = identify.identify(pp, ks, probe, templates, bound, bitsize, group=group, comm=comm, all_bits=all_bits)
-    api.wait()
-    dist.barrier()
-    if xdev == "cuda":
-        torch.cuda.synchronize()
-    dt = time.perf_counter() - t0
-    st = api.stats()
-    tt = torch.tensor([dt], dtype=torch.float64, device=xdev)
-    dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-    rr = torch.tensor([float(st["blind_rotates"])], dtype=torch.float64, device=xdev)
-    dist.all_reduce(rr, op=dist.ReduceOp.SUM)
-    got = [int(b) for b in bits.decrypt(ks)]
-    assert got == [plain_bit(t) for t in tv], f"rank {rank}: identification bits {got}"
-    if rank != 0:
-        return None
-    gathered = [int(b) for b in all_bits.decrypt(ks)]
-    assert gathered[:M] == got and gathered.count(0) == 1, f"gathered match bits {gathered}"
-    total = float(rr.item()) / float(tt.item())
-    return {"gates_per_s_all_ranks": total, "per_gpu": total / world, "matches_per_gpu": M, "group": group,
-            "seconds": float(tt.item()), "n_gpus": world, "scaling": "weak",
-            "checked": f"all {M} decrypted match bits per rank == plaintext rule; the {world * M} gathered bits on rank 0 hold exactly "
-                       "one 0 (the genuine template)",
-            "note": "independent matches per GPU (1-to-N identification, BASELINE configs[3]) through peba1_identify: rank 0's "
-                    "encrypted probe broadcast to every rank, no data-path collective, one gather of the match bits; timed on "
-                    "its own after the strong-scaling steps"}
-
-
-def extras(api, circuits, identify, lib, pd, pp, ks, probe, tmpl, bound, base, probe_vals, bitsize, plain_bit, last):
-    """Untimed-by-the-contract extra workloads of the single-GPU run (each timed on its own)."""
-    import random
-    out = {}
-    L = lib.load()
-    # the same match with the library default: identical pending gates evaluated once
-    api.set_tuning("reuse_gates", 1)
-    api.reset_stats()
-    t = time.perf_counter()
-    rbg = api.CiphertextArray(pp, 3 * bitsize)
-    circuits.function_f(rbg, probe, tmpl, bound, bitsize, ks)
-    api.flush()
-    t = time.perf_counter() - t
-    s = api.stats()
-    assert (rbg.words() == last.words()).all()          # the same ciphertexts, word for word
-    out["match_with_gate_sharing"] = {"match_ms": t * 1e3, "blind_rotates": int(s["blind_rotates"]),
-                                      "gates_shared": int(s["reused_gates"])}
-    # ... and with every library default (gate sharing + dead-gate elimination: what an unmodified caller gets)
-    api.set_tuning("eliminate_dead", 1)
-    api.reset_stats()
-    t = time.perf_counter()
-    rbd = api.CiphertextArray(pp, 3 * bitsize)
-    circuits.function_f(rbd, probe, tmpl, bound, bitsize, ks)
-    api.flush()
-    t = time.perf_counter() - t
-    s = api.stats()
-    assert (rbd.words() == last.words()).all()
-    out["match_library_defaults"] = {"match_ms": t * 1e3, "blind_rotates": int(s["blind_rotates"]),
-                                     "gates_shared": int(s["reused_gates"]), "gates_dropped_as_dead": int(s["dead_gates"])}
-    api.set_tuning("eliminate_dead", 0)
-    api.set_tuning("reuse_gates", 0)
-    # BASELINE configs[3] shape, small: one probe against 4 templates in one flush
-    tv = [identify.synthetic_template(base, k) for k in range(4)]
-    templates = [tmpl] + [circuits.EncryptedVector(pp, v, bitsize, ks).to_device() for v in tv[1:]]
-    api.reset_stats()
-    t = time.perf_counter()
-    bits = identify.identify(pp, ks, probe, templates, bound, bitsize, group=4)
-    api.wait()                                   # peba1_identify leaves its last group in flight
-    t = time.perf_counter() - t
-    s = api.stats()
-    assert [int(b) for b in bits.decrypt(ks)] == [plain_bit(v) for v in tv]
-    out["identify_4_matches_one_flush"] = {"matches": 4, "gates_per_s": s["blind_rotates"] / t, "seconds": t,
-                                           "levels": int(s["levels"])}
-    del templates
-    # BASELINE configs[2] on one device: a 256-slot match, whole and slot-sharded over 8 logical ranks
-    import torch
-    b256 = [((37 * i + 11) % 255) or 1 for i in range(256)]
-    p256 = [v + 1 for v in b256]
-    T256 = circuits.EncryptedVector(pp, b256, bitsize, ks).to_device()
-    S256 = circuits.EncryptedVector(pp, p256, bitsize, ks).to_device()
-    api.reset_stats()
-    t = time.perf_counter()
-    rb = api.CiphertextArray(pp, 3 * bitsize)
-    circuits.function_f(rb, S256, T256, bound, bitsize, ks)
-    api.flush()
-    t = time.perf_counter() - t
-    s = api.stats()
-    assert int(rb.decrypt(ks)[0]) == 0                               # distance 256 is not > 256
-    out["match_256_slots"] = {"match_ms": t * 1e3, "blind_rotates": int(s["blind_rotates"]), "levels": int(s["levels"]),
-                              "gates_per_s": s["blind_rotates"] / t}
-    import ctypes as C
-    S_ptr, T_ptr = [a.ptr for a in S256.slots], [a.ptr for a in T256.slots]
-    for fast, name in ((False, "match_256_slots_sharded_8_logical_ranks"), (True, "match_256_slots_sharded_8_logical_ranks_latency_form")):
-        # the C phases of libpeba1-dist one logical rank after the other (fast: PEBA1_DIST_FAST_PARTIAL, the
-        # depth-optimised per-rank circuit -- not the reference's gate sequence; both use the prefix combine)
-        api.reset_stats()
-        t = time.perf_counter()
-        parts, rank_ms = [], []
-        for r in range(8):
-            lo, hi = pd.shard_slots(256, 8, r)
-            tr = time.perf_counter()
-            parts.append(pd.local_partial_packed(ks.cloud, pp.words, S_ptr[lo:hi], T_ptr[lo:hi], bitsize, fast=fast))
-            rank_ms.append((time.perf_counter() - tr) * 1e3)
-        tr = time.perf_counter()
-        res = pd.combine_packed(L, pp.ptr, ks.cloud, parts, bound.ptr, fast=True)
-        api.flush()
-        combine_ms = (time.perf_counter() - tr) * 1e3
-        t = time.perf_counter() - t
-        s = api.stats()
-        assert L.bootsSymDecrypt(C.cast(res, lib.LS), ks.ptr) == 0
-        L.delete_gate_bootstrapping_ciphertext_array(24, C.cast(res, lib.LS))
-        out[name] = {"match_ms": t * 1e3, "blind_rotates": int(s["blind_rotates"]), "levels": int(s["levels"]),
-                     "flushes": int(s["flushes"]), "gates_per_s": s["blind_rotates"] / t,
-                     "per_rank_phase_ms_max": max(rank_ms), "combine_ms": combine_ms,
-                     "projected_match_ms_one_gpu_per_rank": max(rank_ms) + combine_ms,
-                     "note": "logical ranks timed on one device; the projection is not a multi-GPU measurement"}
-    del T256, S256
-    # BASELINE.json's literal wording: a 128-BIT template under Hamming distance + threshold
-    # (peba1_hamming_match; not in the reference, SURVEY.md 8f.4)
-    rnd = random.Random(7)
-    ta, tb = rnd.getrandbits(128), rnd.getrandbits(128)
-    w = circuits.hamming_count_bits(128)
-    A = circuits.encrypt_number(pp, ta, 128, ks); A.set_words(A.words())
-    Bv = circuits.encrypt_number(pp, tb, 128, ks); Bv.set_words(Bv.words())
-    hb = circuits.encrypt_number(pp, 40, w, ks)
-    api.reset_stats()
-    t = time.perf_counter()
-    rbh = api.CiphertextArray(pp, w)
-    circuits.hamming_match(rbh, A, Bv, 128, hb, ks)
-    api.flush()
-    t = time.perf_counter() - t
-    s = api.stats()
-    assert int(rbh.decrypt(ks)[0]) == (1 if bin(ta ^ tb).count("1") > 40 else 0)
-    out["hamming128_match"] = {"match_ms": t * 1e3, "blind_rotates": int(s["blind_rotates"]),
-                               "levels": int(s["levels"]), "gates_per_s": s["blind_rotates"] / t}
-    out["independent_gates_4096"] = independent_gates(api, lib, 4096)
-    out["independent_gates_sweep"] = independent_gates_sweep(api, lib)
-    # the same 128-slot match through the optimised DAG (peba1_function_f_fast; not the reference's
-    # gate sequence, SURVEY.md 8f.3) -- same match bit, fewer and shallower gates
-    api.reset_stats()
-    t = time.perf_counter()
-    rbf = api.CiphertextArray(pp, 3 * bitsize)
-    circuits.function_f_fast(rbf, probe, tmpl, bound, bitsize, ks)
-    api.flush()
-    t = time.perf_counter() - t
-    s = api.stats()
-    assert int(rbf.decrypt(ks)[0]) == int(last.decrypt(ks)[0])
-    out["optimised_dag_match"] = {"match_ms": t * 1e3, "blind_rotates": int(s["blind_rotates"]),
-                                  "levels": int(s["levels"]), "gates_per_s": s["blind_rotates"] / t}
-    return out
-
-
-def independent_gates(api, lib, G):
-    """SURVEY 8(d)'s microbenchmark inside the driver-run line: G independent bootsAND on fresh encryptions of
-    random bits, one launch, for the three parameter sets (P128 = the headline's; P80 = tfhe's legacy set;
-    P2048 = BASELINE configs[4]).  Blind-rotate launch time from HIP events; the fraction is algorithmic bytes
-    per second over the 8 TB/s HBM peak (SURVEY 8d's table)."""
-    import numpy as np
-    L = lib.load()
-    res = {}
-    was = api.get_deferred()
-    api.set_deferred(False)
-    try:
-        for name, make in (("P128", lambda: api.ParameterSet(128)), ("P80", lambda: api.ParameterSet(80)),
-                           ("P2048", lambda: api.ParameterSet(p2048=True))):
-            pq = make()
-            kq = api.SecretKeySet(pq, 0x5EBA2)
-            rng = np.random.default_rng(11)
-            xa, xb = rng.integers(0, 2, G), rng.integers(0, 2, G)
-            A = api.CiphertextArray(pq, G).encrypt(xa, kq)
-            B = api.CiphertextArray(pq, G).encrypt(xb, kq)
-            A.set_words(A.words()); B.set_words(B.words())            # resident in HBM
-            R = api.CiphertextArray(pq, G)
-            api.gate_batch("AND", R, A, B, kq)                         # warm-up launch
-            best = None
-            for _ in range(3):
-                api.reset_stats()
-                t = time.perf_counter()
-                api.gate_batch("AND", R, A, B, kq)
-                t = time.perf_counter() - t
-                s = api.stats()
-                if best is None or s["ms_blind_rotate"] < best[0]["ms_blind_rotate"]:
-                    best = (s, t)
-            s, t = best
-            sample = R.decrypt(kq)[:64]
-            assert list(sample) == [int(x & y) for x, y in zip(xa[:64], xb[:64])], name
-            a_br, a_ks, _ = algorithmic_bytes(pq)
-            rps = G / (s["ms_blind_rotate"] * 1e-3)
-            res[name] = {"n": pq.n, "N": pq.N, "l": pq.l, "Bgbit": pq.Bgbit, "gates": G,
-                         "ms_blind_rotate": s["ms_blind_rotate"], "ms_keyswitch": s["ms_keyswitch"],
-                         "rotations_per_s_blind_rotate_only": rps,
-                         "gates_per_s_with_keyswitch": G / ((s["ms_blind_rotate"] + s["ms_keyswitch"]) * 1e-3),
-                         "roofline_frac_algorithmic": rps * a_br / (HBM_PEAK_GBPS * 1e9),
-                         "shader_clock_ghz": 0.1 * s["clk_shader_cycles"] / s["clk_ref_ticks"] if s["clk_ref_ticks"] else None,
-                         "checked": "64 decrypted outputs == a AND b",
-                         # rocprofv3 evidence of the same launch (kernel trace, FETCH_SIZE / WRITE_SIZE, SQ counters), quoted
-                         # while it was measured on the kernel sources running now: profiles/r04_set_profile_<set>.json
-                         "rocprof": committed_set_profile(name)}
-            del A, B, R
-            kq.close()
-    finally:
-        api.set_deferred(was)
-    return res
-
-
-def independent_gates_sweep(api, lib, sizes=(1, 16, 256, 1024, 4096)):
-    """SURVEY 8(d)'s batch-size sweep, driver-visible: G independent bootsAND per launch under P128 (the one-gate-per-call
-    site /root/reference/src/Math.cpp:34-43 is G = 1), blind-rotate and key-switch launch times from HIP events."""
-    import numpy as np
-    res = {}
-    was = api.get_deferred()
-    api.set_deferred(False)
-    try:
-        pq = api.ParameterSet(128)
-        kq = api.SecretKeySet(pq, 0x5EBA2)
-        rng = np.random.default_rng(13)
-        G = max(sizes)
-        xa, xb = rng.integers(0, 2, G), rng.integers(0, 2, G)
-        A = api.CiphertextArray(pq, G).encrypt(xa, kq)
-        B = api.CiphertextArray(pq, G).encrypt(xb, kq)
-        wa, wb = A.words(), B.words()
-        a_br, _, _ = algorithmic_bytes(pq)
-        for g in sizes:
-            a = api.CiphertextArray(pq, g); b = api.CiphertextArray(pq, g); r = api.CiphertextArray(pq, g)
-            a.set_words(wa[:g]); b.set_words(wb[:g])
-            api.gate_batch("AND", r, a, b, kq)
-            best = None
-            for _ in range(3):
-                api.reset_stats()
-                t = time.perf_counter()
-                api.gate_batch("AND", r, a, b, kq)
-                t = time.perf_counter() - t
-                s = api.stats()
-                if best is None or s["ms_blind_rotate"] < best[0]["ms_blind_rotate"]:
-                    best = (s, t)
-            s, t = best
-            assert list(r.decrypt(kq)[:16]) == [int(x & y) for x, y in zip(xa[:min(g, 16)], xb[:min(g, 16)])]
-            rps = g / (s["ms_blind_rotate"] * 1e-3)
-            res[str(g)] = {"ms_blind_rotate": s["ms_blind_rotate"], "ms_keyswitch": s["ms_keyswitch"], "ms_wall": t * 1e3,
-                           "rotations_per_s_blind_rotate_only": rps, "gates_per_s_wall": g / t,
-                           "roofline_frac_algorithmic": rps * a_br / (HBM_PEAK_GBPS * 1e9),
-                           "shader_clock_ghz": 0.1 * s["clk_shader_cycles"] / s["clk_ref_ticks"] if s["clk_ref_ticks"] else None,
-                           "kernel": "blind_rotate8_kernel" if s["br8_launches"] else "blind_rotate4_kernel"}
-            del a, b, r
-        del A, B
-        kq.close()
-    finally:
-        api.set_deferred(was)
-    return res
 
 
 if __name__ == "__main__":

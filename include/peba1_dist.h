@@ -62,6 +62,15 @@ int peba1_dist_rccl_version(void);
 int peba1_dist_transport(const Peba1Comm *comm);
 /* out4 = {status-word exchanges, gathers, broadcasts, payload bytes this rank sent} since the communicator was made */
 void peba1_dist_counters(const Peba1Comm *comm, uint64_t out4[4]);
+/* how the status words of the RCCL transport travel: 2 = on a communicator of their own (ncclCommSplit of the data
+ * communicator, made with this one) and a stream of their own -- they wait neither for the gates in flight nor for the
+ * previous data collective; 1 = on the data communicator and the provider's stream (the loaded RCCL has no ncclCommSplit,
+ * the split failed, or PEBA1_DIST_NO_STATUS_COMM is set): ordered by the stream, behind the gates; 0 = host transport (the
+ * word rides in front of the payload) */
+int peba1_dist_status_channel(const Peba1Comm *comm);
+/* out2 = {collectives this communicator has issued, rolling hash of their (kind, words per rank, root) in issue order}:
+ * equal on every rank of a job iff every rank issued the same collectives in the same order */
+void peba1_dist_sequence(const Peba1Comm *comm, uint64_t out2[2]);
 
 /* flags */
 #define PEBA1_DIST_FAST_COMBINE 1   /* rank 0: carry-save compressor + prefix adder + prefix comparator

@@ -147,40 +147,23 @@ void tfhe_hip_set_diag_label(const char *label);
 int tfhe_hip_gate_batch(int gate, LweSample *result, const LweSample *a, const LweSample *b,
                         int32_t count, const TFheGateBootstrappingCloudKeySet *bk);
 
-/* ---- tuning (results never depend on these) ----
- * "br4_max_rotations": launches of at most this many blind rotations use the
- * 4-wave kernel (one wave per prime and input polynomial) instead of the 2-wave
- * kernel (one wave per prime); default 2^30 = always, env TFHE_HIP_BR4_MAX; 0 = never.
- * "br_variant": which form of the blind-rotate kernel runs (env TFHE_HIP_BR_VARIANT): -1 (default) =
- * the fastest measured for the ring size (N = 1024: 4 waves per rotation, wide; N = 2048: split),
- * 0 = 4 waves wide (N = 2048: lean), 1 = 4 waves lean, 2 = split (8 waves, every transform as two
- * half-size ones).  "br8_max_rotations": launches of at most min(this, CU count) rotations use the
- * 8-wave form at N = 1024 (default 2^30, env TFHE_HIP_BR8_MAX; 0 = never).  "br_digit_table": 1
- * (default, env TFHE_HIP_BR_TABLE) = products of gadget digits with the first twiddles come from
- * LDS tables where the digits are at most 7 bits wide (split form: 2 = the stage-0 table only).
- * "ks_target_blocks": a launch's key switches are each cut into 2^s <= 32 ranges of
- * input coefficients until about this many workgroups exist (default 32768, env
- * TFHE_HIP_KS_BLOCKS); 0 disables splitting.
- * "ks_tile": 16 (default), 24 ("ks_branch" 2 only; elsewhere read as 16) or 32 = launches of at least 2*tile key switches use the tiled
- * kernel (a workgroup streams the KSK rows of one range once for `tile` gates); 0 = always
- * one workgroup per (gate, range); env TFHE_HIP_KS_TILE.
- * "ks_narrow": 1 = in the tiled kernel a thread owns 2 words of the output row instead of 4 (five light waves per
- * workgroup at n = 630 instead of three heavy ones); 0 (default) = 4 words per thread.  Measured slower (126 against 111 ms
- * per match: twice the LDS instructions for the same bytes); kept selectable and tested; env TFHE_HIP_KS_NARROW.
- * "ks_pipe": 1 (default) = the tiled kernel issues the LDS reads of the next pair of gates before it subtracts the current
- * pair's rows and waits for "all but the last eight" (105 against 111.5 ms per match); 0 = sixteen reads, then one wait;
- * env TFHE_HIP_KS_PIPE.
- * "ks_branch": register forms of the tiled kernel -- a thread keeps its 16-byte column of the three rows of a digit position
- * in registers (loaded straight from global memory a position ahead), no LDS read per subtraction: 2 (default) = pinned
- * registers addressed through the VGPR index mode by the wave-uniform digit (tiles of 16, 24 or 32; 60.8 ms per match
- * against 105 ms of the LDS-strip form); 1 = scalar branches on the digit (73 ms); 0 = the LDS-strip form ("ks_pipe",
- * "ks_narrow" apply to it); ignored with "ks_atomic"; env TFHE_HIP_KS_BRANCH.
- * "ks_atomic": 1 = the ranges of a split key switch add their partial sums into the zeroed destination
- * slot with 32-bit atomic adds (no partial-sum buffer, no reduce launch); 0 (default) = partial sums + reduce;
- * env TFHE_HIP_KS_ATOMIC.  Integer adds commute: the same words either way.
- * "br_fair": k > 0 (env TFHE_HIP_BR_FAIR) = in launches that put two blind-rotate workgroups on a CU, the two swap
- * wave issue priority every 2^k shader cycles; 0 (default since round 5) = the kernel's own progress priority alone (a
- * wave's issue priority follows its progress through the blind-rotate step; measured faster than the time slices).
+/* ---- tuning (results never depend on these; ten names) ----
+ * "br_variant": which form of the blind-rotate kernel runs wide launches (env TFHE_HIP_BR_VARIANT): -1 (default) =
+ * the fastest measured for the ring size (N = 1024: 4 waves per rotation; N = 2048: split), 0 = 4 waves (N = 1024),
+ * 2 = split (8 waves, every transform as two half-size ones), 4 = 2 waves (N = 1024; the form with the widest admissible
+ * gadget range).  A form whose bounds do not admit the key's gadget is replaced by one that does (br_forms.hpp).
+ * "br8_max_rotations": launches of at most min(this, CU count) rotations use the 8-wave form at N = 1024 (default 2^30,
+ * env TFHE_HIP_BR8_MAX; 0 = never).
+ * "br_tail8": 1 (default, env TFHE_HIP_BR_TAIL8) = the last, at most half-filled round of a wide 4-wave launch runs on the
+ * 8-wave form as a second launch.
+ * "br_digit_table": 1 (default, env TFHE_HIP_BR_TABLE) = products of gadget digits with the first twiddles come from
+ * LDS tables where the digits are at most 7 bits wide (split form: 2 = the stage-0 table only); 0 = multiplies.
+ * "ks_tile": 16 (default), 24 or 32 (index form only; elsewhere read as 16) = launches of at least 2*tile key switches use
+ * a tiled kernel (a workgroup streams the KSK rows of one range once for `tile` gates); 0 = always one workgroup per
+ * (gate, range); env TFHE_HIP_KS_TILE.
+ * "ks_index": 1 (default, env TFHE_HIP_KS_INDEX) = the tiled kernel keeps a thread's 16-byte column of the three rows of a
+ * digit position in pinned registers addressed through the VGPR index mode by the wave-uniform digit (56 ms of key switch
+ * per match); 0 = the rows in thread-private LDS strips (105 ms; plain HIP source).
  * "reuse_gates": 1 (default) = in deferred mode a gate recorded again with the same operand
  * samples before the flush shares the pending gate's result instead of being evaluated again
  * (same function of the same ciphertexts, so the same words); 0 = evaluate every call.
@@ -190,6 +173,8 @@ int tfhe_hip_gate_batch(int gate, LweSample *result, const LweSample *a, const L
  * "balance_levels": 1 (default) = slack-aware level filling at flush, 0 = plain ASAP
  * levels.
  * "sync_deadline_ms": see "bounded host waits" above.
+ * (Environment only: TFHE_HIP_KS_BLOCKS / TFHE_HIP_KS_MAX_SPLITS / TFHE_HIP_KS_SPLIT_TIES, how key switches are cut into
+ * coefficient ranges -- engine.hpp.)
  * Returns 0, or -1 for an unknown name. */
 int tfhe_hip_set_tuning(const char *name, int64_t value);
 
@@ -226,25 +211,27 @@ void tfhe_hip_reset_stats(void);
 /* when on, every kernel launch is bracketed by HIP events, read back after the flush */
 void tfhe_hip_set_kernel_timing(int on);
 
-/* ---- host-logic test entry: does blind-rotate kernel form `form` (0 = 4 waves wide, 1 = 4 waves lean, 2 = split,
- * 3 = 8 waves, 4 = 2 waves) keep its magnitude bounds for gadget (l, Bgbit) at ring size N with digit-table mode
+/* ---- host-logic test entry: does blind-rotate kernel form `form` (0 = 4 waves, 1 = split, 2 = 8 waves, 3 = 2 waves)
+ * keep its magnitude bounds for gadget (l, Bgbit) at ring size N with digit-table mode
  * `tables` (0, 1, 2 as "br_digit_table")?  A key is refused at upload when no form does; a launch falls back to an
  * admissible form (peba1_amd/csrc/br_forms.hpp).  Returns 1 or 0. ---- */
 int tfhe_hip_test_form_admissible(int form, int32_t N, int32_t l, int32_t Bgbit, int tables);
+
+/* ---- test entry: device allocations of the ciphertext slot pool and of the per-flush scratch that would bring their total
+ * above `bytes` fail as if the card were full (0 = no cap).  Running out of device memory there is RECOVERABLE: the call
+ * that needed the memory has no effect (recorded gates stay recorded, tfhe_hip_flush returns -1), tfhe_hip_last_error()
+ * says what could not be allocated, and the caller may free ciphertext arrays and carry on. ---- */
+void tfhe_hip_test_set_alloc_cap(int64_t bytes);
 
 /* ---- host-logic test entry: levelise a DAG given as count x {kind, dst, a, b, c} slot
  * records (kind: gate code 0..9, 16 = MUX, 17 = NOT; absent operands -1) without
  * touching the device; writes the level of each op, returns the depth ---- */
 int tfhe_hip_test_schedule(const int32_t *ops5, int32_t count, int32_t unit, int32_t balance, int32_t *levels_out);
-/* Diagnostic (tools/lane_probe.py): `levels` rounds of (blind rotate + key switch) over `width`
- * random gates, issued as `lanes` independent chains on `lanes` HIP streams; returns the wall
- * time in ms (negative on error).  Measures what overlapping level-synchronous chains could gain. */
-/* Diagnostic: a blind-rotate launch of `width` random gates (the second of two back to back);
+/* Diagnostic (tools/wg_times.py): a 4-wave blind-rotate launch of `width` random gates (the second of two back to back);
  * times4[4i .. 4i+3] = s_memtime (shader cycles; the start stamp carries the XCC / CU id in its top 16
  * bits) at the start and end of workgroup i, then s_memrealtime (constant 100 MHz) at its start and
  * end; *launch_ms = the launch's duration between two stream events. */
 int tfhe_hip_test_wg_times(const TFheGateBootstrappingCloudKeySet *bk, int32_t width, uint64_t *times4, double *launch_ms);
-double tfhe_hip_test_lane_probe(const TFheGateBootstrappingCloudKeySet *bk, int32_t lanes, int32_t levels, int32_t width);
 
 /* ---- kernel-level entry points (K2/K3 parity tests against the oracle) ---- */
 /* exact negacyclic products res[c] = ip[c] * tp[c] mod (X^N+1) mod 2^32 through

@@ -17,11 +17,10 @@ namespace tfhe_hip {
 
 enum BrForm : int {
     BR_FORM_WIDE4 = 0,    // 4 waves, 64-bit sums kept and sent (N = 1024)
-    BR_FORM_LEAN4 = 1,    // 4 waves, N = 1024: sent sum reduced per row; N = 2048: both sums reduced per row
-    BR_FORM_SPLIT = 2,    // 8 waves, half transforms, 64-bit sums
-    BR_FORM_WAVE8 = 3,    // 8 waves for narrow launches (N = 1024): rows split over two waves
-    BR_FORM_WAVE2 = 4,    // 2 waves (N = 1024)
-    BR_FORM_COUNT = 5
+    BR_FORM_SPLIT = 1,    // 8 waves, half transforms, 64-bit sums (N = 1024 or 2048)
+    BR_FORM_WAVE8 = 2,    // 8 waves for narrow launches (N = 1024): rows split over two waves
+    BR_FORM_WAVE2 = 3,    // 2 waves (N = 1024): one reduction of all 2 l rows, no tables -- the widest gadget range
+    BR_FORM_COUNT = 4
 };
 
 namespace br_forms_detail {
@@ -72,11 +71,9 @@ inline bool br_form_admissible(int form, int N, int l, int Bgbit, int tables) {
     // 64-bit sums: up to 2 l rows of |x| < F P times a key word < P
     if (2.0 * l * F * kP * kP >= 9.2e18) return false;
     const double wide = l * F * kQ + 0.5;               // l rows summed in 64 bits, reduced once
-    const double per_row = l * (F * kQ + 0.5);          // l rows reduced one by one
     double into_inverse;
     switch (form) {
     case BR_FORM_WIDE4: if (N != 1024) return false; into_inverse = 2 * wide; break;
-    case BR_FORM_LEAN4: into_inverse = N == 1024 ? wide + per_row : 2 * per_row; break;
     case BR_FORM_SPLIT: into_inverse = 2 * wide; break;
     case BR_FORM_WAVE8:
         if (N != 1024 || l < 2) return false;

@@ -45,6 +45,7 @@ struct Rccl {
     ncclResult_t (*GetUniqueId)(ncclUniqueId *) = nullptr;
     ncclResult_t (*CommInitRank)(ncclComm_t *, int, ncclUniqueId, int) = nullptr;
     ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
+    ncclResult_t (*CommSplit)(ncclComm_t, int, int, ncclComm_t *, ncclConfig_t *) = nullptr;      // optional (NCCL >= 2.18)
     ncclResult_t (*Gather)(const void *, void *, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
     ncclResult_t (*AllGather)(const void *, void *, size_t, ncclDataType_t, ncclComm_t, hipStream_t) = nullptr;
     ncclResult_t (*Bcast)(void *, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
@@ -65,6 +66,7 @@ struct Rccl {
         Bcast = reinterpret_cast<decltype(Bcast)>(dlsym(handle, "ncclBcast"));
         GetErrorString = reinterpret_cast<decltype(GetErrorString)>(dlsym(handle, "ncclGetErrorString"));
         GetVersion = reinterpret_cast<decltype(GetVersion)>(dlsym(handle, "ncclGetVersion"));     // evidence only: may be absent
+        CommSplit = reinterpret_cast<decltype(CommSplit)>(dlsym(handle, "ncclCommSplit"));        // may be absent: status_comm()
         return GetUniqueId && CommInitRank && CommDestroy && Gather && AllGather && Bcast && GetErrorString;
     }
 };
@@ -88,9 +90,23 @@ struct Peba1Comm {
     int32_t *st_dev = nullptr, *st_host = nullptr;
     hipStream_t st_stream = nullptr;
     hipEvent_t st_event = nullptr;
+    // ... and on a COMMUNICATOR of its own: split off the data communicator when this one is made
+    // (ncclCommSplit, every rank in one colour).  Two communicators are independent by contract, whatever streams their
+    // collectives are enqueued on; one communicator used from two streams relies on the library chaining its kernels.
+    // Null where the loaded RCCL has no ncclCommSplit or the split failed: the status words then ride on the data
+    // communicator AND the provider's stream -- one communicator, one stream, trivially ordered, at the price of waiting
+    // for the gates in flight.
+    ncclComm_t st_nccl = nullptr;
     int inject_failures = 0;             // test hook (peba1_dist_inject_failure): local failures still to report
     // what this communicator has done (peba1_dist_counters): status exchanges, gathers, broadcasts, payload bytes sent
     uint64_t n_status = 0, n_gather = 0, n_bcast = 0, bytes_sent = 0;
+    // the ORDER it has issued collectives in (peba1_dist_sequence): how many, and a rolling hash of (kind, words per rank,
+    // root) -- equal on every rank of a job iff every rank issued the same collectives in the same order
+    uint64_t seq_count = 0, seq_hash = 0xcbf29ce484222325ull;
+    void issued(int kind, uint64_t words, int root) {
+        for (uint64_t v : {(uint64_t)kind, words, (uint64_t)(root + 1)}) { seq_hash ^= v; seq_hash *= 0x100000001b3ull; }
+        ++seq_count;
+    }
 };
 
 namespace {
@@ -160,26 +176,32 @@ int exchange_status_rccl(Peba1Comm *c, int local) {
             return -2;
         }
     }
-    // On a stream of its own: the words say what the HOST of every rank knows after it has enqueued its
-    // export -- they do not depend on the gates in flight, so reading them back must not wait for those.  The
-    // collectives of one communicator execute in issue order whatever their streams (RCCL chains them), so this
-    // all-gather waits at most for the previous call's data collective, never for the flush enqueued since; the data
-    // collective issued next on the provider's stream is ordered behind it the same way.
-    hipStream_t stream = c->st_stream;
+    // On a stream AND a communicator of their own: the words say what the HOST of every rank knows after
+    // it has enqueued its export -- they do not depend on the gates in flight, so reading them back must not wait for
+    // those, nor for the previous call's data collective.  Without a communicator of their own (Peba1Comm::st_nccl) they
+    // take the data communicator on the provider's stream: ordered by the stream, behind the gates.
+    const bool own = c->st_nccl != nullptr;
+    hipStream_t stream = own ? c->st_stream : static_cast<hipStream_t>(tfhe_hip_stream());
+    constexpr int32_t UNSET = INT32_MIN;      // a word still holding this after the wait was never received
     c->st_host[0] = local;
-    for (int r = 0; r < c->world; ++r) c->st_host[1 + r] = 0;
+    for (int r = 0; r < c->world; ++r) c->st_host[1 + r] = UNSET;
     if (hipMemcpyAsync(c->st_dev, c->st_host, sizeof(int32_t), hipMemcpyHostToDevice, stream) != hipSuccess) { fail("upload of the status word failed"); return -2; }
-    const ncclResult_t r = g_rccl.AllGather(c->st_dev, c->st_dev + 1, 1, ncclInt32, c->nccl, stream);
+    const ncclResult_t r = g_rccl.AllGather(c->st_dev, c->st_dev + 1, 1, ncclInt32, own ? c->st_nccl : c->nccl, stream);
     if (r != ncclSuccess) { fail(std::string("ncclAllGather of the status words: ") + g_rccl.GetErrorString(r)); return -2; }
+    c->issued(0, 1, -1);
     if (hipMemcpyAsync(c->st_host + 1, c->st_dev + 1, (size_t)c->world * sizeof(int32_t), hipMemcpyDeviceToHost, stream) != hipSuccess ||
         hipEventRecord(c->st_event, stream) != hipSuccess) {
         fail("download of the status words failed");
         return -2;
     }
     ++c->n_status;
-    // bounded: a peer that never arrives ends the process with a message (the provider's deadline, its exit code)
-    if (tfhe_hip_wait_event) (void)tfhe_hip_wait_event(c->st_event, "status words of a collective");
-    else (void)hipEventSynchronize(c->st_event);
+    // bounded: a peer that never arrives ends the process with a message (the provider's deadline, its exit code).  A wait
+    // that FAILED is a failed exchange: the words were never received and must not read as "no rank failed"
+    const bool waited = tfhe_hip_wait_event ? tfhe_hip_wait_event(c->st_event, "status words of a collective") == 0
+                                            : hipEventSynchronize(c->st_event) == hipSuccess;
+    if (!waited) { fail("the wait for the status words failed: " + provider_error()); return -2; }
+    for (int k = 0; k < c->world; ++k)
+        if (c->st_host[1 + k] == UNSET) { fail("status word of rank " + std::to_string(k) + " was not received"); return -2; }
     for (int k = 0; k < c->world; ++k)
         if (c->st_host[1 + k] != 0) return k;
     return -1;
@@ -210,6 +232,7 @@ int gather_samples(Peba1Comm *c, LweSample *all, const LweSample *mine, int coun
         const ncclResult_t r = g_rccl.Gather(c->send, c->rank == 0 ? c->recv : nullptr, words, ncclInt32, 0, c->nccl, stream);
         if (r != ncclSuccess) return fail(std::string("ncclGather: ") + g_rccl.GetErrorString(r));
         ++c->n_gather; c->bytes_sent += words * sizeof(int32_t);
+        c->issued(1, words, 0);
         if (c->rank == 0 && tfhe_hip_import_samples_device_async(all, count * c->world, params, c->recv) != 0)
             return fail("import of the gathered samples: " + provider_error());
         return 0;
@@ -221,6 +244,7 @@ int gather_samples(Peba1Comm *c, LweSample *all, const LweSample *mine, int coun
     if (c->gather(c->ctx, send.data(), c->rank == 0 ? recv.data() : nullptr, (1 + words) * sizeof(int32_t), 0) != 0)
         return fail("the host gather callback failed");
     ++c->n_gather; ++c->n_status; c->bytes_sent += (1 + words) * sizeof(int32_t);      // the status word rides in front
+    c->issued(1, words, 0);
     if (local != 0) return fail("rank " + std::to_string(c->rank) + " (this rank) failed before the gather: " + why);
     if (c->rank != 0) return 0;
     for (int k = 0; k < c->world; ++k)
@@ -259,6 +283,7 @@ int broadcast_samples(Peba1Comm *c, LweSample *samples, int count, const TFheGat
         const ncclResult_t r = g_rccl.Bcast(c->send, words, ncclInt32, root, c->nccl, stream);
         if (r != ncclSuccess) return fail(std::string("ncclBcast: ") + g_rccl.GetErrorString(r));
         ++c->n_bcast; if (c->rank == root) c->bytes_sent += words * sizeof(int32_t);
+        c->issued(2, words, root);
         if (c->rank != root && tfhe_hip_import_samples_device_async(samples, count, params, c->send) != 0)
             return fail("import of the broadcast samples: " + provider_error());
         return 0;
@@ -271,6 +296,7 @@ int broadcast_samples(Peba1Comm *c, LweSample *samples, int count, const TFheGat
     }
     if (c->bcast(c->ctx, buf.data(), (1 + words) * sizeof(int32_t), root) != 0) return fail("the host broadcast callback failed");
     ++c->n_bcast; ++c->n_status; if (c->rank == root) c->bytes_sent += (1 + words) * sizeof(int32_t);
+    c->issued(2, words, root);
     if (local != 0) return fail("rank " + std::to_string(c->rank) + " (this rank) failed before the broadcast: " + why);
     if (buf[0] != 0) return fail("rank " + std::to_string(root) + " (the root) reported a failure before the broadcast; its payload is void");
     if (c->rank != root && tfhe_hip_import_samples(samples, count, params, buf.data() + 1) != 0)
@@ -311,6 +337,14 @@ int peba1_dist_unique_id(void *id128) {
     return 0;
 }
 
+// the status words' own communicator (Peba1Comm::st_nccl): a collective over the data communicator -- every rank makes its
+// Peba1Comm at the same point, so every rank is here together.  Failure is not an error: the fallback is documented there.
+static void status_comm(Peba1Comm *c) {
+    if (!g_rccl.CommSplit || std::getenv("PEBA1_DIST_NO_STATUS_COMM")) return;
+    ncclComm_t split = nullptr;
+    if (g_rccl.CommSplit(c->nccl, 0, c->rank, &split, nullptr) == ncclSuccess && split) c->st_nccl = split;
+}
+
 Peba1Comm *peba1_dist_init_rccl(const void *id128, int world, int rank) {
     if (!id128 || world < 1 || rank < 0 || rank >= world) { fail("peba1_dist_init_rccl: bad arguments"); return nullptr; }
     if (!g_rccl.load()) { fail(std::string("cannot open RCCL: ") + (dlerror() ? dlerror() : "symbols missing")); return nullptr; }
@@ -322,6 +356,7 @@ Peba1Comm *peba1_dist_init_rccl(const void *id128, int world, int rank) {
     c->world = world; c->rank = rank; c->rccl = true; c->own = true;
     const ncclResult_t r = g_rccl.CommInitRank(&c->nccl, world, id, rank);
     if (r != ncclSuccess) { fail(std::string("ncclCommInitRank: ") + g_rccl.GetErrorString(r)); delete c; return nullptr; }
+    status_comm(c);
     arm_deadline(c);
     return c;
 }
@@ -332,6 +367,8 @@ Peba1Comm *peba1_dist_adopt_rccl(void *nccl_comm, int world, int rank) {
     auto *c = new Peba1Comm();
     c->world = world; c->rank = rank; c->rccl = true; c->own = false;
     c->nccl = static_cast<ncclComm_t>(nccl_comm);
+    DeviceScope on_provider_device;
+    status_comm(c);
     arm_deadline(c);
     return c;
 }
@@ -351,6 +388,7 @@ void peba1_dist_destroy(Peba1Comm *c) {
         stream_sync();
         // (every status exchange was waited for when it was made: nothing is in flight on the status stream; the wait is a formality)
         if (c->st_stream) (void)hipStreamSynchronize(c->st_stream);
+        if (c->st_nccl) (void)g_rccl.CommDestroy(c->st_nccl);           // the split-off communicator is ours even when the parent is adopted
         if (c->own && c->nccl) (void)g_rccl.CommDestroy(c->nccl);
         if (c->send) (void)hipFree(c->send);
         if (c->recv) (void)hipFree(c->recv);
@@ -451,6 +489,13 @@ void peba1_dist_counters(const Peba1Comm *c, uint64_t out4[4]) {
 }
 
 int peba1_dist_transport(const Peba1Comm *c) { return c && c->rccl ? 1 : 0; }
+
+int peba1_dist_status_channel(const Peba1Comm *c) { return !c || !c->rccl ? 0 : c->st_nccl ? 2 : 1; }
+
+void peba1_dist_sequence(const Peba1Comm *c, uint64_t out2[2]) {
+    if (!c || !out2) return;
+    out2[0] = c->seq_count; out2[1] = c->seq_hash;
+}
 
 void peba1_dist_inject_failure(Peba1Comm *c, int count) { if (c) c->inject_failures = count > 0 ? count : 0; }
 

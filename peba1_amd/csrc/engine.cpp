@@ -39,6 +39,34 @@ void hip_check(hipError_t e, const char *what) {
     if (e != hipSuccess) fatal(std::string(what) + ": " + hipGetErrorString(e));
 }
 
+// Device memory whose exhaustion is RECOVERABLE: the slot pool's growth and the per-flush scratch.
+// A library living inside a matching server must not abort() because one request recorded more than the card holds:
+// hipErrorOutOfMemory becomes an ApiError -- the call that needed the memory has no effect (the gates recorded so far
+// stay recorded; a flush returns -1), tfhe_hip_last_error() says what could not be allocated, and the caller may free
+// ciphertext arrays and go on.  Anything else hipMalloc can return is still fatal.  `g_alloc_cap` (test hook
+// tfhe_hip_test_set_alloc_cap) makes allocations above a total fail the same way, so that the path has a test.
+static long long g_alloc_cap = 0, g_alloc_total = 0;
+void set_alloc_cap(long long bytes) { g_alloc_cap = bytes > 0 ? bytes : 0; }
+static void *recoverable_alloc(size_t bytes, const char *what) {
+    void *p = nullptr;
+    hipError_t e = hipErrorOutOfMemory;
+    if (!(g_alloc_cap > 0 && g_alloc_total + (long long)bytes > g_alloc_cap)) e = hipMalloc(&p, bytes);
+    if (e == hipErrorOutOfMemory) {
+        (void)hipGetLastError();                 // the sticky error of the failed call must not fail the next launch check
+        api_fail(std::string("out of device memory: ") + what + " needs " + std::to_string(bytes >> 20) + " MiB more (" +
+                 std::to_string(g_alloc_total >> 20) + " MiB held by the slot pool and the flush scratch); the call had no "
+                 "effect -- free ciphertext arrays, flush less at a time, or lower TFHE_HIP_POOL_SLOTS");
+    }
+    hip_check(e, what);
+    g_alloc_total += (long long)bytes;
+    return p;
+}
+static void recoverable_free(void *p, size_t bytes) {
+    if (!p) return;
+    (void)hipFree(p);
+    g_alloc_total -= (long long)bytes;
+}
+
 // HIP's current device is per host thread and starts at 0: a worker thread of a multi-GPU server (rank r drives GPU r)
 // that calls in without ever having selected a device -- or after selecting another one for its own work -- would launch
 // on the engine's stream with the wrong device current.  Every method below that calls the HIP runtime therefore binds
@@ -71,12 +99,12 @@ SlotPool::SlotPool(int ct_words, int ct_stride, size_t capacity) : words_(ct_wor
 }
 SlotPool::~SlotPool() {
     ENGINE_DEVICE_SCOPE();
-    if (data_) (void)hipFree(data_);
+    recoverable_free(data_, cap_ * (size_t)stride_ * sizeof(int32_t));
 }
 void SlotPool::grow(size_t new_cap) {
     ENGINE_DEVICE_SCOPE();
-    int32_t *fresh = nullptr;
-    hip_check(hipMalloc(reinterpret_cast<void **>(&fresh), new_cap * (size_t)stride_ * sizeof(int32_t)), "hipMalloc(slot pool)");
+    // (throws ApiError when the card is full: nothing has changed yet, the pool keeps its size and its contents)
+    int32_t *fresh = static_cast<int32_t *>(recoverable_alloc(new_cap * (size_t)stride_ * sizeof(int32_t), "growing the ciphertext slot pool"));
     if (data_) {
         // growth happens while recording (host side).  A pipelined flush may still be in flight -- its launches carry
         // the old pointer -- and a caller's own stream may still read an exported buffer: wait for the whole device
@@ -84,7 +112,7 @@ void SlotPool::grow(size_t new_cap) {
         Engine::get().sync_stream("sync before pool growth");      // bounded when a deadline is set (a collective may sit there)
         hip_check(hipDeviceSynchronize(), "sync before pool growth");
         hip_check(hipMemcpy(fresh, data_, cap_ * (size_t)stride_ * sizeof(int32_t), hipMemcpyDeviceToDevice), "copy slot pool");
-        (void)hipFree(data_);
+        recoverable_free(data_, cap_ * (size_t)stride_ * sizeof(int32_t));
     }
     data_ = fresh;
     ref_.resize(new_cap, 0);
@@ -132,14 +160,10 @@ void Engine::ensure_init() {
     if (hipGetDeviceCount(&count) != hipSuccess || count == 0)
         fatal("no HIP device available: libtfhe-hip evaluates gates on the GPU only (there is no CPU fallback)");
     if (const char *env = std::getenv("TFHE_HIP_DEVICE")) device_ = std::atoi(env);
-    if (const char *env = std::getenv("TFHE_HIP_BR4_MAX")) br4_max_rotations = std::atoi(env);
     if (const char *env = std::getenv("TFHE_HIP_KS_BLOCKS")) ks_target_blocks = std::atoi(env);
     if (const char *env = std::getenv("TFHE_HIP_KS_MAX_SPLITS")) ks_max_splits = std::atoi(env);
     if (const char *env = std::getenv("TFHE_HIP_KS_TILE")) ks_tile = std::atoi(env);
-    if (const char *env = std::getenv("TFHE_HIP_KS_ATOMIC")) ks_atomic = std::atoi(env);
-    if (const char *env = std::getenv("TFHE_HIP_KS_NARROW")) ks_narrow = std::atoi(env);
-    if (const char *env = std::getenv("TFHE_HIP_KS_PIPE")) ks_pipe = std::atoi(env);
-    if (const char *env = std::getenv("TFHE_HIP_KS_BRANCH")) ks_branch = std::atoi(env);
+    if (const char *env = std::getenv("TFHE_HIP_KS_INDEX")) ks_index = std::atoi(env);
     if (const char *env = std::getenv("TFHE_HIP_KS_SPLIT_TIES")) ks_split_ties = std::atoi(env);
     DeviceScope bind(device_);               // (an invalid device shows at the first runtime call below)
     {
@@ -156,12 +180,14 @@ void Engine::ensure_init() {
         hip_check(hipDeviceGetStreamPriorityRange(&least, &greatest), "priority range");
         hip_check(hipStreamCreateWithPriority(&stream_, hipStreamNonBlocking, greatest), "hipStreamCreate");
     }
-    if (const char *env = std::getenv("TFHE_HIP_BR_FAIR")) br_fair = std::atoi(env);
     if (const char *env = std::getenv("TFHE_HIP_BR8_MAX")) br8_max_rotations = std::atoi(env);
     if (const char *env = std::getenv("TFHE_HIP_BR_TAIL8")) br_tail8 = std::atoi(env);
     if (const char *env = std::getenv("TFHE_HIP_BR_VARIANT")) br_variant = std::atoi(env);
     if (const char *env = std::getenv("TFHE_HIP_BR_TABLE")) br_digit_table = std::atoi(env);
     if (const char *env = std::getenv("TFHE_HIP_SYNC_DEADLINE_MS")) sync_deadline_ms = std::atoll(env);
+    // a caller that cannot reach tfhe_hip_set_kernel_timing (the reference's unmodified program) asks for the per-level
+    // times by naming the trace file
+    if (std::getenv("TFHE_HIP_TRACE_TIMES")) kernel_timing = true;
     for (auto &e : ev_) hip_check(hipEventCreate(&e), "hipEventCreate");
     inited_.store(true, std::memory_order_release);
 }
@@ -238,9 +264,19 @@ void *Engine::scratch(size_t idx, size_t bytes) {
     if (scratch_ptr_.size() <= idx) { scratch_ptr_.resize(idx + 1, nullptr); scratch_size_.resize(idx + 1, 0); }
     if (scratch_size_[idx] < bytes) {
         sync_stream("sync before scratch realloc");
-        if (scratch_ptr_[idx]) (void)hipFree(scratch_ptr_[idx]);
+        // the old buffer goes first (the two need not fit side by side); if the new one cannot be had the entry is empty,
+        // which the next call sees as size 0 -- and the ApiError leaves the caller's call without effect
+        recoverable_free(scratch_ptr_[idx], scratch_size_[idx]);
+        scratch_ptr_[idx] = nullptr;
+        scratch_size_[idx] = 0;
         size_t cap = bytes + bytes / 2 + 4096;
-        hip_check(hipMalloc(&scratch_ptr_[idx], cap), "hipMalloc(scratch)");
+        try {
+            scratch_ptr_[idx] = recoverable_alloc(cap, "the scratch buffers of a flush");
+        } catch (const ApiError &) {
+            if (cap == bytes + 4096) throw;
+            cap = bytes + 4096;                  // without the growth margin
+            scratch_ptr_[idx] = recoverable_alloc(cap, "the scratch buffers of a flush");
+        }
         scratch_size_[idx] = cap;
     }
     return scratch_ptr_[idx];
@@ -327,11 +363,8 @@ static DevParams make_dev_params(const Params &p) {
     d.kpl = p.kpl(); d.ct_stride = p.ct_stride(); d.u_stride = p.u_stride();
     d.decomp_offset = p.decomp_offset(); d.ks_prec_offset = p.ks_prec_offset();
     d.mu = 1 << 29;
-    d.wave_prio = 0;
-    d.fair_shift = 0;
     d.br_variant = 0;
     d.digit_table = 1;
-    d.cu_arrivals = nullptr;
     d.clock_acc = nullptr;
     d.wg_times = nullptr;
     return d;
@@ -526,7 +559,7 @@ hipEvent_t Engine::next_timing_event() {
 }
 
 bool Engine::launch_br(const DeviceKeyImage *key, const int32_t *pool, const RotDesc *rots, int count, int32_t *u_buf,
-                       int32_t *acc_dbg, hipStream_t stream, int wave_prio) {
+                       int32_t *acc_dbg, hipStream_t stream) {
     ENGINE_DEVICE_SCOPE();
     if (!stream) stream = stream_;
     tail_event_ = nullptr;                   // what an earlier launch left is not this one's
@@ -534,19 +567,19 @@ bool Engine::launch_br(const DeviceKeyImage *key, const int32_t *pool, const Rot
     DevParams dp = key->dp;
     // the form the tunings ask for ...
     int form;
-    if (count > br4_max_rotations) form = dp.N == 1024 ? BR_FORM_WAVE2 : BR_FORM_LEAN4;
-    else if (br_variant == 2 || (br_variant < 0 && dp.N == 2048 && br_split_auto_2048)) form = BR_FORM_SPLIT;
+    if (br_variant == 4 && dp.N == 1024) form = BR_FORM_WAVE2;
+    else if (br_variant == 2 || dp.N == 2048) form = BR_FORM_SPLIT;
     // launches that leave CUs with at most one workgroup: the 8-wave form (a second wave per SIMD)
-    else if (br8_max_rotations > 0 && count <= std::min(br8_max_rotations, cu_count_) && dp.N == 1024 && dp.l >= 2 && !wg_times_dbg_)
+    else if (br8_max_rotations > 0 && count <= std::min(br8_max_rotations, cu_count_) && dp.l >= 2 && !wg_times_dbg_)
         form = BR_FORM_WAVE8;
-    else form = dp.N == 1024 && br_variant != 1 ? BR_FORM_WIDE4 : BR_FORM_LEAN4;
+    else form = BR_FORM_WIDE4;
     // the workgroup-time probe reads stamps only the 4-wave kernel writes
-    if (wg_times_dbg_ && form != BR_FORM_WIDE4 && form != BR_FORM_LEAN4) form = dp.N == 1024 ? BR_FORM_WIDE4 : BR_FORM_LEAN4;
-    // ... if its magnitude bounds hold for this key's gadget (br_forms.hpp; every built-in set passes everywhere
-    // except l = 3 in the 4-wave form at N = 2048); else the same form with smaller or no digit tables, else another form
+    if (wg_times_dbg_ && dp.N == 1024) form = BR_FORM_WIDE4;
+    // ... if its magnitude bounds hold for this key's gadget (br_forms.hpp; every built-in set passes in every form of its
+    // ring); else the same form with smaller or no digit tables, else the next form of the order
     int tables = br_digit_table < 0 || br_digit_table > 2 ? 0 : br_digit_table;
     if (!key->form_ok[form][tables]) {
-        static const int order[BR_FORM_COUNT] = {BR_FORM_WIDE4, BR_FORM_SPLIT, BR_FORM_LEAN4, BR_FORM_WAVE2, BR_FORM_WAVE8};
+        static const int order[BR_FORM_COUNT] = {BR_FORM_WIDE4, BR_FORM_SPLIT, BR_FORM_WAVE2, BR_FORM_WAVE8};
         int pick_f = -1, pick_t = 0;
         for (int k = -1; k < BR_FORM_COUNT && pick_f < 0; ++k) {
             const int f = k < 0 ? form : order[k];
@@ -557,9 +590,7 @@ bool Engine::launch_br(const DeviceKeyImage *key, const int32_t *pool, const Rot
         if (pick_f < 0) fatal("no admissible blind-rotate form (upload_key should have refused this key)");
         form = pick_f; tables = pick_t;
     }
-    dp.wave_prio = wave_prio;
     dp.digit_table = tables;
-    dp.br_variant = dp.N == 1024 && form == BR_FORM_LEAN4 ? 1 : 0;
     if (kernel_timing) {
         if (!clock_acc_) {
             hip_check(hipMalloc(&clock_acc_, 2 * sizeof(unsigned long long)), "hipMalloc(clock sums)");
@@ -568,22 +599,12 @@ bool Engine::launch_br(const DeviceKeyImage *key, const int32_t *pool, const Rot
         dp.clock_acc = clock_acc_;
     }
     if (form == BR_FORM_WAVE2) {
-        // (splitting a short last round off to the latency kernel was measured: the kernel
-        // boundary costs more overlap than the faster tail gains -- match 3.99 s -> 4.15 s)
-        launch_blind_rotate(stream, dp, key->key, pool, rots, count, u_buf, acc_dbg);
+        launch_blind_rotate2(stream, dp, key->key, pool, rots, count, u_buf, acc_dbg);
         return false;
     }
     if (form == BR_FORM_SPLIT) {
         launch_blind_rotate_split(stream, dp, key->key, pool, rots, count, u_buf, acc_dbg);
         return false;
-    }
-    if (br_fair > 0 && count > cu_count_) {                   // only launches that put several workgroups on a CU
-        if (!cu_arrivals_) {
-            hip_check(hipMalloc(&cu_arrivals_, 4096 * sizeof(uint32_t)), "hipMalloc(cu arrivals)");
-            hip_check(hipMemset(cu_arrivals_, 0, 4096 * sizeof(uint32_t)), "hipMemset(cu arrivals)");
-        }
-        dp.fair_shift = br_fair;
-        dp.cu_arrivals = cu_arrivals_;
     }
     dp.wg_times = wg_times_dbg_;
     if (form == BR_FORM_WAVE8) {
@@ -593,17 +614,14 @@ bool Engine::launch_br(const DeviceKeyImage *key, const int32_t *pool, const Rot
     // the last, at most half-filled round of a wide launch on the 8-wave form (descriptors carry their own output
     // index, so a level splits anywhere; the debug probes index by workgroup and keep one launch)
     const int round = 2 * cu_count_, tail = count % round;
-    if (br_tail8 && count > round && tail > 0 && tail <= std::min(br8_max_rotations, cu_count_) && dp.N == 1024 && dp.l >= 2 &&
+    if (br_tail8 && count > round && tail > 0 && tail <= std::min(br8_max_rotations, cu_count_) && dp.l >= 2 &&
         !acc_dbg && !wg_times_dbg_ && key->form_ok[BR_FORM_WAVE8][tables]) {
         launch_blind_rotate4(stream, dp, key->key, pool, rots, count - tail, u_buf, nullptr);
         tail_count_ = tail;
         // the event between the two launches belongs to execute()'s per-flush set (reset there); the raw test paths and
         // probes have no reader for it and must not grow the set
         if (kernel_timing && in_execute_) { tail_event_ = next_timing_event(); hip_check(hipEventRecord(tail_event_, stream), "event"); }
-        DevParams dp8 = dp;                                   // as a narrow launch gets them: no turn-taking
-        dp8.fair_shift = 0;
-        dp8.cu_arrivals = nullptr;
-        launch_blind_rotate8(stream, dp8, key->key, pool, rots + (count - tail), tail, u_buf, nullptr);
+        launch_blind_rotate8(stream, dp, key->key, pool, rots + (count - tail), tail, u_buf, nullptr);
         return false;
     }
     launch_blind_rotate4(stream, dp, key->key, pool, rots, count, u_buf, acc_dbg);
@@ -611,14 +629,14 @@ bool Engine::launch_br(const DeviceKeyImage *key, const int32_t *pool, const Rot
 }
 
 void Engine::launch_ks(const DeviceKeyImage *key, const int32_t *u_buf, const KsDesc *descs, int count, int32_t *pool,
-                       hipStream_t stream, int scratch_set) {
+                       hipStream_t stream) {
     ENGINE_DEVICE_SCOPE();
     if (count <= 0) return;
     if (!stream) stream = stream_;
     const DevParams &dp = key->dp;
     const int nin = dp.k * dp.N;
-    // tiles of 24 gates exist in the index form of the register key switch only (kernels.hip keyswitch_index_kernel)
-    const int ks_tile = (this->ks_tile == 24 && !(ks_branch == 2 && !ks_atomic)) ? 16 : this->ks_tile;
+    // tiles of 24 or 32 gates exist in the index form only (kernels.hip keyswitch_index_kernel)
+    const int ks_tile = (this->ks_tile > 16 && !ks_index) ? 16 : this->ks_tile;
     // tiled kernel: wide launches, ranges of at most 64 input coefficients
     const bool tiled = ks_tile > 0 && count >= 2 * ks_tile && dp.ks_t == 8 && dp.ks_basebit == 2 && ks_max_splits > 1 &&
                        (nin + ks_max_splits - 1) / ks_max_splits <= 64;
@@ -628,15 +646,16 @@ void Engine::launch_ks(const DeviceKeyImage *key, const int32_t *u_buf, const Ks
         int splits = 1;
         if (tiled && cnt >= 2 * ks_tile) {
             // the number of coefficient ranges is free between nin/64 and ks_max_splits: take the
-            // one whose grid (tiles x ranges) fills whole rounds of the workgroups the chip holds
-            // (the kernel's ~190 VGPRs allow two waves per SIMD, i.e. 8 / waves-per-workgroup
-            // workgroups per CU, and its LDS strips a similar number), e.g. 36 tiles x 28 ranges =
-            // 1008 of 1024 slots in two rounds instead of 36 x 32 = 1152 in three
+            // one whose grid (tiles x ranges) fills whole rounds of the workgroups the chip holds,
+            // e.g. 36 tiles x 28 ranges = 1008 of 1024 slots in two rounds instead of 36 x 32 = 1152 in three
             const int threads = ((dp.ct_stride / 4 + 63) / 64) * 64;
-            const size_t lds = (size_t)16 * threads * 16 + (size_t)ks_tile * 65 * 4;
-            int per_cu = std::max(1, std::min((int)((160 * 1024) / lds), 8 / (threads / 64)));
-            // register form: no LDS strips; 116 VGPRs at tile 16 (four waves per SIMD), 196 at tile 32 (two)
-            if (ks_branch && !ks_atomic) per_cu = std::max(1, (ks_tile == 16 ? 16 : ks_tile == 24 && ks_branch == 2 ? 12 : 8) / (threads / 64));
+            // index form: no LDS strips; 120 VGPRs at tile 16 (four waves per SIMD), 162 at 24 (three), 204 at 32 (two);
+            // strip form: ~235 VGPRs (two waves per SIMD) and 16 x threads x 16 bytes of strips
+            int per_cu = std::max(1, (ks_tile == 16 ? 16 : ks_tile == 24 ? 12 : 8) / (threads / 64));
+            if (!ks_index) {
+                const size_t lds = (size_t)16 * threads * 16 + (size_t)ks_tile * 65 * 4;
+                per_cu = std::max(1, std::min((int)((160 * 1024) / lds), 8 / (threads / 64)));
+            }
             const long long slots = (long long)cu_count_ * per_cu;
             const long long tiles = (cnt + ks_tile - 1) / ks_tile;
             const int lo = std::max(2, (nin + 63) / 64);
@@ -651,9 +670,8 @@ void Engine::launch_ks(const DeviceKeyImage *key, const int32_t *u_buf, const Ks
             while (splits < ks_max_splits && cnt * splits * 2 <= ks_target_blocks) splits *= 2;
         }
         int32_t *partial = nullptr;
-        if (splits > 1 && !ks_atomic) partial = static_cast<int32_t *>(scratch(10 + (size_t)scratch_set, (size_t)cnt * splits * dp.ct_stride * 4));
-        launch_keyswitch(stream, dp, key->key, u_buf, descs + done, cnt, pool, splits, partial, tiled ? ks_tile : 0,
-                         ks_atomic != 0, ks_narrow != 0, ks_pipe != 0, ks_branch);
+        if (splits > 1) partial = static_cast<int32_t *>(scratch(10, (size_t)cnt * splits * dp.ct_stride * 4));
+        launch_keyswitch(stream, dp, key->key, u_buf, descs + done, cnt, pool, splits, partial, tiled ? ks_tile : 0, ks_index != 0);
     }
 }
 
@@ -665,16 +683,19 @@ void Engine::execute(const DeviceKeyImage *key, SlotPool *pool, LevelPlan &&plan
     ENGINE_DEVICE_SCOPE();
     wait_flight();                                   // at most one flush in flight: its descriptors and scratch are in use
     flight_t0_ = std::chrono::steady_clock::now();
+    // Every device buffer of the flush is sized here, before anything is enqueued and before the plan changes hands:
+    // scratch() may reallocate, which must not happen under a running launch -- and it may throw (out of device memory:
+    // recoverable_alloc), in which case nothing has run, the caller's recorded gates are still pending and its flush
+    // returns -1 (shim.cpp flush_locked releases nothing before this call returns)
+    RotDesc *drots = static_cast<RotDesc *>(scratch(0, plan_in.rots.size() * sizeof(RotDesc) + 16));
+    KsDesc *dks = static_cast<KsDesc *>(scratch(1, plan_in.kss.size() * sizeof(KsDesc) + 16));
+    NotDesc *dnots = static_cast<NotDesc *>(scratch(2, plan_in.nots.size() * sizeof(NotDesc) + 16));
+    // extract buffer and key-switch partial sums, sized for the widest level
+    int32_t *u_buf = static_cast<int32_t *>(scratch(5, (size_t)(plan_in.max_rots + 1) * key->dp.u_stride * 4));
+    (void)scratch(10, (size_t)std::min(plan_in.max_rots + 1, 8192) * ks_max_splits * key->dp.ct_stride * 4);
     flight_plan_ = std::move(plan_in);               // owns the host descriptors until the uploads have certainly happened
     const LevelPlan &plan = flight_plan_;
     const int levels = plan.levels;
-    RotDesc *drots = static_cast<RotDesc *>(scratch(0, plan.rots.size() * sizeof(RotDesc) + 16));
-    KsDesc *dks = static_cast<KsDesc *>(scratch(1, plan.kss.size() * sizeof(KsDesc) + 16));
-    NotDesc *dnots = static_cast<NotDesc *>(scratch(2, plan.nots.size() * sizeof(NotDesc) + 16));
-    // extract buffer and key-switch partial sums, sized for the widest level before anything runs (scratch() may
-    // reallocate, which must not happen under a running launch)
-    int32_t *u_buf = static_cast<int32_t *>(scratch(5, (size_t)(plan.max_rots + 1) * key->dp.u_stride * 4));
-    (void)scratch(10, (size_t)std::min(plan.max_rots + 1, 8192) * ks_max_splits * key->dp.ct_stride * 4);
     if (!plan.rots.empty())
         hip_check(hipMemcpyAsync(drots, plan.rots.data(), plan.rots.size() * sizeof(RotDesc), hipMemcpyHostToDevice, stream_), "upload rots");
     if (!plan.kss.empty())
@@ -711,7 +732,7 @@ void Engine::execute(const DeviceKeyImage *key, SlotPool *pool, LevelPlan &&plan
         }
         if (nrot) {
             in_execute_ = true;
-            t.wide8 = launch_br(key, pool->data(), drots + plan.rot_off[gg], nrot, u_buf, nullptr, stream_, 0);
+            t.wide8 = launch_br(key, pool->data(), drots + plan.rot_off[gg], nrot, u_buf, nullptr, stream_);
             in_execute_ = false;
             if (t.wide8) { ++stats.br8_launches; stats.br8_rotations += (uint64_t)nrot; }
             if (tail_count_) {                       // a second launch, of the 8-wave kernel
@@ -722,7 +743,7 @@ void Engine::execute(const DeviceKeyImage *key, SlotPool *pool, LevelPlan &&plan
             }
         }
         if (kernel_timing) { t.e1 = timing_event(); hip_check(hipEventRecord(t.e1, stream_), "event"); }
-        if (nks) launch_ks(key, u_buf, dks + plan.ks_off[gg], nks, pool->data(), stream_, 0);
+        if (nks) launch_ks(key, u_buf, dks + plan.ks_off[gg], nks, pool->data(), stream_);
         if (kernel_timing) {
             t.e2 = timing_event(); hip_check(hipEventRecord(t.e2, stream_), "event"); timed.push_back(t);
             if (nnot == 0) shared_end = t.e2;
@@ -762,7 +783,11 @@ void Engine::wait_flight() {
         // diagnostic: start, blind-rotate and key-switch time of every level (TFHE_HIP_TRACE_TIMES = file)
         FILE *tf = nullptr;
         if (const char *trace = std::getenv("TFHE_HIP_TRACE_TIMES")) tf = std::fopen(trace, "a");
-        if (tf) std::fprintf(tf, "flush levels=%d\n", levels);
+        // "flush levels=L start_ms=S": S = host time of the flush's start since the process's first flush (the gaps between
+        // flushes are the caller's own time: recording, encrypting, decrypting)
+        static const auto trace_t0 = flight_t0_;
+        if (tf) std::fprintf(tf, "flush levels=%d start_ms=%.3f\n", levels,
+                             std::chrono::duration<double, std::milli>(flight_t0_ - trace_t0).count());
         for (const Timed &t : timed) {
             float a = 0, b = 0, c = 0;
             hip_check(hipEventElapsedTime(&a, base, t.e0), "elapsed");
@@ -790,7 +815,10 @@ void Engine::wait_flight() {
             }
         }
         if (cur_b >= cur_a) stats.ms_blind_rotate_busy += cur_b - cur_a;
-        if (tf) std::fclose(tf);
+        if (tf) {
+            std::fprintf(tf, "wall_ms=%.3f\n", std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - flight_t0_).count());
+            std::fclose(tf);
+        }
     }
     if (kernel_timing && clock_acc_) {
         unsigned long long sums[2] = {0, 0};
@@ -857,92 +885,57 @@ void Engine::run_keyswitch(const DeviceKeyImage *key, const Torus32 *u, int coun
     stats.keyswitches += (uint64_t)count;
 }
 
-double Engine::run_lane_probe(const DeviceKeyImage *key, int lanes, int levels, int width, unsigned long long *wg_times) {
+double Engine::run_wg_times(const DeviceKeyImage *key, int width, unsigned long long *wg_times) {
     ENGINE_DEVICE_SCOPE();
     wait_flight();
     const DevParams &dp = key->dp;
-    lanes = std::max(1, std::min(lanes, 8));
-    const int per = width / lanes;
-    if (per <= 0 || levels <= 0) return 0.0;
-    // a private "pool": `width` random input ciphertexts, then `width` outputs
+    if (width <= 0 || !wg_times || dp.N != 1024) return -1.0;       // the stamps come from the 4-wave kernel only
+    // a private "pool": `width` random input ciphertexts
     std::vector<int32_t> host((size_t)width * dp.ct_stride);
     uint64_t x = 0x9E3779B97F4A7C15ull;
     for (auto &w : host) { x ^= x << 13; x ^= x >> 7; x ^= x << 17; w = (int32_t)(x >> 16); }
-    int32_t *pool = static_cast<int32_t *>(scratch(40, (size_t)2 * width * dp.ct_stride * 4));
+    int32_t *pool = static_cast<int32_t *>(scratch(40, (size_t)width * dp.ct_stride * 4));
     hip_check(hipMemcpy(pool, host.data(), host.size() * 4, hipMemcpyHostToDevice), "probe pool");
     std::vector<RotDesc> rots(width);
-    std::vector<KsDesc> kss(width);
-    for (int i = 0; i < width; ++i) {
-        const int local = i % per;
-        rots[i] = RotDesc{i, (i + 1) % width, 1, 1, -dp.mu, local};
-        kss[i] = KsDesc{local, -1, 0, width + i};
-    }
+    for (int i = 0; i < width; ++i) rots[i] = RotDesc{i, (i + 1) % width, 1, 1, -dp.mu, i};
     RotDesc *drots = static_cast<RotDesc *>(scratch(41, rots.size() * sizeof(RotDesc)));
-    KsDesc *dks = static_cast<KsDesc *>(scratch(42, kss.size() * sizeof(KsDesc)));
     hip_check(hipMemcpy(drots, rots.data(), rots.size() * sizeof(RotDesc), hipMemcpyHostToDevice), "probe rots");
-    hip_check(hipMemcpy(dks, kss.data(), kss.size() * sizeof(KsDesc), hipMemcpyHostToDevice), "probe ks");
-    std::vector<hipStream_t> st(lanes);
-    std::vector<int32_t *> ubuf(lanes);
-    for (int s = 0; s < lanes; ++s) {
-        hip_check(hipStreamCreateWithFlags(&st[s], hipStreamNonBlocking), "probe stream");
-        ubuf[s] = static_cast<int32_t *>(scratch(50 + (size_t)s, (size_t)(per + 1) * dp.u_stride * 4));
-        (void)scratch(10 + (size_t)s, (size_t)per * ks_max_splits * dp.ct_stride * 4);   // no growth while running
-    }
-    unsigned long long *dtimes = nullptr;
-    if (wg_times) {                                      // one launch, per-workgroup start/end stamps
-        dtimes = static_cast<unsigned long long *>(scratch(43, (size_t)4 * width * 8));
-        hipEvent_t e0, e1;
-        hip_check(hipEventCreate(&e0), "probe event");
-        hip_check(hipEventCreate(&e1), "probe event");
-        // launches back to back, the last one stamped and timed: what a level of a circuit sees
-        // (TFHE_HIP_PROBE_WARM = "count:width[:ks]" changes the unstamped launches before it, default one of
-        // the same width; ks = 1 puts a key-switch launch of that width after each of them, as a circuit does)
-        int warm_count = 1, warm_width = width, warm_ks = 0;
-        if (const char *env = std::getenv("TFHE_HIP_PROBE_WARM")) std::sscanf(env, "%d:%d:%d", &warm_count, &warm_width, &warm_ks);
-        warm_width = std::max(1, std::min(warm_width, width));
-        for (int w = 0; w < warm_count; ++w) {
-            launch_br(key, pool, drots, warm_width, ubuf[0], nullptr, st[0]);
-            if (warm_ks) launch_ks(key, ubuf[0], dks, warm_width, pool, st[0], 0);
-        }
-        // stamps come from the 4-wave kernel only (launch_br forces it while the probe is armed); cleared first so
-        // that a launch which wrote none is noticed instead of read as timings
-        hip_check(hipMemsetAsync(dtimes, 0, (size_t)4 * width * 8, st[0]), "clear stamps");
-        wg_times_dbg_ = dtimes;
-        hip_check(hipEventRecord(e0, st[0]), "probe event record");
-        launch_br(key, pool, drots, width, ubuf[0], nullptr, st[0]);
-        hip_check(hipEventRecord(e1, st[0]), "probe event record");
-        hip_check(hipStreamSynchronize(st[0]), "probe stamps");
-        wg_times_dbg_ = nullptr;
-        float ems = 0.f;
-        hip_check(hipEventElapsedTime(&ems, e0, e1), "probe event time");
-        (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
-        hip_check(hipMemcpy(wg_times, dtimes, (size_t)4 * width * 8, hipMemcpyDeviceToHost), "probe stamps copy");
-        for (int s = 0; s < lanes; ++s) hip_check(hipStreamDestroy(st[s]), "probe stream destroy");
-        for (int i = 0; i < width; ++i)
-            if (wg_times[4 * i] == 0 || wg_times[4 * i + 1] == 0) return -1.0;      // a workgroup left no stamp
-        return (double)ems;
-    }
-    hip_check(hipDeviceSynchronize(), "probe sync");
-    const auto t0 = std::chrono::steady_clock::now();
-    for (int L = 0; L < levels; ++L)
-        for (int s = 0; s < lanes; ++s) {
-            launch_br(key, pool, drots + (size_t)s * per, per, ubuf[s], nullptr, st[s]);
-            launch_ks(key, ubuf[s], dks + (size_t)s * per, per, pool, st[s], s);
-        }
-    for (int s = 0; s < lanes; ++s) hip_check(hipStreamSynchronize(st[s]), "probe lane");
-    const double ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
-    for (int s = 0; s < lanes; ++s) hip_check(hipStreamDestroy(st[s]), "probe stream destroy");
-    return ms;
+    int32_t *ubuf = static_cast<int32_t *>(scratch(50, (size_t)(width + 1) * dp.u_stride * 4));
+    unsigned long long *dtimes = static_cast<unsigned long long *>(scratch(43, (size_t)4 * width * 8));
+    hipStream_t st;
+    hip_check(hipStreamCreateWithFlags(&st, hipStreamNonBlocking), "probe stream");
+    hipEvent_t e0, e1;
+    hip_check(hipEventCreate(&e0), "probe event");
+    hip_check(hipEventCreate(&e1), "probe event");
+    // launches back to back, the last one stamped and timed: what a level of a circuit sees
+    // (TFHE_HIP_PROBE_WARM = "count:width" changes the unstamped launches before it, default one of the same width)
+    int warm_count = 1, warm_width = width;
+    if (const char *env = std::getenv("TFHE_HIP_PROBE_WARM")) std::sscanf(env, "%d:%d", &warm_count, &warm_width);
+    warm_width = std::max(1, std::min(warm_width, width));
+    for (int w = 0; w < warm_count; ++w) launch_br(key, pool, drots, warm_width, ubuf, nullptr, st);
+    // cleared first so that a launch which wrote no stamps is noticed instead of read as timings
+    hip_check(hipMemsetAsync(dtimes, 0, (size_t)4 * width * 8, st), "clear stamps");
+    wg_times_dbg_ = dtimes;
+    hip_check(hipEventRecord(e0, st), "probe event record");
+    launch_br(key, pool, drots, width, ubuf, nullptr, st);
+    hip_check(hipEventRecord(e1, st), "probe event record");
+    hip_check(hipStreamSynchronize(st), "probe stamps");
+    wg_times_dbg_ = nullptr;
+    float ems = 0.f;
+    hip_check(hipEventElapsedTime(&ems, e0, e1), "probe event time");
+    (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
+    hip_check(hipMemcpy(wg_times, dtimes, (size_t)4 * width * 8, hipMemcpyDeviceToHost), "probe stamps copy");
+    hip_check(hipStreamDestroy(st), "probe stream destroy");
+    for (int i = 0; i < width; ++i)
+        if (wg_times[4 * i] == 0 || wg_times[4 * i + 1] == 0) return -1.0;      // a workgroup left no stamp
+    return (double)ems;
 }
 
 void Engine::run_negacyclic(const DeviceKeyImage *key, const int32_t *ip, const Torus32 *tp, Torus32 *res, int count) {
     ENGINE_DEVICE_SCOPE();
     wait_flight();
     DevParams dp = key->dp;
-    // 2: through the split transforms; 3: first transpose through the cross-lane paths (N = 1024; same results);
-    // 4 / 5: timing forms of the LDS / cross-lane transform repeated 64 times (results meaningless)
-    dp.br_variant = br_variant >= 2 && br_variant <= 5 ? br_variant : 0;
-    if (dp.br_variant >= 3 && dp.N != 1024) dp.br_variant = 0;
+    dp.br_variant = br_variant == 2 ? 2 : 0;            // 2: through the split transforms
     const size_t words = (size_t)count * dp.N;
     uint32_t scale[2];
     (void)make_twiddles(dp.N, scale);

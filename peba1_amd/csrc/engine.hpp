@@ -39,6 +39,9 @@ const char *unsupported_reason(const Params &p);   // why the kernels cannot run
 // the call left without effect.  fatal() (abort, like upstream) is kept for HIP runtime
 // failures and for "no GPU", after which nothing can work.
 struct ApiError { std::string msg; };
+// test hook: device allocations of the slot pool and the flush scratch beyond `bytes` in total fail like hipErrorOutOfMemory
+// (recoverably: engine.cpp recoverable_alloc); 0 = no cap
+void set_alloc_cap(long long bytes);
 [[noreturn]] void api_fail(const std::string &msg);
 
 // Pool of device-resident ciphertext slots (ct_stride words each).  Slots are
@@ -128,51 +131,30 @@ public:
 
     TfheHipStats stats{};
     bool kernel_timing = false;
-    // launches of at most this many rotations use the 4-wave kernel; measured
-    // (tools/width_sweep.py) it matches or beats the 2-wave form at every width, so the
-    // default is "always"; the 2-wave form stays selectable and tested
-    int br4_max_rotations = 1 << 30;
-    // key switches of a launch are split (power of two <= ks_max_splits) until about this many
-    // workgroups exist: beyond filling the chip, more splits mean the blocks in flight share a
-    // KSK sub-table small enough for an XCD's L2 (measured optimum of the per-gate kernel: 32 splits).  The tiled launches
-    // take any count of coefficient ranges up to ks_max_splits whose grid fills whole rounds of resident workgroups
-    // (launch_ks); with the index form of the key switch a cap of 48 measured 56.1 against 61.0 ms per match at 32
-    // (24: 64.4, 64: 57.1; tools/diag/r4_ks_splits.sh, env TFHE_HIP_KS_MAX_SPLITS)
+    // Tunings (tfhe_hip_set_tuning; ten names in all: these six, the recorder's reuse_gates / eliminate_dead /
+    // balance_levels, and sync_deadline_ms above).  HISTORY.md lists the forms and knobs removed in round 6.
+    //
+    // Key switches of a narrow launch are split (power of two <= ks_max_splits) until about ks_target_blocks workgroups
+    // exist: beyond filling the chip, more splits mean the blocks in flight share a KSK sub-table small enough for an
+    // XCD's L2 (measured optimum of the per-gate kernel: 32 splits).  The tiled launches take any count of coefficient
+    // ranges up to ks_max_splits whose grid fills whole rounds of resident workgroups (launch_ks); a cap of 48 measured
+    // 56.1 against 61.0 ms per match at 32 (env TFHE_HIP_KS_BLOCKS, TFHE_HIP_KS_MAX_SPLITS; not tunings)
     int ks_target_blocks = 32768;
     int ks_max_splits = 48;
     // among the range counts that fill the workgroup slots equally well: 1 = the largest (more, shorter ranges), 0 = the smallest
-    // (less partial-sum traffic; 16 matches per flush: key switch 772 against 834 ms, one match 55.4 against 56.1 ms;
-    // env TFHE_HIP_KS_SPLIT_TIES)
+    // (less partial-sum traffic: one match 55.4 against 56.1 ms; env TFHE_HIP_KS_SPLIT_TIES)
     int ks_split_ties = 0;
-    // gates per workgroup of the tiled key switch (16 or 32; 0 = per-gate kernel only)
+    // gates per workgroup of the tiled key switch (16, 24 or 32; 0 = per-gate kernel only); tuning "ks_tile"
     int ks_tile = 16;
-    // 1 = the coefficient ranges of a key switch add their partial sums into the (zeroed) destination slot with
-    // 32-bit atomic adds instead of writing them out for a reduce launch (env TFHE_HIP_KS_ATOMIC, tuning "ks_atomic")
-    int ks_atomic = 0;
-    // 1 = the tiled key switch gives a thread 2 words of the row instead of 4: 5 light waves per workgroup at n = 630
-    // instead of 3 heavy ones (kernels.hip keyswitch_tile_kernel W; env TFHE_HIP_KS_NARROW, tuning "ks_narrow"); measured
-    // slower (126 against 111 ms per match), so off
-    int ks_narrow = 0;
-    // 1 = the tiled key switch issues the strip reads of the next pair of gates before it subtracts the current pair's rows
-    // (keyswitch_tile_kernel PIPE; env TFHE_HIP_KS_PIPE, tuning "ks_pipe"): 105 against 111.5 ms per match, so on
-    int ks_pipe = 1;
-    // register forms of the tiled key switch (env TFHE_HIP_KS_BRANCH, tuning "ks_branch"; ignored with ks_atomic):
-    // 2 (default) = a thread's column of the staged rows in PINNED registers, picked through the VGPR index mode
-    // (kernels.hip keyswitch_index_kernel; tiles of 16, 24 or 32): 60.8 ms per match against 105 ms of the LDS-strip form;
-    // 1 = rows in registers, picked by scalar branches (keyswitch_branch_kernel): 73 ms; 0 = the LDS-strip form
-    int ks_branch = 2;
-    // blind rotate, 4-wave form: k > 0 = the workgroups sharing a CU swap issue priority every 2^k shader cycles
-    // (rounds 1-4: default 18; without anything the hardware's oldest-first issue runs one at full speed and leaves the
-    // other to finish alone).  Round 5: the kernel sets a wave's priority by its progress through the step
-    // (kernels.hip blind_rotate4_body), which measured 3-4 % faster than the time slices and loses that with the
-    // slices on top: default 0; env TFHE_HIP_BR_FAIR, tuning "br_fair"
-    int br_fair = 0;
-    // which form of the blind-rotate kernel runs wide launches (kernels.hip): -1 = the fastest measured
-    // for the ring size, 0 = 4-wave wide at N = 1024 (D and 64-bit partial sums in registers, two
-    // workgroups per CU) / 4-wave lean at N = 2048, 1 = 4-wave lean at N = 1024 (three per CU),
-    // 2 = split (8 waves, half transforms); env TFHE_HIP_BR_VARIANT, tuning "br_variant"
+    // 1 (default) = the tiled key switch keeps a thread's column of the staged rows in PINNED registers, picked through the
+    // VGPR index mode (kernels.hip keyswitch_index_kernel): 56 ms per match; 0 = the LDS-strip form (keyswitch_strip_kernel,
+    // tiles of 16): 105 ms -- plain HIP source, the form to fall back on.  Tuning "ks_index", env TFHE_HIP_KS_INDEX
+    int ks_index = 1;
+    // which form of the blind-rotate kernel runs wide launches (kernels.hip): -1 = the fastest measured for the ring size
+    // (N = 1024: 4-wave; N = 2048: split), 0 = 4-wave (N = 1024), 2 = split (8 waves, half transforms), 4 = 2-wave
+    // (N = 1024).  A form whose lazy-arithmetic bounds do not admit the key's gadget is replaced by one that does
+    // (launch_br).  Tuning "br_variant", env TFHE_HIP_BR_VARIANT
     int br_variant = -1;
-    bool br_split_auto_2048 = true;     // measured: 21.9k against 19.1k rotations/s, and half the latency
     // launches of at most min(this, CU count) rotations (at most one workgroup per CU) use the 8-wave form
     // of the kernel, N = 1024 only; 0 = never (env TFHE_HIP_BR8_MAX, tuning "br8_max_rotations")
     int br8_max_rotations = 1 << 30;
@@ -184,18 +166,15 @@ public:
     // of at most 7 bits; split form: stage 0, and the first radix-4 step too where digits have at most 6
     // bits); 2 = split form: stage 0 only; 0 = multiplies (env TFHE_HIP_BR_TABLE, tuning "br_digit_table")
     int br_digit_table = 1;
-    // stream == nullptr: the engine's stream; `scratch_set` selects the scratch buffer of the partial sums (the lane probe
-    // runs several chains at once)
+    // stream == nullptr: the engine's stream
     void launch_ks(const DeviceKeyImage *key, const int32_t *u_buf, const KsDesc *descs, int count, int32_t *pool,
-                   hipStream_t stream = nullptr, int scratch_set = 0);
+                   hipStream_t stream = nullptr);
     // returns true when the launch used the 8-wave form
     bool launch_br(const DeviceKeyImage *key, const int32_t *pool, const RotDesc *rots, int count, int32_t *u_buf,
-                   int32_t *acc_dbg, hipStream_t stream = nullptr, int wave_prio = 0);
-    // diagnostic (tools/lane_probe.py): `levels` rounds of (blind rotate + key switch) of `width`
-    // random gates in total, issued as `lanes` independent chains on `lanes` streams; returns ms
-    // wg_times != nullptr: instead, ONE blind-rotate launch of `width` gates whose workgroups stamp
-    // s_memtime and s_memrealtime at start and end into wg_times[4 * width]; returns that launch's event time
-    double run_lane_probe(const DeviceKeyImage *key, int lanes, int levels, int width, unsigned long long *wg_times = nullptr);
+                   int32_t *acc_dbg, hipStream_t stream = nullptr);
+    // diagnostic (tools/wg_times.py): ONE 4-wave blind-rotate launch of `width` random gates whose workgroups stamp s_memtime
+    // and s_memrealtime at start and end into wg_times[4 * width]; returns that launch's event time in ms (< 0: no stamps)
+    double run_wg_times(const DeviceKeyImage *key, int width, unsigned long long *wg_times);
 
 private:
     Engine() = default;
@@ -222,7 +201,6 @@ private:
     int cu_count_ = 256;
     std::atomic<bool> inited_{false};
     hipStream_t stream_ = nullptr;
-    uint32_t *cu_arrivals_ = nullptr;
     unsigned long long *clock_acc_ = nullptr;           // kernel timing: shader-cycle / reference-tick sums (kernels.hpp)
     unsigned long long *wg_times_dbg_ = nullptr;        // set by the workgroup-time probe only
     size_t timing_used_ = 0;

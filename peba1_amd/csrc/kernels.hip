@@ -2,18 +2,19 @@
 //
 //   K6    bk_transform_kernel     Torus32 bootstrapping key -> NTT image (once per key)
 //   K1+K2 blind_rotate4_kernel    gate prelude, modulus switch, blind rotate (n external
-//                                 products), sample extract; four wave64 per rotation (default at N = 1024)
+//                                 products), sample extract; four wave64 per rotation (N = 1024: the streaming form)
 //         blind_rotate8_kernel    eight wave64 per rotation (two per prime and input polynomial) for launches of
 //                                 at most one workgroup per CU: narrow levels, single gates (N = 1024)
 //         blind_rotate_split_kernel  eight wave64 per rotation, every transform as two half-size ones
-//                                 (default at N = 2048; selectable at N = 1024)
-//         blind_rotate_kernel     two wave64 per rotation (selectable, tested)
+//                                 (N = 2048; at N = 1024 the form with the widest admissible gadget range but one)
+//         blind_rotate2_kernel    two wave64 per rotation, no tables, one reduction per step: the form whose lazy
+//                                 bounds admit the widest gadgets (br_forms.hpp) -- the admissibility fallback (N = 1024)
 //   K3/K4 keyswitch_index_kernel  (u0 [+ u1] + const) -> LWE sample under the gate key (default for wide launches): one
-//                                 pass over the KSK rows of a coefficient range serves a tile of 16 gates; a thread's
-//                                 column of the staged rows sits in pinned VGPRs picked through the VGPR index mode
-//                                 by the wave-uniform digit (statements generated: ks_index_asm.inc)
-//         keyswitch_branch_kernel / keyswitch_tile_kernel  the scalar-branch and LDS-strip forms of the same tile
-//                                 (selectable with "ks_branch" 1 / 0, tested)
+//                                 pass over the KSK rows of a coefficient range serves a tile of 16 / 24 / 32 gates; a
+//                                 thread's column of the staged rows sits in pinned VGPRs picked through the VGPR index
+//                                 mode by the wave-uniform digit (statements generated: ks_index_asm.inc)
+//         keyswitch_strip_kernel  the same tile with the staged rows in thread-private LDS strips: plain HIP source, no
+//                                 pinned registers (tuning "ks_index" 0)
 //         keyswitch_kernel        per-gate form for narrow launches; ks_reduce_kernel adds the
 //                                 partial sums of the ranges
 //   K5    not_kernel              negation
@@ -34,6 +35,9 @@
 // barriers per step.
 // 2-wave form: wave q does all arithmetic modulo prime q (2l forward and 2 inverse NTTs per
 // step), swaps one residue polynomial with its partner and CRT-recombines the one it owns.
+// Forms measured slower everywhere and removed in round 6 (HISTORY.md): the lean 4-wave forms (three workgroups per
+// CU at N = 1024; the only 4-wave form that fitted N = 2048), the time-sliced issue priority, the W = 2 / atomic /
+// unpipelined LDS-strip key switches and the scalar-branch register key switch.
 #include <type_traits>
 
 #include "kernels.hpp"
@@ -119,10 +123,7 @@ __global__ __launch_bounds__(64) void bk_transform_kernel(const int32_t *__restr
 // ---------------------------------------------------------------------------
 // test kernel: res = ip * tp (negacyclic, mod 2^32), tp given as image
 // ---------------------------------------------------------------------------
-// XLANE: the forward transform's first transpose through v_permlane32_swap / v_permlane16_swap / DPP instead of LDS
-// (N = 1024; measurement only, tools/diag/crosslane.sh -> DESIGN.md section 5); REPS > 1 repeats the forward
-// transform on its own output so that the transform dominates the kernel's time (timing runs only: results differ)
-template <int LOGN, bool XLANE = false, int REPS = 1>
+template <int LOGN>
 __global__ __launch_bounds__(128) void negacyclic_kernel(const int32_t *__restrict__ ip, const uint32_t *__restrict__ img,
                                                          const uint32_t *__restrict__ tw, int32_t *__restrict__ res) {
     using NTT = WaveNtt<LOGN>;
@@ -137,17 +138,7 @@ __global__ __launch_bounds__(128) void negacyclic_kernel(const int32_t *__restri
     int32_t x[REGS];
 #pragma unroll
     for (int r = 0; r < REGS; ++r) x[r] = src[r * 64 + lane];
-#pragma unroll 1
-    for (int rep = 0; rep < REPS; ++rep) {
-        if constexpr (REPS > 1) {
-            if (rep > 0) {               // back to small inputs in natural order (any values do for timing)
-#pragma unroll
-                for (int r = 0; r < REGS; ++r) x[r] = (x[r] >> 20) + rep;
-            }
-        }
-        if constexpr (XLANE) NTT::forward_crosslane(x, c, scr, lane);
-        else NTT::forward(x, c, scr, lane);
-    }
+    NTT::forward(x, c, scr, lane);
     const uint4 *bp = reinterpret_cast<const uint4 *>(img + (size_t)(blockIdx.x * 2 + q) * N) + lane;
     int64_t acc[REGS];
 #pragma unroll
@@ -213,47 +204,16 @@ __device__ __forceinline__ uint32_t testvector_coef(int j, int barb, int32_t mu)
     return (idx & N) ? (uint32_t)(-mu) : (uint32_t)mu;
 }
 
-// How the 4-wave kernel trades registers and LDS for instructions.  The kernel is bound by
-// multiplier-class VALU issue plus dependency stalls, not by memory, so the
-// forms differ in what they keep in registers; all were measured at 4,096 rotations per launch
-// (profiles/r02_kernel_forms.txt):
-//   N = 1024, form 0 (default) "wide": D and both 64-bit row sums in registers, a pass's twiddles
-//       loaded one transpose ahead, three exchange buffers per wave: 241 VGPRs, two workgroups per
-//       CU, 43.4-44.7 ms.
-//   N = 1024, form 1 "lean": D recomputed per gadget row, the sum sent to the partner wave reduced per
-//       row (32-bit), one exchange buffer per wave (one more barrier per step): 161 VGPRs, THREE
-//       workgroups per CU -- and slower (50.7 ms: ~8 % more instructions, 45 % longer latency per
-//       workgroup, which the third workgroup does not buy back).  Kept selectable and tested.
-//   N = 2048 (32 coefficients per lane): only the lean form, with BOTH sums reduced per row, fits two
-//       workgroups per CU (256 VGPRs + 27 spilled words); 196 ms against 226-230 ms for the forms
-//       that keep a 64-bit sum or run one workgroup per CU.
-template <int LOGN, int V = 0>
-struct BrTraits {
-    static constexpr bool LEAN = LOGN != 10 || V == 1;
-    static constexpr bool KEEP_D = !LEAN;                       // D in registers across the gadget rows
-    static constexpr bool WIDE_SEND = !LEAN;                    // the sum sent to the partner wave: 64-bit, reduced once
-    static constexpr bool WIDE_KEEP = LOGN == 10;               // the sum this wave keeps: likewise
-    static constexpr bool EARLY_TW = true;                      // twiddles of a pass loaded before the transpose in front of it
-    static constexpr int ACC_RUNS = LOGN == 10 ? 3 : 2;
-    static constexpr bool MERGED_BUFFERS = LEAN;
-    // the per-lane twiddles of the forward transforms' second and third pass live in LDS (ntt_wave.hpp forward_digits
-    // LDSTW): the default form at N = 1024, whose 80,400 bytes still let two workgroups share a CU
-    static constexpr bool LDS_TWIDDLES = LOGN == 10 && V == 0;
-    static constexpr int WAVES_PER_SIMD = LOGN == 10 && V == 1 ? 3 : 2;
-};
-
-// The accumulator in LDS.  Each polynomial is kept as runs of N words, (acc, -acc[, acc]):
+// The accumulator in LDS.  Each polynomial is kept as three runs of N words, (acc, -acc, acc):
 // coefficient (j - abar) mod 2N of the negacyclic rotation X^abar * ACC is then word
-// ((lane - abar) mod 2N) + 64 r of that array.  With three runs that is one address per lane and
-// step, the 64 r being the immediate offset of the LDS read: no wrap and no sign selection per
-// coefficient.  With two runs the index is wrapped mod 2N per coefficient (one AND).
-template <int LOGN, int RUNS = BrTraits<LOGN, 0>::ACC_RUNS>
+// ((lane - abar) mod 2N) + 64 r of that array -- one address per lane and step, the 64 r being the
+// immediate offset of the LDS read: no wrap and no sign selection per coefficient.
+template <int LOGN>
 struct AccLds {
     static constexpr int N = 1 << LOGN;
-    uint32_t w[2][RUNS * N];
+    uint32_t w[2][3 * N];
     __device__ __forceinline__ void set(int u, int j, uint32_t v) {
-        w[u][j] = v; w[u][N + j] = 0u - v;
-        if constexpr (RUNS == 3) w[u][2 * N + j] = v;
+        w[u][j] = v; w[u][N + j] = 0u - v; w[u][2 * N + j] = v;
     }
     __device__ __forceinline__ uint32_t get(int u, int j) const { return w[u][j]; }
     // D[r] = coefficient 64 r + lane of (X^abar - 1) ACC_u, offset added and digit tops flipped
@@ -263,22 +223,17 @@ struct AccLds {
         // -ACC comes from the negated run, so that rot - acc + offset is ONE three-operand add (v_add3_u32) instead of a
         // subtraction and an addition (round 4: 16 VALU instructions less per wave and step)
         const uint32_t *own_neg = w[u] + N + lane;
-        if constexpr (RUNS == 3) {
-            const uint32_t *rot = w[u] + base;
+        const uint32_t *rot = w[u] + base;
 #pragma unroll
-            for (int r = 0; r < REGS; ++r) D[r] = (rot[r * 64] + own_neg[r * 64] + offset) ^ offset;
-        } else {
-#pragma unroll
-            for (int r = 0; r < REGS; ++r)
-                D[r] = (w[u][(base + r * 64) & (uint32_t)(2 * N - 1)] + own_neg[r * 64] + offset) ^ offset;
-        }
+        for (int r = 0; r < REGS; ++r) D[r] = (rot[r * 64] + own_neg[r * 64] + offset) ^ offset;
     }
 };
 
 // One input polynomial u of one blind-rotate step, modulo the wave's prime:
 // D = (X^abar - 1) * ACC_u, its l gadget digits, forward NTT of each, and the
 // multiply-accumulate against key rows u*l+jj for both output polynomials
-// (acc0 <- output poly 0, acc1 <- output poly 1; exchanged when swap_outputs).
+// (acc0 <- output poly 0, acc1 <- output poly 1; exchanged when swap_outputs).  D and both 64-bit row sums stay in
+// registers across the gadget rows; a pass's twiddles are loaded one transpose ahead.
 // FRESH: acc0 / acc1 are written, not accumulated into -- the first row multiplies, the others
 // multiply-add (no zeroing of 4*REGS registers per step); otherwise every row accumulates.
 // Digits (tfhe tGswTorus32PolynomialDecompH): digit_jj = ((D + offset) >> s_jj) & (Bg-1)) - Bg/2.  The
@@ -289,68 +244,39 @@ struct AccLds {
 // them per row, and 12 fewer vector registers)
 // PROGRESS (4-wave form): the wave's issue priority follows its progress through the step -- 0 for the first gadget row,
 // 1 for the second, 2 from the third (blind_rotate4_body raises it to 3 for the step's tail).
-template <int LOGN, bool FRESH, bool KEEP_D, bool EARLY_TW, bool TABLE, typename Acc0T, typename Acc1T, bool LDSTW = false,
-          bool PROGRESS = false>
+template <int LOGN, bool FRESH, bool TABLE, bool LDSTW = false, bool PROGRESS = false>
 __device__ __forceinline__ void forward_poly(const DevParams &p, const DevKey &key, const PrimeCtx &c,
                                              const AccLds<LOGN> &lds_acc, uint32_t *scr,
                                              int lane, int q, int i, int u, int abar, bool swap_outputs,
-                                             Acc0T (&acc0)[WaveNtt<LOGN>::REGS], Acc1T (&acc1)[WaveNtt<LOGN>::REGS],
+                                             int64_t (&acc0)[WaveNtt<LOGN>::REGS], int64_t (&acc1)[WaveNtt<LOGN>::REGS],
                                              const typename WaveNtt<LOGN>::FwdTw0 &t0, int jbegin = 0, int jend = -1) {
     using NTT = WaveNtt<LOGN>;
     constexpr int N = NTT::N, REGS = NTT::REGS, G4 = REGS / 4;
-    // a sum is kept in 64 bits and reduced once, or Montgomery-reduced per row (|.| < 0.72P each)
-    constexpr bool WIDE0 = sizeof(Acc0T) == 8, WIDE1 = sizeof(Acc1T) == 8;
-    uint32_t Dk[KEEP_D ? REGS : 1];
-    if constexpr (KEEP_D) lds_acc.template rotated_difference<REGS>(Dk, u, lane, abar, p.decomp_offset);
+    uint32_t Dk[REGS];
+    lds_acc.template rotated_difference<REGS>(Dk, u, lane, abar, p.decomp_offset);
     const int o0 = swap_outputs ? N / 4 : 0, o1 = N / 4 - o0;          // uint4 offset of output poly 0 / 1
     const int width = p.Bgbit;
     auto row = [&](int jj, auto first) {
         const int prow = u * p.l + jj;
         const uint4 *bp = reinterpret_cast<const uint4 *>(
                               key.bk_img + ((size_t)((size_t)i * p.kpl + prow) * 2 + q) * 2 * N) + lane;
-        // key rows: both output polynomials are requested before the transform so that their latency
-        // hides under it -- except where registers are short (the lean forms), where the second
-        // polynomial's row, and at N = 2048 both, are requested after the transform
+        // key rows: both output polynomials are requested before the transform so that their latency hides under it
         uint4 b0[G4], b1[G4];
-        constexpr bool LATE_B0 = !KEEP_D && LOGN == 11;     // N = 2048: both rows after the transform (7 instead of 27 spilled words)
-        if constexpr (!LATE_B0) {
 #pragma unroll
-            for (int g = 0; g < G4; ++g) b0[g] = bp[o0 + g * 64];
-        }
-        if constexpr (KEEP_D) {
+        for (int g = 0; g < G4; ++g) b0[g] = bp[o0 + g * 64];
 #pragma unroll
-            for (int g = 0; g < G4; ++g) b1[g] = bp[o1 + g * 64];
-        }
+        for (int g = 0; g < G4; ++g) b1[g] = bp[o1 + g * 64];
         const int shift = 32 - (jj + 1) * width;
         int32_t x[REGS];
-        if constexpr (KEEP_D) {
-            NTT::template forward_digits<EARLY_TW, TABLE, LDSTW>(x, Dk, shift, width, c, scr, lane, t0);
-        } else {
-            uint32_t D[REGS];
-            lds_acc.template rotated_difference<REGS>(D, u, lane, abar, p.decomp_offset);
-            NTT::template forward_digits<EARLY_TW, TABLE, LDSTW>(x, D, shift, width, c, scr, lane, t0);
-        }
-        if constexpr (LATE_B0) {
-#pragma unroll
-            for (int g = 0; g < G4; ++g) b0[g] = bp[o0 + g * 64];
-        }
-        if constexpr (!KEEP_D) {
-#pragma unroll
-            for (int g = 0; g < G4; ++g) b1[g] = bp[o1 + g * 64];
-        }
+        NTT::template forward_digits<TABLE, LDSTW>(x, Dk, shift, width, c, scr, lane, t0);
 #pragma unroll
         for (int g = 0; g < G4; ++g) {
             const int32_t bb0[4] = {(int32_t)b0[g].x, (int32_t)b0[g].y, (int32_t)b0[g].z, (int32_t)b0[g].w};
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
                 const int r = 4 * g + e;
-                if constexpr (decltype(first)::value) {
-                    if constexpr (WIDE0) acc0[r] = (int64_t)x[r] * bb0[e];
-                    else acc0[r] = mont_redc((int64_t)x[r] * bb0[e], c.P, c.pinv);
-                } else {
-                    if constexpr (WIDE0) acc0[r] += (int64_t)x[r] * bb0[e];
-                    else acc0[r] += mont_redc((int64_t)x[r] * bb0[e], c.P, c.pinv);
-                }
+                if constexpr (decltype(first)::value) acc0[r] = (int64_t)x[r] * bb0[e];
+                else acc0[r] += (int64_t)x[r] * bb0[e];
             }
         }
 #pragma unroll
@@ -359,13 +285,8 @@ __device__ __forceinline__ void forward_poly(const DevParams &p, const DevKey &k
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
                 const int r = 4 * g + e;
-                if constexpr (decltype(first)::value) {
-                    if constexpr (WIDE1) acc1[r] = (int64_t)x[r] * bb1[e];
-                    else acc1[r] = mont_redc((int64_t)x[r] * bb1[e], c.P, c.pinv);
-                } else {
-                    if constexpr (WIDE1) acc1[r] += (int64_t)x[r] * bb1[e];
-                    else acc1[r] += mont_redc((int64_t)x[r] * bb1[e], c.P, c.pinv);
-                }
+                if constexpr (decltype(first)::value) acc1[r] = (int64_t)x[r] * bb1[e];
+                else acc1[r] += (int64_t)x[r] * bb1[e];
             }
         }
     };
@@ -400,12 +321,14 @@ __device__ __forceinline__ void extract_sample(const DevParams &p, const RotDesc
 
 // ---------------------------------------------------------------------------
 // K1+K2: blind rotate, 2-wave form.  grid = rotations, 128 threads: wave q works
-// modulo prime q and handles both input polynomials (6 forward + 2 inverse NTTs
-// per step), 4 workgroups per CU.  Kept selectable ("br4_max_rotations" = 0) and
-// tested; the 4-wave form below is faster at every launch width (N = 1024 only).
+// modulo prime q and handles both input polynomials (2l forward + 2 inverse NTTs
+// per step).  Slower than the 4-wave form at every launch width; kept because all 2l rows of an output polynomial
+// are summed in 64 bits and reduced ONCE, without tables: its bounds admit gadgets no other form does (br_forms.hpp
+// BR_FORM_WAVE2, e.g. N = 1024, l = 9, Bg = 2^3) -- the last entry of the engine's fallback order, selectable with
+// "br_variant" 4 (N = 1024 only).
 // ---------------------------------------------------------------------------
 template <int LOGN>
-__global__ __launch_bounds__(128) void blind_rotate_kernel(DevParams p, DevKey key, const int32_t *__restrict__ pool,
+__global__ __launch_bounds__(128) void blind_rotate2_kernel(DevParams p, DevKey key, const int32_t *__restrict__ pool,
                                                            const RotDesc *__restrict__ rots,
                                                            int32_t *__restrict__ u_buf, int32_t *__restrict__ acc_dbg) {
     using NTT = WaveNtt<LOGN>;
@@ -441,8 +364,8 @@ __global__ __launch_bounds__(128) void blind_rotate_kernel(DevParams p, DevKey k
         if (abar == 0) continue;                            // tfhe_blindRotate_FFT skips these too
 
         int64_t acc0[REGS], acc1[REGS];
-        forward_poly<LOGN, true, true, true, false>(p, key, c, lds_acc, scr, lane, q, i, 0, abar, false, acc0, acc1, t0);
-        forward_poly<LOGN, false, true, true, false>(p, key, c, lds_acc, scr, lane, q, i, 1, abar, false, acc0, acc1, t0);
+        forward_poly<LOGN, true, false>(p, key, c, lds_acc, scr, lane, q, i, 0, abar, false, acc0, acc1, t0);
+        forward_poly<LOGN, false, false>(p, key, c, lds_acc, scr, lane, q, i, 1, abar, false, acc0, acc1, t0);
 
         int32_t y0[REGS], y1[REGS];
         finish_inverse<LOGN>(acc0, y0, c, scr, lane);
@@ -500,42 +423,41 @@ __device__ unsigned long long g_stamps[8][8];      // [wave][phase]; the 4-wave 
 // wave (q,u) works modulo prime q on input polynomial u (l forward NTTs), hands
 // the partial sum of the other output polynomial to wave (q,1-u), runs ONE
 // inverse NTT for output polynomial u, and shares the CRT with wave (1-q,u).
-// Three workgroup barriers per step.  N = 1024: 2 workgroups per CU; N = 2048: 1.
+// Three workgroup barriers per step.  N = 1024 only (241 VGPRs, two workgroups per CU): D and both 64-bit row sums in
+// registers, a pass's twiddles loaded one transpose ahead, three exchange buffers per wave.  (N = 2048 runs the split form:
+// 32 coefficients per lane do not fit the register file without reducing both sums per row, 196 against 142 ms per 4,096.)
 // ---------------------------------------------------------------------------
-// LDS of one 4-wave workgroup.  Each wave has two exchange areas: the scratch of its NTT transposes (private while
-// a transform runs; from the end of its inverse transform to the step's last barrier it carries the residues of the
-// half its CRT partner recombines -- nobody else touches it in between) and the partial sums it sends to the wave of
-// the other input polynomial.  MERGED_BUFFERS: both are one buffer (one more barrier per step, blind_rotate4_body).
-template <int LOGN, int V = 0>
+// LDS of one 4-wave workgroup (81,428 B: two per CU).  Each wave has two exchange areas: the scratch of its NTT
+// transposes (private while a transform runs; from the end of its inverse transform to the step's last barrier it carries
+// the residues of the half its CRT partner recombines -- nobody else touches it in between) and the partial sums it sends
+// to the wave of the other input polynomial.
+template <int LOGN>
 struct Br4Lds {
     using NTT = WaveNtt<LOGN>;
-    static constexpr bool MERGED = BrTraits<LOGN, V>::MERGED_BUFFERS;
-    static constexpr bool LTW = BrTraits<LOGN, V>::LDS_TWIDDLES;
     AccLds<LOGN> acc;                              // the accumulator (signed runs), resident for all n steps
     uint32_t buf0[4][NTT::SCRATCH_WORDS];          // per wave: transpose scratch (layouts R and H of ntt_wave.hpp), then residues
-    uint32_t buf1[MERGED ? 1 : 4][MERGED ? 4 : NTT::ROW_WORDS];   // per wave: the partial sums sent (rows only: layout R)
+    uint32_t buf1[4][NTT::ROW_WORDS];              // per wave: the partial sums sent (rows only: layout R)
     uint16_t bar[1024 + 8];                        // modulus-switched mask and body
     alignas(8) uint32_t dtab[2][5 * DIGIT_TAB];    // per prime: first-step products of the gadget digits (ntt_wave.hpp)
     // per prime: the forward transforms' second-pass twiddles (one image per group of 2^LC lanes) and third-pass
     // twiddles (one per lane)
-    uint4 ft1[LTW ? 2 : 1][LTW ? (64 >> NTT::LC) : 1][NTT::FwdTw1::IMAGE16];
-    uint4 ft2[LTW ? 2 : 1][LTW ? 64 : 1][NTT::FwdTw2::IMAGE16];
+    uint4 ft1[2][64 >> NTT::LC][NTT::FwdTw1::IMAGE16];
+    uint4 ft2[2][64][NTT::FwdTw2::IMAGE16];
     __device__ __forceinline__ uint32_t *scr(int wv) { return buf0[wv]; }
-    __device__ __forceinline__ uint32_t *x1(int wv) { return MERGED ? buf0[wv] : buf1[wv]; }
+    __device__ __forceinline__ uint32_t *x1(int wv) { return buf1[wv]; }
     __device__ __forceinline__ uint32_t *x2(int wv) { return buf0[wv]; }
 };
-static_assert(sizeof(Br4Lds<10, 0>) <= 80 * 1024, "two workgroups of the default form must fit the 160 KB of a CU");
+static_assert(sizeof(Br4Lds<10>) <= 80 * 1024, "two workgroups of the 4-wave form must fit the 160 KB of a CU");
 
 // prelude + modulus switch + the n-step blind rotation of one descriptor; the result is left
 // in sh.acc (complete for every thread on return)
 // TAB: the first radix-4 step of every forward transform reads digit products from an LDS table
 // (gadget digits of at most DIGIT_TAB_BITS bits: every built-in set but the legacy Bg = 2^10 one)
-template <int LOGN, int V = 0, bool TAB = false>
+template <int LOGN, bool TAB>
 __device__ __forceinline__ void blind_rotate4_body(const DevParams &p, const DevKey &key,
                                                    const int32_t *__restrict__ pool, const RotDesc &rd,
-                                                   Br4Lds<LOGN, V> &sh, int tid, int parity = 0) {
+                                                   Br4Lds<LOGN> &sh, int tid) {
     using NTT = WaveNtt<LOGN>;
-    using TR = BrTraits<LOGN, V>;
     constexpr int N = NTT::N, REGS = NTT::REGS, HALF = REGS / 2;
     const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int q = wv & 1, u = wv >> 1;
@@ -550,19 +472,17 @@ __device__ __forceinline__ void blind_rotate4_body(const DevParams &p, const Dev
         NTT::build_digit_table(sh.dtab[q], c, p.Bgbit, (u << 6) | lane, 128);
         c.dtab = sh.dtab[q];
     }
-    if constexpr (TR::LDS_TWIDDLES) {
-        // wave (q, 0) copies prime q's pass-2 / pass-3 twiddles of the forward transforms into LDS, once
-        if (u == 0) {
-            typename NTT::FwdTw1 a;
-            a.load(c, lane);
-            if ((lane & ((1 << NTT::LC) - 1)) == 0) a.to_image(sh.ft1[q][lane >> NTT::LC]);
-            typename NTT::FwdTw2 b;
-            b.load(c, lane);
-            b.to_image(sh.ft2[q][lane]);
-        }
-        c.fw1 = sh.ft1[q][lane >> NTT::LC];
-        c.fw2 = sh.ft2[q][lane];
+    // wave (q, 0) copies prime q's pass-2 / pass-3 twiddles of the forward transforms into LDS, once
+    if (u == 0) {
+        typename NTT::FwdTw1 a;
+        a.load(c, lane);
+        if ((lane & ((1 << NTT::LC) - 1)) == 0) a.to_image(sh.ft1[q][lane >> NTT::LC]);
+        typename NTT::FwdTw2 b;
+        b.load(c, lane);
+        b.to_image(sh.ft2[q][lane]);
     }
+    c.fw1 = sh.ft1[q][lane >> NTT::LC];
+    c.fw2 = sh.ft2[q][lane];
     __syncthreads();
     if (q == 0) {
         const int barb = sh.bar[n];
@@ -580,33 +500,21 @@ __device__ __forceinline__ void blind_rotate4_body(const DevParams &p, const Dev
 
     // Issue priority by PROGRESS (round 5).  The workgroups that share a CU put one wave each on every SIMD, and the SIMD
     // arbitrates their issue by priority, then age: left alone, the older workgroup runs at the pace of a lone wave and the
-    // younger gets the leftover slots, then finishes alone.  Rounds 1-4 let them take turns by time slices of 2^18 cycles
-    // ("br_fair").  Now a wave's priority follows its progress through the step: 0 in the first gadget row, 1 in the second,
-    // 2 from the third, 3 from the first barrier to the last (the inverse transform, the CRT, the accumulator update -- the
-    // part of a step in which four waves wait for each other three times).  Whichever workgroup is further along wins, gets
-    // through its barriers at full pace, drops to 0 for its next step and becomes the filler of the other's bubbles: they
-    // leapfrog step by step.  Measured, variants interleaved on one box (profiles/r05_ab_kernel_variants.txt): 4,096
-    // rotations 36.97 -> 35.41 ms (-4.2 %), 512 rotations 5.37 -> 5.22 ms, P80 23.59 -> 22.53 ms; with fewer levels, other
-    // points, or the time slices on top of it: less or nothing.  "br_fair" > 0 still selects the time slices (default 0 now).
+    // younger gets the leftover slots, then finishes alone.  A wave's priority therefore follows its progress through the
+    // step: 0 in the first gadget row, 1 in the second, 2 from the third, 3 from the first barrier to the last (the inverse
+    // transform, the CRT, the accumulator update -- the part of a step in which four waves wait for each other three
+    // times).  Whichever workgroup is further along wins, gets through its barriers at full pace, drops to 0 for its next
+    // step and becomes the filler of the other's bubbles: they leapfrog step by step.  Measured, variants interleaved on one
+    // box (profiles/r05_ab_kernel_variants.txt): 4,096 rotations 36.97 -> 35.41 ms (-4.2 %) against the time slices of
+    // rounds 1-4 (removed in round 6).
     for (int i = 0; i < n; ++i) {
-        if (p.fair_shift > 0) {
-            // time slices of 2^fair_shift shader cycles: the workgroups of a CU read the same clock,
-            // so exactly one of them holds the higher priority at any moment
-            const uint32_t slice = (uint32_t)(__builtin_amdgcn_s_memtime() >> p.fair_shift);
-            if (slice % (uint32_t)TR::WAVES_PER_SIMD == (uint32_t)parity) __builtin_amdgcn_s_setprio(1);
-            else __builtin_amdgcn_s_setprio(0);
-        }
         const int abar = __builtin_amdgcn_readfirstlane((int)sh.bar[i]);
         if (abar == 0) continue;
         STAMP(0);
 
-        // acc0 accumulates output poly u (kept), acc1 output poly 1-u (sent to wave (q,1-u))
-        using Acc0T = typename std::conditional<TR::WIDE_KEEP, int64_t, int32_t>::type;
-        using Acc1T = typename std::conditional<TR::WIDE_SEND, int64_t, int32_t>::type;
-        Acc0T acc0[REGS];
-        Acc1T acc1[REGS];
-        forward_poly<LOGN, true, TR::KEEP_D, TR::EARLY_TW, TAB, Acc0T, Acc1T, TR::LDS_TWIDDLES, true>(p, key, c, sh.acc, scr, lane, q, i, u,
-                                                                                                     abar, u != 0, acc0, acc1, t0);
+        // acc0 accumulates output poly u (kept), acc1 output poly 1-u (sent to wave (q,1-u)); both in 64 bits, reduced once
+        int64_t acc0[REGS], acc1[REGS];
+        forward_poly<LOGN, true, TAB, true, true>(p, key, c, sh.acc, scr, lane, q, i, u, abar, u != 0, acc0, acc1, t0);
         STAMP(1);
 
         int32_t t[REGS];
@@ -614,10 +522,8 @@ __device__ __forceinline__ void blind_rotate4_body(const DevParams &p, const Dev
             int32_t send[REGS];
 #pragma unroll
             for (int r = 0; r < REGS; ++r) {
-                if constexpr (TR::WIDE_KEEP) t[r] = mont_redc((int64_t)acc0[r], c.P, c.pinv);   // l rows: |.| < 1.2P
-                else t[r] = (int32_t)acc0[r];
-                if constexpr (TR::WIDE_SEND) send[r] = mont_redc((int64_t)acc1[r], c.P, c.pinv);
-                else send[r] = (int32_t)acc1[r];                       // l rows reduced one by one: |.| < 2.2P
+                t[r] = mont_redc(acc0[r], c.P, c.pinv);                 // l rows: |.| < 1.2P
+                send[r] = mont_redc(acc1[r], c.P, c.pinv);
             }
             NTT::write_row(send, sh.x1(wv), lane);
         }
@@ -634,16 +540,11 @@ __device__ __forceinline__ void blind_rotate4_body(const DevParams &p, const Dev
 #pragma unroll
             for (int r = 0; r < REGS; ++r) t[r] += other[r];       // |.| < 3.4P (the inverse takes < 4P)
         }
-        if constexpr (TR::MERGED_BUFFERS) lds_barrier();          // partner has read my sums: the buffer is scratch again
-        // (the last pass's lane-uniform twiddles loaded once per kernel instead of per step, like the forward ones:
-        // measured, no gain -- 37.30 against 37.37 ms on one box, profiles/r04_ab_kernel_variants.txt -- and 25 scalar registers)
-        NTT::template inverse<TR::EARLY_TW>(t, c, scr, lane, t2);  // signed residues, |t| < P: recombined as they are
+        NTT::inverse(t, c, scr, lane, t2);                         // signed residues, |t| < P: recombined as they are
         STAMP(4);
 
         // CRT of output poly u is split with wave (1-q,u): wave q recombines registers [q*HALF, (q+1)*HALF)
-        // (the barrier in front of it orders only that pair; a pairwise hand-off through an LDS step counter instead of the
-        // 4-wave s_barrier was built and measured in round 5: 38.11 against 38.14 ms per 4,096 rotations -- nothing;
-        // profiles/r05_ab_kernel_variants.txt)
+        // (the barrier in front of it orders only that pair)
         const uint32_t *ox = sh.x2(wv ^ 1);
         uint32_t *mx = sh.x2(wv);
         if (q == 0) {                                    // (two copies: register indices must be compile-time constants)
@@ -670,33 +571,13 @@ __device__ __forceinline__ void blind_rotate4_body(const DevParams &p, const Dev
     STAMP_FLUSH;
 }
 
-template <int LOGN, int V, bool TAB>
-__global__ __launch_bounds__(256, (BrTraits<LOGN, V>::WAVES_PER_SIMD)) void blind_rotate4_kernel(
+template <int LOGN, bool TAB>
+__global__ __launch_bounds__(256, 2) void blind_rotate4_kernel(
     DevParams p, DevKey key, const int32_t *__restrict__ pool, const RotDesc *__restrict__ rots,
     int32_t *__restrict__ u_buf, int32_t *__restrict__ acc_dbg) {
-    __shared__ __align__(16) Br4Lds<LOGN, V> sh;
-    constexpr int PER_CU = BrTraits<LOGN, V>::WAVES_PER_SIMD;     // workgroups (of 4 waves) that share a CU
-    // urgent lane: these waves win issue arbitration against a co-resident workgroup of the
-    // other lane, so a critical-chain gate runs at nearly its stand-alone latency
-    if (p.wave_prio) __builtin_amdgcn_s_setprio(3);
-    // Workgroups share a CU, and the hardware issues oldest-wave-first: launched together,
-    // one runs at its stand-alone speed (4.1 ms) and the other gets the leftover issue slots,
-    // then finishes alone with one wave per SIMD (6.45 ms in all; tools/wg_times.py).  Letting
-    // them take turns at the higher issue priority keeps all of them running to the end.
-    int parity = 0;
-    if (p.fair_shift > 0) {
-        __shared__ int s_parity;
-        if (threadIdx.x == 0) {
-            const uint32_t hw = __builtin_amdgcn_s_getreg((31 << 11) | (0 << 6) | 4);    // HW_ID
-            const uint32_t xcc = __builtin_amdgcn_s_getreg((3 << 11) | (0 << 6) | 20);   // XCC_ID
-            const uint32_t cu = ((xcc & 0xFu) << 8) | ((hw >> 8) & 0xFFu);              // cu, sh, se
-            s_parity = (int)(atomicAdd(&p.cu_arrivals[cu], 1u) % (uint32_t)PER_CU);
-        }
-        __syncthreads();
-        parity = __builtin_amdgcn_readfirstlane(s_parity);
-    }
+    __shared__ __align__(16) Br4Lds<LOGN> sh;
     if (p.wg_times && threadIdx.x == 0) {
-        // low 48 bits: shader clock; high 16 bits: XCC id and the CU / SH / SE fields of HW_ID
+        // diagnostic (tools/wg_times.py): low 48 bits: shader clock; high 16 bits: XCC id and the CU / SH / SE fields of HW_ID
         const uint64_t hw = __builtin_amdgcn_s_getreg((31 << 11) | (0 << 6) | 4);
         const uint64_t xcc = __builtin_amdgcn_s_getreg((3 << 11) | (0 << 6) | 20);
         p.wg_times[4 * blockIdx.x] = (__builtin_amdgcn_s_memtime() & 0xFFFFFFFFFFFFull) |
@@ -706,7 +587,7 @@ __global__ __launch_bounds__(256, (BrTraits<LOGN, V>::WAVES_PER_SIMD)) void blin
     ClockProbe clk;
     clk.begin(p);
     const RotDesc rd = rots[blockIdx.x];
-    blind_rotate4_body<LOGN, V, TAB>(p, key, pool, rd, sh, threadIdx.x, parity);
+    blind_rotate4_body<LOGN, TAB>(p, key, pool, rd, sh, threadIdx.x);
     extract_sample<LOGN, 256>(p, rd, sh.acc, u_buf, acc_dbg, threadIdx.x);
     clk.end(p);
     if (p.wg_times && threadIdx.x == 0) {
@@ -719,7 +600,7 @@ __global__ __launch_bounds__(256, (BrTraits<LOGN, V>::WAVES_PER_SIMD)) void blin
 // K1+K2: blind rotate, 8-wave form for launches that cannot fill the chip (at most one
 // workgroup per CU).  With four waves a CU runs one wave per SIMD, and a lone wave issues its
 // multiplier-class instructions at half the rate two waves share (v_mad_i64_i32: 10 cycles
-// against 5; profiles/r01_valu_rates.txt).  Here a second wave sits on each SIMD: for prime q and
+// against 5; profiles/archive/r01_valu_rates.txt).  Here a second wave sits on each SIMD: for prime q and
 // input polynomial u, wave A = (q,u,0) transforms and multiplies the gadget rows 0..l-2, wave
 // B = (q,u,1) the last row; all four partial sums of an output polynomial (A's and B's own, and the
 // two the waves of the other input polynomial send) go through LDS.  The inverse transform is then SPLIT
@@ -742,9 +623,6 @@ __device__ __forceinline__ uint32_t split_finish(int h, int32_t a0, int32_t a1, 
     return crt_signed_to_torus(mont_mul(a0 - a1, iw1_0, NTT_P0, NTT_PINV0), mont_mul(b0 - b1, iw1_1, NTT_P1, NTT_PINV1));
 }
 
-#ifndef BR8_INV_LAYOUT_H
-#define BR8_INV_LAYOUT_H false
-#endif
 // (round 5: wave B raising its issue priority -- in the step's tail before the half inverse, behind it, inside it, for the last
 // phase only, or for the reductions in front of the first barrier, where the phase stamps show it 700 cycles behind wave A --
 // measured slower in all eight combinations, 2.80-2.84 against 2.76 ms per rotation; profiles/r05_ab_kernel_variants.txt,
@@ -837,10 +715,10 @@ __global__ __launch_bounds__(512, 2) void blind_rotate8_kernel(
         {
             int64_t acc0[REGS], acc1[REGS];             // output poly u, output poly 1-u
             if (!role_b)
-                forward_poly<LOGN, true, true, true, TAB, int64_t, int64_t, true>(p, key, c, sh.acc, scr, lane, q, i, u, abar, u != 0,
+                forward_poly<LOGN, true, TAB, true>(p, key, c, sh.acc, scr, lane, q, i, u, abar, u != 0,
                                                                                 acc0, acc1, t0, 0, last);
             else
-                forward_poly<LOGN, true, true, true, TAB, int64_t, int64_t, true>(p, key, c, sh.acc, scr, lane, q, i, u, abar, u != 0,
+                forward_poly<LOGN, true, TAB, true>(p, key, c, sh.acc, scr, lane, q, i, u, abar, u != 0,
                                                                                 acc0, acc1, t0, last, last + 1);
             STAMP(1);
             int32_t s0[REGS], s1[REGS];
@@ -873,8 +751,8 @@ __global__ __launch_bounds__(512, 2) void blind_rotate8_kernel(
                 }
             }                                                           // |.| < 3.3P (the inverse takes < 4P)
             // (layout R for this inverse: measured, round 4 -- with layout H the compiler's schedule of this kernel came out
-            // 0.13 ms per rotation slower, 2.87 against 2.74 ms, although H saves LDS cycles here too; profiles/r04_ab_*.txt)
-            SUB::template inverse<true, BR8_INV_LAYOUT_H>(t, ch, scr, lane, t2);   // half-transform outputs, natural order, |t| < P
+            // 0.13 ms per rotation slower, 2.87 against 2.74 ms, although H saves LDS cycles here too; profiles/archive/r04_ab_*.txt)
+            SUB::template inverse<false>(t, ch, scr, lane, t2);      // half-transform outputs, natural order, |t| < P
 #pragma unroll
             for (int r = 0; r < RS; ++r) scr[r * 64 + lane] = (uint32_t)t[r];
         }
@@ -945,7 +823,7 @@ constexpr int SPLIT_TAB2_BITS = 6;
 template <int LOGN, int TM>
 struct BrSplitLds {
     using SUB = WaveNtt<LOGN - 1>;
-    AccLds<LOGN, 3> acc;
+    AccLds<LOGN> acc;
     uint32_t scr[8][SUB::SCRATCH_WORDS];           // wave-private NTT transposes; from the end of the inverse to the
                                                    // step's last barrier: its outputs (natural order), read by 3 waves
     uint32_t x1[8][SUB::ROW_WORDS];                // partial sums sent to the wave of the other input polynomial
@@ -1019,13 +897,9 @@ __global__ __launch_bounds__(512, (LOGN == 10 ? 4 : 2)) void blind_rotate_split_
             const int32_t half = (int32_t)(c.P >> 1);
             if (v > half) v -= (int32_t)c.P;
             if (v < -half) v += (int32_t)c.P;
-#if BR_TAB_PAIRS
-            // tables read by one digit sit side by side (ntt_wave.hpp BR_TAB_PAIRS): (3,7) lo1, (4,8) hi1, (5,9) lo3, (6,10) hi3
+            // tables read by one digit sit side by side (8-byte entries, as in ntt_wave.hpp): (3,7) lo1, (4,8) hi1, (5,9) lo3, (6,10) hi3
             const int pos = k < 3 ? (k << SPLIT_TAB2_BITS) + f
                                   : ((3 + 2 * ((k - 3) & 3)) << SPLIT_TAB2_BITS) + 2 * f + (k >= 7 ? 1 : 0);
-#else
-            const int pos = (k << SPLIT_TAB2_BITS) + f;
-#endif
             sh.tab[q][h][pos] = (uint32_t)v;
         }
     }
@@ -1073,7 +947,6 @@ __global__ __launch_bounds__(512, (LOGN == 10 ? 4 : 2)) void blind_rotate_split_
                     return (int32_t)*reinterpret_cast<const uint32_t *>(tab + (k << (SPLIT_TAB2_BITS + 2)) + off);
                 };
                 auto field = [&](int i) { return (D[i] >> sh2) & mask4; };
-#if BR_TAB_PAIRS
                 const uint32_t mask8 = mask4 << 1;
                 const int sh3 = shift - 3;
                 auto pair = [&](int k, uint32_t off) {       // tables (k, k + 4) of one digit: an 8-byte entry
@@ -1093,21 +966,6 @@ __global__ __launch_bounds__(512, (LOGN == 10 ? 4 : 2)) void blind_rotate_split_
                         const int32_t uu = x0 + A, vv = x0 - A;
                         x[r] = uu + S; x[r | lb] = uu - S; x[r | hb] = vv + T; x[r | hb | lb] = vv - T;
                     }
-#else
-#pragma unroll
-                for (int r = 0; r < RS; ++r)
-                    if (!(r & (hb | lb))) {
-                        const uint32_t l1 = field(r | lb), l2 = field(r | hb), l3 = field(r | hb | lb);
-                        const uint32_t h0 = field(RS + r), h1 = field(RS + (r | lb)), h2 = field(RS + (r | hb)),
-                                       h3 = field(RS + (r | hb | lb));
-                        const int32_t x0 = __builtin_amdgcn_sbfe((int32_t)D[r], shift, width) + entry(0, h0);
-                        const int32_t A = entry(1, l2) + entry(2, h2);
-                        const int32_t S = (entry(3, l1) + entry(4, h1)) + (entry(5, l3) + entry(6, h3));
-                        const int32_t T = (entry(7, l1) + entry(8, h1)) + (entry(9, l3) + entry(10, h3));
-                        const int32_t uu = x0 + A, vv = x0 - A;
-                        x[r] = uu + S; x[r | lb] = uu - S; x[r | hb] = vv + T; x[r | hb | lb] = vv - T;
-                    }
-#endif
             } else if constexpr (TAB) {
                 const uint32_t mask4 = ((1u << width) - 1u) << 2;
                 const int sh2 = shift - 2;
@@ -1123,8 +981,8 @@ __global__ __launch_bounds__(512, (LOGN == 10 ? 4 : 2)) void blind_rotate_split_
                     x[r] = __builtin_amdgcn_sbfe((int32_t)D[r], shift, width) + (h ? -v : v);
                 }
             }
-            if constexpr (TM == 2) SUB::template forward_rest<true, LTW>(x, c, scr, lane, t0);     // < 3.5P + 2^11 in, < 9.7P out
-            else SUB::template forward<true, LTW>(x, c, scr, lane, t0);    // |x| < P + 2^11 in, < 8.3P out
+            if constexpr (TM == 2) SUB::template forward_rest<LTW>(x, c, scr, lane, t0);     // < 3.5P + 2^11 in, < 9.7P out
+            else SUB::template forward<LTW>(x, c, scr, lane, t0);    // |x| < P + 2^11 in, < 8.3P out
 #pragma unroll
             for (int g = 0; g < G4; ++g) {
                 const int32_t bb0[4] = {(int32_t)b0[g].x, (int32_t)b0[g].y, (int32_t)b0[g].z, (int32_t)b0[g].w};
@@ -1170,7 +1028,7 @@ __global__ __launch_bounds__(512, (LOGN == 10 ? 4 : 2)) void blind_rotate_split_
 #pragma unroll
             for (int r = 0; r < RS; ++r) t[r] += other[r];          // |.| < 3.6P (the inverse takes < 4P)
         }
-        SUB::template inverse<true>(t, c, scr, lane, t2);
+        SUB::inverse(t, c, scr, lane, t2);
 #pragma unroll
         for (int r = 0; r < RS; ++r) scr[r * 64 + lane] = (uint32_t)t[r];
         lds_barrier();
@@ -1295,25 +1153,9 @@ __global__ __launch_bounds__(KS_MAX_THREADS) void keyswitch_kernel(DevParams p, 
         if (wi == p.n && split == 0) o[e] += su[i1 - i0];
         if (wi > p.n) o[e] = 0;
     }
-    if (splits > 1 && !partial) {                     // accumulate in place (the slot was zeroed by ks_zero_kernel)
-        uint32_t *dst = reinterpret_cast<uint32_t *>(pool + (size_t)d.dst_slot * p.ct_stride) + 4 * tid;
-#pragma unroll
-        for (int e = 0; e < 4; ++e)
-            if (4 * tid + e <= p.n) __hip_atomic_fetch_add(dst + e, o[e], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        return;
-    }
     int32_t *dst = splits == 1 ? pool + (size_t)d.dst_slot * p.ct_stride
                                : partial + ((size_t)blockIdx.x * splits + split) * p.ct_stride;
     reinterpret_cast<uint4 *>(dst)[tid] = make_uint4(o[0], o[1], o[2], o[3]);
-}
-
-// in-place accumulation (tuning "ks_atomic"): the destination slots start at zero and every coefficient range
-// adds its partial sum with 32-bit atomic adds -- integer adds commute, so the words are the same whatever the order
-__global__ __launch_bounds__(KS_MAX_THREADS) void ks_zero_kernel(DevParams p, const KsDesc *__restrict__ descs,
-                                                             int32_t *__restrict__ pool) {
-    const int tid = threadIdx.x;
-    if (tid >= (p.ct_stride >> 2)) return;
-    reinterpret_cast<uint4 *>(pool + (size_t)descs[blockIdx.x].dst_slot * p.ct_stride)[tid] = make_uint4(0, 0, 0, 0);
 }
 
 __global__ __launch_bounds__(KS_MAX_THREADS) void ks_reduce_kernel(DevParams p, const KsDesc *__restrict__ descs, int splits,
@@ -1330,42 +1172,33 @@ __global__ __launch_bounds__(KS_MAX_THREADS) void ks_reduce_kernel(DevParams p, 
     reinterpret_cast<uint4 *>(pool + (size_t)descs[blockIdx.x].dst_slot * p.ct_stride)[tid] = acc;
 }
 
-// Tiled form for wide launches.  grid (ceil(gates / G), splits), THREADS = ct_stride/4 rounded
+// Tiled forms for wide launches.  grid (ceil(gates / G), splits), THREADS = ct_stride/4 rounded
 // up to a wave.  A workgroup key-switches G gates over one range of input coefficients:
-// it streams the range's KSK rows ONCE (12 rows = four digit positions of one coefficient
-// per stage, prefetched a stage ahead) and applies each row to every gate of the tile
+// it streams the range's KSK rows ONCE and applies each row to every gate of the tile
 // whose digit selects it.  The per-gate form above fetches 15.5 MB of rows per gate (from
-// L2, which is what bounds it); here the fetch is shared by G gates.  A thread only ever
-// needs its own 16-byte column of a row, so the staged rows sit in a thread-private LDS
-// strip (LDS because the row is picked by a run-time digit) and the stage loop has no
-// barrier.  Strips are laid out [digit position][digit 0..3]; digit 0 is a strip of zeros,
-// so the inner loop is branch-free (address = digit bits, one 16-byte LDS read, four
-// subtractions) and the reads of a stage can be in flight together.  Digits come from one
-// LDS word per (gate, coefficient), the same for all lanes.  Needs ks_t = 8,
+// L2, which is what bounds it); here the fetch is shared by G gates.  Both need ks_t = 8,
 // ks_basebit = 2 (every built-in parameter set) and at most 64 coefficients per range;
 // partial sums go through ks_reduce_kernel as above.
-// W: words of the row a thread owns.  W = 4 (the default): one 16-byte column per thread, 3 waves per workgroup at n = 630,
-// ~190 VGPRs -> two waves per SIMD.  W = 2 (round 4, tuning "ks_narrow"): 5 waves per workgroup, 98 VGPRs -> four waves
-// per SIMD, the same LDS bytes and subtractions spread over more resident waves -- measured SLOWER, 126 against 111 ms per
-// match (tile 32 with it: 147 ms; profiles/r04_ks_tile.txt): the loop is bound by LDS instruction issue, and W = 2 issues
-// twice the reads for the same bytes.  Kept selectable and tested.  Also tried in round 4 and dropped: the rows in REGISTER
-// banks picked by the wave-uniform digit through the VGPR index mode (s_set_gpr_idx_on) -- no LDS access at all on paper;
-// the compiler either moves a dynamically indexed array to scratch memory or, for a 16-word vector value, re-assembles the
-// register tuple with 16 moves in front of every indexed read.  Not reachable from HIP source.
-template <int W> struct KsVec;
-template <> struct KsVec<4> { typedef uint32_t type __attribute__((ext_vector_type(4))); };
-template <> struct KsVec<2> { typedef uint32_t type __attribute__((ext_vector_type(2))); };
+//
+// LDS-strip form (tuning "ks_index" 0; G = 16).  A thread only ever needs its own 16-byte column of a row,
+// so the staged rows (12 rows = four digit positions of one coefficient per stage, prefetched a stage
+// ahead) sit in a thread-private LDS strip -- LDS because the row is picked by a run-time digit -- and the stage
+// loop has no barrier.  Strips are laid out [digit position][digit 0..3]; digit 0 is a strip of zeros,
+// so the inner loop is branch-free (address = digit bits, one 16-byte LDS read, four subtractions).
+// Digits come from one LDS word per (gate, coefficient), the same for all lanes.  The strip reads of the
+// next pair of gates are issued BEFORE the subtractions of the current pair, and the wait is for "all but
+// the last eight reads" (a wave's LDS operations complete in order, so s_waitcnt lgkmcnt(8) means the older
+// eight have arrived).  Plain HIP source apart from the explicit ds_read / s_waitcnt: what runs if the pinned
+// registers of the index form below ever stop compiling.  Bound by LDS instruction issue: 105 ms of key switch
+// per match where the index form takes 56 (profiles/archive/r04_ks_tile.txt, r04_ks_register_forms.txt).
+typedef uint32_t ks_u4 __attribute__((ext_vector_type(4)));
 
-// PIPE (round 4): the strip reads of the next pair of gates are issued BEFORE the subtractions of the current pair, and the
-// wait is for "all but the last eight reads" (a wave's LDS operations complete in order, so s_waitcnt lgkmcnt(8) means the
-// older eight have arrived): the wave no longer sits at s_waitcnt lgkmcnt(0) four times per stage with nothing in flight
-// (SQ counters: 29 % of its cycles parked, profiles/r04_ks_counters.txt).  Same registers (two buffers of eight rows).
-template <int THREADS, int G, bool ATOMIC = false, int W = 4, bool PIPE = false>
-__global__ __launch_bounds__(THREADS) void keyswitch_tile_kernel(DevParams p, DevKey key, const int32_t *__restrict__ u_buf,
-                                                              const KsDesc *__restrict__ descs, int count,
-                                                              int32_t *__restrict__ partial /* ATOMIC: the slot pool */) {
-    typedef typename KsVec<W>::type vw;
-    constexpr int JB = 4, ROWS = JB * 3, MAXR = 64, EB = W * 4;      // EB: bytes of a strip entry
+template <int THREADS, int G>
+__global__ __launch_bounds__(THREADS) void keyswitch_strip_kernel(DevParams p, DevKey key, const int32_t *__restrict__ u_buf,
+                                                               const KsDesc *__restrict__ descs, int count,
+                                                               int32_t *__restrict__ partial) {
+    typedef ks_u4 vw;
+    constexpr int JB = 4, ROWS = JB * 3, MAXR = 64, EB = 16;         // EB: bytes of a strip entry
     __shared__ __align__(16) vw rows[JB * 4 * THREADS];
     __shared__ __align__(16) uint32_t su[MAXR][G];       // [coefficient][gate]: four gates' digit words per 16-byte read
     __shared__ uint32_t sbody[G];
@@ -1394,7 +1227,7 @@ __global__ __launch_bounds__(THREADS) void keyswitch_tile_kernel(DevParams p, De
 #pragma unroll
     for (int jj = 0; jj < JB; ++jj) rows[(jj * 4) * THREADS + tid] = (vw)(0u);
     __syncthreads();
-    const int nvec = p.ct_stride / W;
+    const int nvec = p.ct_stride / 4;
     if (tid >= nvec) return;                             // no barrier below
     const vw *ksk = reinterpret_cast<const vw *>(key.ksk) + tid;
     vw acc[G];
@@ -1427,64 +1260,36 @@ __global__ __launch_bounds__(THREADS) void keyswitch_tile_kernel(DevParams p, De
                 for (int jj = 0; jj < JB; ++jj) {
                     const uint32_t d = (x >> (6 - 2 * jj)) & 3u;
                     const uint32_t addr = strip_addr + d * (uint32_t)(THREADS * EB);
-                    if constexpr (W == 4)
-                        asm volatile("ds_read_b128 %0, %1 offset:%2"
-                                     : "=v"(buf[e * 4 + jj]) : "v"(addr), "n"(jj * 4 * THREADS * EB) : "memory");
-                    else
-                        asm volatile("ds_read_b64 %0, %1 offset:%2"
-                                     : "=v"(buf[e * 4 + jj]) : "v"(addr), "n"(jj * 4 * THREADS * EB) : "memory");
+                    asm volatile("ds_read_b128 %0, %1 offset:%2"
+                                 : "=v"(buf[e * 4 + jj]) : "v"(addr), "n"(jj * 4 * THREADS * EB) : "memory");
                 }
             }
         };
-        if constexpr (PIPE) {
-            // all sixteen gates' digit words first (one wait), then pairs of gates through two buffers of eight rows
-            uint32_t xg[G];
-#pragma unroll
-            for (int g = 0; g < G; g += 4) {
-                const uint4 xs = *reinterpret_cast<const uint4 *>(&su[ii][g]);
-                xg[g] = xs.x; xg[g + 1] = xs.y; xg[g + 2] = xs.z; xg[g + 3] = xs.w;
-            }
-            vw bufA[8], bufB[8];
-            issue(bufA, xg[0], xg[1]);
-#pragma unroll
-            for (int g = 0; g < G; g += 2) {
-                vw (&cur)[8] = (g & 2) ? bufB : bufA;
-                vw (&nxt)[8] = (g & 2) ? bufA : bufB;
-                if (g + 2 < G) {
-                    issue(nxt, xg[g + 2], xg[g + 3]);
-                    asm volatile("s_waitcnt lgkmcnt(8)"
-                                 : "+v"(cur[0]), "+v"(cur[1]), "+v"(cur[2]), "+v"(cur[3]), "+v"(cur[4]), "+v"(cur[5]), "+v"(cur[6]), "+v"(cur[7]));
-                } else {
-                    asm volatile("s_waitcnt lgkmcnt(0)"
-                                 : "+v"(cur[0]), "+v"(cur[1]), "+v"(cur[2]), "+v"(cur[3]), "+v"(cur[4]), "+v"(cur[5]), "+v"(cur[6]), "+v"(cur[7]));
-                }
-#pragma unroll
-                for (int e = 0; e < 2; ++e)
-#pragma unroll
-                    for (int jj = 0; jj < JB; ++jj) acc[g + e] -= cur[e * 4 + jj];
-            }
-        } else {
-        // Four gates at a time: their sixteen strip reads are issued back to back and waited for
-        // once.  (Left to the compiler the reads are sunk next to their uses, two in flight,
-        // and the loop is bound by LDS latency; hence the explicit ds_read / s_waitcnt.
-        // The compiler's own LDS waits stay correct: operations of a wave complete in order
-        // and it only ever under-counts what is outstanding.)
+        // all sixteen gates' digit words first (one wait), then pairs of gates through two buffers of eight rows
+        uint32_t xg[G];
 #pragma unroll
         for (int g = 0; g < G; g += 4) {
-            vw row[16];
             const uint4 xs = *reinterpret_cast<const uint4 *>(&su[ii][g]);
-            issue(reinterpret_cast<vw (&)[8]>(row[0]), xs.x, xs.y);
-            issue(reinterpret_cast<vw (&)[8]>(row[8]), xs.z, xs.w);
-            asm volatile("s_waitcnt lgkmcnt(0)"
-                         : "+v"(row[0]), "+v"(row[1]), "+v"(row[2]), "+v"(row[3]), "+v"(row[4]), "+v"(row[5]),
-                           "+v"(row[6]), "+v"(row[7]), "+v"(row[8]), "+v"(row[9]), "+v"(row[10]), "+v"(row[11]),
-                           "+v"(row[12]), "+v"(row[13]), "+v"(row[14]), "+v"(row[15]));
-#pragma unroll
-            for (int e = 0; e < 4; ++e) {
-#pragma unroll
-                for (int jj = 0; jj < JB; ++jj) acc[g + e] -= row[e * 4 + jj];
-            }
+            xg[g] = xs.x; xg[g + 1] = xs.y; xg[g + 2] = xs.z; xg[g + 3] = xs.w;
         }
+        vw bufA[8], bufB[8];
+        issue(bufA, xg[0], xg[1]);
+#pragma unroll
+        for (int g = 0; g < G; g += 2) {
+            vw (&cur)[8] = (g & 2) ? bufB : bufA;
+            vw (&nxt)[8] = (g & 2) ? bufA : bufB;
+            if (g + 2 < G) {
+                issue(nxt, xg[g + 2], xg[g + 3]);
+                asm volatile("s_waitcnt lgkmcnt(8)"
+                             : "+v"(cur[0]), "+v"(cur[1]), "+v"(cur[2]), "+v"(cur[3]), "+v"(cur[4]), "+v"(cur[5]), "+v"(cur[6]), "+v"(cur[7]));
+            } else {
+                asm volatile("s_waitcnt lgkmcnt(0)"
+                             : "+v"(cur[0]), "+v"(cur[1]), "+v"(cur[2]), "+v"(cur[3]), "+v"(cur[4]), "+v"(cur[5]), "+v"(cur[6]), "+v"(cur[7]));
+            }
+#pragma unroll
+            for (int e = 0; e < 2; ++e)
+#pragma unroll
+                for (int jj = 0; jj < JB; ++jj) acc[g + e] -= cur[e * 4 + jj];
         }
 #define KS_STORE(r) rows[((r) / 3 * 4 + (r) % 3 + 1) * THREADS + tid] = pre##r;
         KS_ROWS(KS_STORE)
@@ -1494,154 +1299,24 @@ __global__ __launch_bounds__(THREADS) void keyswitch_tile_kernel(DevParams p, De
 #pragma unroll
     for (int g = 0; g < G; ++g) {
         if (g0 + g >= count) break;
-        uint32_t o[W];
-#pragma unroll
-        for (int e = 0; e < W; ++e) {
-            o[e] = acc[g][e];
-            const int wi = W * tid + e;
-            if (wi == p.n && split == 0) o[e] += sbody[g];
-            if (wi > p.n) o[e] = 0;
-        }
-        if constexpr (ATOMIC) {
-            uint32_t *dst = reinterpret_cast<uint32_t *>(partial + (size_t)descs[g0 + g].dst_slot * p.ct_stride) + W * tid;
-#pragma unroll
-            for (int e = 0; e < W; ++e)
-                if (W * tid + e <= p.n) __hip_atomic_fetch_add(dst + e, o[e], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        } else {
-            vw out;
-#pragma unroll
-            for (int e = 0; e < W; ++e) out[e] = o[e];
-            reinterpret_cast<vw *>(partial + ((size_t)(g0 + g) * splits + split) * p.ct_stride)[tid] = out;
-        }
-    }
-}
-
-// Register form of the tiled key switch (round 4, tuning "ks_branch").  The tiled kernel above keeps the staged rows in
-// LDS because the row a gate subtracts is picked by a run-time digit -- and pays one 16-byte LDS read per four
-// subtractions, which is what bounds it (the LDS array moves 128 bytes per cycle and CU; profiles/r04_ks_tile.txt).  But
-// the digit is the same for every lane of a wave: it can live in a SCALAR register and pick the row by a scalar branch.
-// Here a thread holds its 16-byte column of the three non-zero rows of one digit position in registers (loaded straight
-// from global memory, a position ahead), every gate's digit is a scalar bit-field extract of the gate's coefficient word
-// (one v_readfirstlane per gate and coefficient), and a three-way scalar branch runs the four subtractions against the
-// picked row -- or nothing for digit 0, a quarter of all digits, which the LDS form subtracts as a strip of zeros.  No
-// LDS access in the loop except the 16-byte reads of the digit words.  The subtractions are asm volatile so that the
-// compiler cannot turn the branches into per-lane selects (3 v_cndmask per word would cost more than the LDS read).
-// Same grid, same partial sums and reduce launch as the tiled kernel; needs ks_t = 8, ks_basebit = 2.
-// One (gate, digit position): the two bits of the digit are tested in the gate's scalar coefficient word (s_bitcmp1_b32,
-// bit numbers as immediates) and the branch tree runs the four subtractions against the picked row, or none.  Everything
-// -- tests, branches, subtractions -- is ONE asm block: left to the compiler, the same tree comes out with a copy of the
-// accumulator in front of every arm (the arms define new values that it merges through moves: 1,682 v_mov_b32 in a first build).
-template <int SH>
-__device__ __forceinline__ void ks_branch_sub(uint4 &a, uint32_t x, const uint4 &r1, const uint4 &r2, const uint4 &r3) {
-    asm volatile(
-        "s_bitcmp1_b32 %[x], %[hi]\n\t"
-        "s_cbranch_scc1 .Lks_hi_%=\n\t"
-        "s_bitcmp1_b32 %[x], %[lo]\n\t"
-        "s_cbranch_scc0 .Lks_end_%=\n\t"
-        "v_sub_u32 %[a0], %[a0], %[p0]\n\tv_sub_u32 %[a1], %[a1], %[p1]\n\tv_sub_u32 %[a2], %[a2], %[p2]\n\tv_sub_u32 %[a3], %[a3], %[p3]\n\t"
-        "s_branch .Lks_end_%=\n"
-        ".Lks_hi_%=:\n\t"
-        "s_bitcmp1_b32 %[x], %[lo]\n\t"
-        "s_cbranch_scc1 .Lks_three_%=\n\t"
-        "v_sub_u32 %[a0], %[a0], %[q0]\n\tv_sub_u32 %[a1], %[a1], %[q1]\n\tv_sub_u32 %[a2], %[a2], %[q2]\n\tv_sub_u32 %[a3], %[a3], %[q3]\n\t"
-        "s_branch .Lks_end_%=\n"
-        ".Lks_three_%=:\n\t"
-        "v_sub_u32 %[a0], %[a0], %[t0]\n\tv_sub_u32 %[a1], %[a1], %[t1]\n\tv_sub_u32 %[a2], %[a2], %[t2]\n\tv_sub_u32 %[a3], %[a3], %[t3]\n"
-        ".Lks_end_%=:"
-        : [a0] "+v"(a.x), [a1] "+v"(a.y), [a2] "+v"(a.z), [a3] "+v"(a.w)
-        : [x] "s"(x), [hi] "n"(SH + 1), [lo] "n"(SH),
-          [p0] "v"(r1.x), [p1] "v"(r1.y), [p2] "v"(r1.z), [p3] "v"(r1.w),
-          [q0] "v"(r2.x), [q1] "v"(r2.y), [q2] "v"(r2.z), [q3] "v"(r2.w),
-          [t0] "v"(r3.x), [t1] "v"(r3.y), [t2] "v"(r3.z), [t3] "v"(r3.w)
-        : "scc");
-}
-template <int SH, int G>
-__device__ __forceinline__ void ks_branch_apply(uint4 (&acc)[G], const uint32_t (&x)[G], const uint4 &r1, const uint4 &r2,
-                                                const uint4 &r3) {
-#pragma unroll
-    for (int g = 0; g < G; ++g) ks_branch_sub<SH>(acc[g], x[g], r1, r2, r3);
-}
-template <int THREADS, int G>
-__global__ __launch_bounds__(THREADS) void keyswitch_branch_kernel(DevParams p, DevKey key, const int32_t *__restrict__ u_buf,
-                                                                const KsDesc *__restrict__ descs, int count,
-                                                                int32_t *__restrict__ partial) {
-    constexpr int MAXR = 64;
-    __shared__ __align__(16) uint32_t su[MAXR][G];       // [coefficient][gate]
-    __shared__ uint32_t sbody[G];
-    const int tid = threadIdx.x;
-    const int nin = p.k * p.N;
-    const int splits = gridDim.y, split = blockIdx.y;
-    const int i0 = (int)((long long)nin * split / splits), i1 = (int)((long long)nin * (split + 1) / splits);
-    const int range = i1 - i0;
-    const int g0 = blockIdx.x * G;
-    for (int e = tid; e < G * range; e += THREADS) {
-        const int g = e / range, ii = e - g * range;
-        uint32_t v = 0;                                  // gates past the end: every digit 0
-        if (g0 + g < count) {
-            const KsDesc d = descs[g0 + g];
-            v = (uint32_t)u_buf[(size_t)d.u0 * p.u_stride + i0 + ii] + p.ks_prec_offset;
-            if (d.u1 >= 0) v += (uint32_t)u_buf[(size_t)d.u1 * p.u_stride + i0 + ii];
-        }
-        su[ii][g] = v;
-    }
-    if (tid < G && g0 + tid < count) {
-        const KsDesc d = descs[g0 + tid];
-        uint32_t b = (uint32_t)u_buf[(size_t)d.u0 * p.u_stride + nin] + (uint32_t)d.add_b;
-        if (d.u1 >= 0) b += (uint32_t)u_buf[(size_t)d.u1 * p.u_stride + nin];
-        sbody[tid] = b;
-    }
-    __syncthreads();
-    const int nvec = p.ct_stride >> 2;
-    if (tid >= nvec) return;                             // no barrier below
-    const uint4 *src = reinterpret_cast<const uint4 *>(key.ksk) + tid + (size_t)(i0 * 8) * 3 * nvec;
-    const size_t step = (size_t)3 * nvec;
-    uint4 acc[G];
-#pragma unroll
-    for (int g = 0; g < G; ++g) acc[g] = make_uint4(0, 0, 0, 0);
-    // digit j of a coefficient word sits at bits [31-2j, 30-2j]
-    uint4 a1 = src[0], a2 = src[nvec], a3 = src[2 * nvec];
-    for (int ii = 0; ii < range; ++ii) {
-        uint32_t x[G];
-#pragma unroll
-        for (int g = 0; g < G; g += 4) {
-            const uint4 xs = *reinterpret_cast<const uint4 *>(&su[ii][g]);
-            x[g] = __builtin_amdgcn_readfirstlane(xs.x); x[g + 1] = __builtin_amdgcn_readfirstlane(xs.y);
-            x[g + 2] = __builtin_amdgcn_readfirstlane(xs.z); x[g + 3] = __builtin_amdgcn_readfirstlane(xs.w);
-        }
-        const bool last_coeff = ii + 1 == range;
-        // the rows of the next digit position are requested before this position's subtractions (two register sets in
-        // turn, no copies); the very last request of the range re-reads its own rows instead of running past the table
-#define KS_PAIR(JP, LAST)                                                                             \
-        {                                                                                             \
-            src += step;                                                                              \
-            const uint4 b1 = src[0], b2 = src[nvec], b3 = src[2 * nvec];                              \
-            ks_branch_apply<30 - 4 * (JP), G>(acc, x, a1, a2, a3);                                    \
-            if (!(LAST)) src += step;                                                                 \
-            a1 = src[0]; a2 = src[nvec]; a3 = src[2 * nvec];                                          \
-            ks_branch_apply<28 - 4 * (JP), G>(acc, x, b1, b2, b3);                                    \
-        }
-        KS_PAIR(0, false) KS_PAIR(1, false) KS_PAIR(2, false) KS_PAIR(3, last_coeff)
-#undef KS_PAIR
-    }
-#pragma unroll
-    for (int g = 0; g < G; ++g) {
-        if (g0 + g >= count) break;
-        uint32_t o[4] = {acc[g].x, acc[g].y, acc[g].z, acc[g].w};
+        vw out = acc[g];
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
             const int wi = 4 * tid + e;
-            if (wi == p.n && split == 0) o[e] += sbody[g];
-            if (wi > p.n) o[e] = 0;
+            if (wi == p.n && split == 0) out[e] += sbody[g];
+            if (wi > p.n) out[e] = 0;
         }
-        reinterpret_cast<uint4 *>(partial + ((size_t)(g0 + g) * splits + split) * p.ct_stride)[tid] = make_uint4(o[0], o[1], o[2], o[3]);
+        reinterpret_cast<vw *>(partial + ((size_t)(g0 + g) * splits + split) * p.ct_stride)[tid] = out;
     }
 }
 
-// Index form of the register key switch (round 4, tuning "ks_branch" 2).  The branch form above is bound by the latency of
-// its taken branches (about 130 cycles per wave, gate and digit whatever the occupancy: tile 32 at two waves per SIMD takes
-// exactly twice as long as tile 16 at four).  gfx9's VGPR index mode removes the branches: with SRC1_REL set, the row
-// operand of a v_sub_u32 is VGPR[encoded + M0[7:0]], so ONE instruction sequence subtracts whichever row the scalar index
-// picks.  The compiler cannot express that (section 5 of DESIGN.md: a dynamically indexed
+// Index form (round 4; the default, tuning "ks_index" 1).  The strip form pays one 16-byte LDS read per four subtractions,
+// which is what bounds it.  But the digit is the same for every lane of a wave: it can live in a SCALAR register and pick
+// the row.  A thread holds its 16-byte column of the three non-zero rows of a digit position in registers (loaded
+// straight from global memory, a position ahead).  Picking by scalar branches was built first and is bound by the latency
+// of its taken branches (about 130 cycles per wave, gate and digit whatever the occupancy; removed in round 6).  gfx9's
+// VGPR index mode removes the branches: with SRC1_REL set, the row operand of a v_sub_u32 is VGPR[encoded + M0[7:0]], so
+// ONE instruction sequence subtracts whichever row the scalar index picks.  The compiler cannot express that (section 5 of DESIGN.md: a dynamically indexed
 // register array goes to scratch memory), and inline asm cannot name a sub-register of a tuple operand -- but an asm operand
 // can be PINNED to physical registers ("{v[96:99]}"), and then the asm text may name them.  Register map (pinned only at
 // the asm statements; the compiler keeps the values there in between because every statement of the loop wants them there):
@@ -1653,10 +1328,6 @@ __global__ __launch_bounds__(THREADS) void keyswitch_branch_kernel(DevParams p, 
 // a scalar branch over the gate for digit 0 (a quarter of all digits; s_bfe_u32 leaves SCC = result != 0, and a branch
 // that is mostly not taken costs the wave little), s_set_gpr_idx_idx and four v_sub_u32 whose row operand is encoded as
 // the register four below row 1.  M0 is saved and restored around each statement (the compiler treats it as reserved).
-#ifndef KS_IDX_EXPERIMENT
-#define KS_IDX_EXPERIMENT 0
-#endif
-typedef uint32_t ks_u4 __attribute__((ext_vector_type(4)));
 #include "ks_index_asm.inc"      // KsIndexSub<G, OCT, SETB>::run<NIB>: the asm statements (tools/gen_ks_index_asm.py)
 
 // the coefficient word of a gate (digit j at bits [31-2j, 30-2j]) as eight index nibbles (comment above)
@@ -1730,26 +1401,6 @@ __global__ __launch_bounds__(THREADS) void keyswitch_index_kernel(DevParams p, D
         KS_IDX_OCT(0, SET, NIB, R1, R2, R3) KS_IDX_OCT(1, SET, NIB, R1, R2, R3)                                                 \
         if constexpr (G >= 24) { KS_IDX_OCT(2, SET, NIB, R1, R2, R3) }                                                          \
         if constexpr (G == 32) { KS_IDX_OCT(3, SET, NIB, R1, R2, R3) }
-        // KS_IDX_EXPERIMENT (timing only, wrong results; tools/diag/r4_ksx.sh): 1 = no row loads inside the loop, 2 = the loads
-        // without the subtractions
-#if KS_IDX_EXPERIMENT == 1
-#define KS_IDX_PAIR(JP, LAST)                                                                         \
-        {                                                                                             \
-            KS_IDX_APPLY(0, 2 * (JP), a1, a2, a3)                                                     \
-            KS_IDX_APPLY(1, 2 * (JP) + 1, a1, a2, a3)                                                 \
-        }
-#elif KS_IDX_EXPERIMENT == 2
-#define KS_IDX_KEEP(R) asm volatile("" ::"v"(R));
-#define KS_IDX_PAIR(JP, LAST)                                                                         \
-        {                                                                                             \
-            src += step;                                                                              \
-            const ks_u4 b1 = src[0], b2 = src[nvec], b3 = src[2 * nvec];                              \
-            KS_IDX_KEEP(a1) KS_IDX_KEEP(a2) KS_IDX_KEEP(a3)                                           \
-            if (!(LAST)) src += step;                                                                 \
-            a1 = src[0]; a2 = src[nvec]; a3 = src[2 * nvec];                                          \
-            KS_IDX_KEEP(b1) KS_IDX_KEEP(b2) KS_IDX_KEEP(b3)                                           \
-        }
-#else
 #define KS_IDX_PAIR(JP, LAST)                                                                         \
         {                                                                                             \
             src += step;                                                                              \
@@ -1759,7 +1410,6 @@ __global__ __launch_bounds__(THREADS) void keyswitch_index_kernel(DevParams p, D
             a1 = src[0]; a2 = src[nvec]; a3 = src[2 * nvec];                                          \
             KS_IDX_APPLY(1, 2 * (JP) + 1, b1, b2, b3)                                                 \
         }
-#endif
         KS_IDX_PAIR(0, false) KS_IDX_PAIR(1, false) KS_IDX_PAIR(2, false) KS_IDX_PAIR(3, last_coeff)
 #undef KS_IDX_PAIR
 #undef KS_IDX_APPLY
@@ -1825,14 +1475,11 @@ void launch_bk_transform(hipStream_t s, const DevParams &p, const int32_t *raw_p
                            scale[0], scale[1]);
 }
 
-void launch_blind_rotate(hipStream_t s, const DevParams &p, const DevKey &key, const int32_t *pool,
-                         const RotDesc *rots, int count, int32_t *u_buf, int32_t *acc_dbg) {
-    if (count <= 0) return;
-    // the 2-wave form exists for N = 1024 only; N = 2048 always takes the 4-wave form
-    if (p.N == 2048)
-        hipLaunchKernelGGL((blind_rotate4_kernel<11, 0, false>), dim3(count), dim3(256), 0, s, p, key, pool, rots, u_buf, acc_dbg);
-    else
-        hipLaunchKernelGGL(blind_rotate_kernel<10>, dim3(count), dim3(128), 0, s, p, key, pool, rots, u_buf, acc_dbg);
+// 2-wave form: N = 1024 only (the engine's admissibility order never picks it for another ring)
+void launch_blind_rotate2(hipStream_t s, const DevParams &p, const DevKey &key, const int32_t *pool,
+                          const RotDesc *rots, int count, int32_t *u_buf, int32_t *acc_dbg) {
+    if (count <= 0 || p.N != 1024) return;
+    hipLaunchKernelGGL(blind_rotate2_kernel<10>, dim3(count), dim3(128), 0, s, p, key, pool, rots, u_buf, acc_dbg);
 }
 
 // the LDS digit tables index by (D >> (shift - 3)) & mask (8-byte entries): digits of at most DIGIT_TAB_BITS bits whose
@@ -1843,7 +1490,7 @@ static bool digit_table_usable(const DevParams &p) {
 
 void launch_blind_rotate8(hipStream_t s, const DevParams &p, const DevKey &key, const int32_t *pool,
                           const RotDesc *rots, int count, int32_t *u_buf, int32_t *acc_dbg) {
-    if (count <= 0) return;
+    if (count <= 0 || p.N != 1024) return;
     if (digit_table_usable(p))
         hipLaunchKernelGGL((blind_rotate8_kernel<10, true>), dim3(count), dim3(512), 0, s, p, key, pool, rots, u_buf, acc_dbg);
     else
@@ -1876,88 +1523,41 @@ void read_stamps(unsigned long long *out, bool reset) {
 
 void launch_blind_rotate4(hipStream_t s, const DevParams &p, const DevKey &key, const int32_t *pool,
                           const RotDesc *rots, int count, int32_t *u_buf, int32_t *acc_dbg) {
-    if (count <= 0) return;
-#define BR4(LN, VV, TB) hipLaunchKernelGGL((blind_rotate4_kernel<LN, VV, TB>), dim3(count), dim3(256), 0, s, p, key, pool, rots, u_buf, acc_dbg)
-    const bool tab = digit_table_usable(p);
-    if (p.N == 2048) { if (tab) BR4(11, 0, true); else BR4(11, 0, false); }
-    else if (p.br_variant == 1) { if (tab) BR4(10, 1, true); else BR4(10, 1, false); }
-    else { if (tab) BR4(10, 0, true); else BR4(10, 0, false); }
-#undef BR4
+    if (count <= 0 || p.N != 1024) return;
+    if (digit_table_usable(p))
+        hipLaunchKernelGGL((blind_rotate4_kernel<10, true>), dim3(count), dim3(256), 0, s, p, key, pool, rots, u_buf, acc_dbg);
+    else
+        hipLaunchKernelGGL((blind_rotate4_kernel<10, false>), dim3(count), dim3(256), 0, s, p, key, pool, rots, u_buf, acc_dbg);
 }
 
-
+// tile = 0 or splits <= 1: one workgroup per (gate, range) [keyswitch_kernel].  tile = 16 / 24 / 32 with the key switch of
+// the built-in sets (t = 8, base 4) and ranges of at most 64 coefficients: the tiled kernels -- the index form, or the
+// LDS-strip form (tile 16) when `index` is false.  Every form with splits > 1 leaves partial sums for ks_reduce_kernel.
 void launch_keyswitch(hipStream_t s, const DevParams &p, const DevKey &key, const int32_t *u_buf,
-                      const KsDesc *descs, int count, int32_t *pool, int splits, int32_t *partial, int tile, bool atomic,
-                      bool narrow, bool pipe, int branch) {
+                      const KsDesc *descs, int count, int32_t *pool, int splits, int32_t *partial, int tile, bool index) {
     if (count <= 0) return;
-    const int threads = ((p.ct_stride / 4 + 63) / 64) * 64;      // one 16-byte lane per 4 output words
-    if (splits <= 1 || (!partial && !atomic)) {
+    const int threads = ((p.ct_stride / 4 + 63) / 64) * 64;      // one 16-byte lane per 4 output words: 128, 192 or 320
+    if (splits <= 1 || !partial) {
         hipLaunchKernelGGL(keyswitch_kernel, dim3(count, 1), dim3(threads), 0, s, p, key, u_buf, descs, pool, nullptr);
         return;
     }
-    if (atomic) hipLaunchKernelGGL(ks_zero_kernel, dim3(count), dim3(threads), 0, s, p, descs, pool);
     const int range = (p.k * p.N + splits - 1) / splits;
-    if (tile > 0 && count >= 2 * tile && p.ks_t == 8 && p.ks_basebit == 2 && range <= 64 &&
-        (tile == 16 || tile == 32 || (tile == 24 && branch == 2 && !atomic))) {
-        const dim3 grid((count + tile - 1) / tile, splits);
-        // register form: rows in registers, picked by scalar branches (tuning "ks_branch")
-        if (branch == 2 && !atomic && (threads == 128 || threads == 192 || threads == 320)) {
-#define KS_INDEX(T, GT) hipLaunchKernelGGL((keyswitch_index_kernel<T, GT>), grid, dim3(T), 0, s, p, key, u_buf, descs, count, partial)
-            if (tile == 16) { if (threads == 128) KS_INDEX(128, 16); else if (threads == 192) KS_INDEX(192, 16); else KS_INDEX(320, 16); }
-            else if (tile == 24) { if (threads == 128) KS_INDEX(128, 24); else if (threads == 192) KS_INDEX(192, 24); else KS_INDEX(320, 24); }
-            else { if (threads == 128) KS_INDEX(128, 32); else if (threads == 192) KS_INDEX(192, 32); else KS_INDEX(320, 32); }
-#undef KS_INDEX
-            hipLaunchKernelGGL(ks_reduce_kernel, dim3(count), dim3(threads), 0, s, p, descs, splits, partial, pool);
-            return;
-        }
-        if (branch && !atomic && (threads == 128 || threads == 192 || threads == 320)) {
-#define KS_BRANCH(T, GT) hipLaunchKernelGGL((keyswitch_branch_kernel<T, GT>), grid, dim3(T), 0, s, p, key, u_buf, descs, count, partial)
-            if (tile == 16) { if (threads == 128) KS_BRANCH(128, 16); else if (threads == 192) KS_BRANCH(192, 16); else KS_BRANCH(320, 16); }
-            else { if (threads == 128) KS_BRANCH(128, 32); else if (threads == 192) KS_BRANCH(192, 32); else KS_BRANCH(320, 32); }
-#undef KS_BRANCH
-            hipLaunchKernelGGL(ks_reduce_kernel, dim3(count), dim3(threads), 0, s, p, descs, splits, partial, pool);
-            return;
-        }
-        // W = 2 form: a thread per 2 words of the row (tuning "ks_narrow")
-        const int threads2 = ((p.ct_stride / 2 + 63) / 64) * 64;
-        if (narrow && (threads2 == 256 || threads2 == 320 || threads2 == 576)) {
-#define KS_NARROW(T, GT)                                                                                                    \
+    const bool tiled = (tile == 16 || ((tile == 24 || tile == 32) && index)) && count >= 2 * tile && p.ks_t == 8 &&
+                       p.ks_basebit == 2 && range <= 64 && (threads == 128 || threads == 192 || threads == 320);
+    const dim3 grid((count + (tiled ? tile : 1) - 1) / (tiled ? tile : 1), splits);
+#define KS_FORM(K, GT)                                                                                                      \
     do {                                                                                                                    \
-        if (atomic) hipLaunchKernelGGL((keyswitch_tile_kernel<T, GT, true, 2>), grid, dim3(T), 0, s, p, key, u_buf, descs, count, pool); \
-        else hipLaunchKernelGGL((keyswitch_tile_kernel<T, GT, false, 2>), grid, dim3(T), 0, s, p, key, u_buf, descs, count, partial);    \
+        if (threads == 128) hipLaunchKernelGGL((K<128, GT>), grid, dim3(128), 0, s, p, key, u_buf, descs, count, partial);  \
+        else if (threads == 192) hipLaunchKernelGGL((K<192, GT>), grid, dim3(192), 0, s, p, key, u_buf, descs, count, partial); \
+        else hipLaunchKernelGGL((K<320, GT>), grid, dim3(320), 0, s, p, key, u_buf, descs, count, partial);                 \
     } while (0)
-            if (tile == 16) { if (threads2 == 256) KS_NARROW(256, 16); else if (threads2 == 320) KS_NARROW(320, 16); else KS_NARROW(576, 16); }
-            else { if (threads2 == 256) KS_NARROW(256, 32); else if (threads2 == 320) KS_NARROW(320, 32); else KS_NARROW(576, 32); }
-#undef KS_NARROW
-            if (!atomic) hipLaunchKernelGGL(ks_reduce_kernel, dim3(count), dim3(threads), 0, s, p, descs, splits, partial, pool);
-            return;
-        }
-#define KS_TILE(T, GT)                                                                                                      \
-    do {                                                                                                                    \
-        if (atomic) hipLaunchKernelGGL((keyswitch_tile_kernel<T, GT, true>), grid, dim3(T), 0, s, p, key, u_buf, descs, count, pool); \
-        else hipLaunchKernelGGL((keyswitch_tile_kernel<T, GT, false>), grid, dim3(T), 0, s, p, key, u_buf, descs, count, partial);    \
-    } while (0)
-        if (tile == 16 && pipe) {
-#define KS_PIPE(T)                                                                                                          \
-    do {                                                                                                                    \
-        if (atomic) hipLaunchKernelGGL((keyswitch_tile_kernel<T, 16, true, 4, true>), grid, dim3(T), 0, s, p, key, u_buf, descs, count, pool); \
-        else hipLaunchKernelGGL((keyswitch_tile_kernel<T, 16, false, 4, true>), grid, dim3(T), 0, s, p, key, u_buf, descs, count, partial);    \
-    } while (0)
-            if (threads == 128) KS_PIPE(128); else if (threads == 192) KS_PIPE(192); else if (threads == 320) KS_PIPE(320); else tile = 0;
-#undef KS_PIPE
-        } else if (tile == 16) {
-            if (threads == 128) KS_TILE(128, 16); else if (threads == 192) KS_TILE(192, 16); else if (threads == 320) KS_TILE(320, 16); else tile = 0;
-        } else {
-            if (threads == 128) KS_TILE(128, 32); else if (threads == 192) KS_TILE(192, 32); else if (threads == 320) KS_TILE(320, 32); else tile = 0;
-        }
-#undef KS_TILE
-    } else {
-        tile = 0;
-    }
-    if (tile == 0)
-        hipLaunchKernelGGL(keyswitch_kernel, dim3(count, splits), dim3(threads), 0, s, p, key, u_buf, descs, pool,
-                           atomic ? nullptr : partial);
-    if (!atomic) hipLaunchKernelGGL(ks_reduce_kernel, dim3(count), dim3(threads), 0, s, p, descs, splits, partial, pool);
+    if (!tiled) hipLaunchKernelGGL(keyswitch_kernel, grid, dim3(threads), 0, s, p, key, u_buf, descs, pool, partial);
+    else if (!index) KS_FORM(keyswitch_strip_kernel, 16);
+    else if (tile == 16) KS_FORM(keyswitch_index_kernel, 16);
+    else if (tile == 24) KS_FORM(keyswitch_index_kernel, 24);
+    else KS_FORM(keyswitch_index_kernel, 32);
+#undef KS_FORM
+    hipLaunchKernelGGL(ks_reduce_kernel, dim3(count), dim3(threads), 0, s, p, descs, splits, partial, pool);
 }
 
 void launch_not(hipStream_t s, const DevParams &p, const NotDesc *descs, int count, int32_t *pool) {
@@ -1968,15 +1568,12 @@ void launch_not(hipStream_t s, const DevParams &p, const NotDesc *descs, int cou
 void launch_negacyclic(hipStream_t s, const DevParams &p, const uint32_t *tw, const int32_t *ip,
                        const uint32_t *img, int32_t *res, int count) {
     if (count <= 0) return;
-    if (p.br_variant == 2) {
+    if (p.br_variant == 2) {                 // through the split transforms
         if (p.N == 2048) hipLaunchKernelGGL(negacyclic_split_kernel<11>, dim3(count), dim3(256), 0, s, ip, img, tw, res);
         else hipLaunchKernelGGL(negacyclic_split_kernel<10>, dim3(count), dim3(256), 0, s, ip, img, tw, res);
         return;
     }
     if (p.N == 2048) hipLaunchKernelGGL(negacyclic_kernel<11>, dim3(count), dim3(128), 0, s, ip, img, tw, res);
-    else if (p.br_variant == 3) hipLaunchKernelGGL((negacyclic_kernel<10, true>), dim3(count), dim3(128), 0, s, ip, img, tw, res);
-    else if (p.br_variant == 4) hipLaunchKernelGGL((negacyclic_kernel<10, false, 64>), dim3(count), dim3(128), 0, s, ip, img, tw, res);
-    else if (p.br_variant == 5) hipLaunchKernelGGL((negacyclic_kernel<10, true, 64>), dim3(count), dim3(128), 0, s, ip, img, tw, res);
     else hipLaunchKernelGGL(negacyclic_kernel<10>, dim3(count), dim3(128), 0, s, ip, img, tw, res);
 }
 

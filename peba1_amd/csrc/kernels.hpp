@@ -14,12 +14,8 @@ struct DevParams {
     uint32_t decomp_offset; // sum_j (Bg/2) 2^{32-j Bgbit}
     uint32_t ks_prec_offset;// 2^{32-(1+basebit t)}
     int32_t mu;             // test-vector amplitude, 1/8
-    int32_t wave_prio;      // per launch: 1 = the blind-rotate waves raise their issue priority (urgent lane)
-    int32_t fair_shift;     // k > 0: the workgroups sharing a CU take turns at the higher issue priority every 2^k shader cycles
     int32_t digit_table;    // 1 = digit products of the first NTT step from an LDS table where Bgbit allows (kernels.hip)
-    int32_t br_variant;     // N = 1024: 0 = wide form (2 workgroups per CU), 1 = lean form (3 per CU); kernels.hip BrTraits
-                            // (2 = split transforms: only read by the negacyclic test launcher)
-    uint32_t *cu_arrivals;  // [4096] arrival counters per CU (never reset: only the parity of the arrival order is used)
+    int32_t br_variant;     // 2 = split transforms: only read by the negacyclic test launcher
     unsigned long long *clock_acc;  // kernel timing: [2] running sums of shader cycles (s_memtime) and of 100 MHz ticks
                                     // (s_memrealtime) over every 61st workgroup of every blind-rotate launch -> the shader
                                     // clock the launches ran at; or null
@@ -58,9 +54,10 @@ struct NotDesc { int32_t src_slot, dst_slot; };
 
 void launch_bk_transform(hipStream_t s, const DevParams &p, const int32_t *raw_polys, uint32_t *img,
                          const uint32_t *tw, int npoly_per_w, int nw, const uint32_t scale[2]);
-void launch_blind_rotate(hipStream_t s, const DevParams &p, const DevKey &key, const int32_t *pool,
-                         const RotDesc *rots, int count, int32_t *u_buf, int32_t *acc_dbg);
-// latency form (4 waves per rotation), for launches that cannot fill the chip
+// 2-wave form (N = 1024): the admissibility fallback (br_forms.hpp BR_FORM_WAVE2)
+void launch_blind_rotate2(hipStream_t s, const DevParams &p, const DevKey &key, const int32_t *pool,
+                          const RotDesc *rots, int count, int32_t *u_buf, int32_t *acc_dbg);
+// 4-wave form (N = 1024): the streaming form, two workgroups per CU
 void launch_blind_rotate4(hipStream_t s, const DevParams &p, const DevKey &key, const int32_t *pool,
                           const RotDesc *rots, int count, int32_t *u_buf, int32_t *acc_dbg);
 // 8-wave form (N = 1024, l >= 2) for launches of at most one workgroup per CU: a second wave per SIMD
@@ -70,18 +67,14 @@ void launch_blind_rotate8(hipStream_t s, const DevParams &p, const DevKey &key, 
 void launch_blind_rotate_split(hipStream_t s, const DevParams &p, const DevKey &key, const int32_t *pool,
                                const RotDesc *rots, int count, int32_t *u_buf, int32_t *acc_dbg);
 // splits > 1: each gate's key switch is cut into `splits` ranges of input coefficients
-// (partial sums in `partial[count][splits][ct_stride]`, then a reduce launch).  tile = 16 or
-// 32: launches of at least 2*tile gates use the tiled kernel (one pass over the KSK rows of
-// a range serves `tile` gates); 0 = always one workgroup per (gate, range)
-// atomic: no partial-sum buffer and no reduce launch -- the destination slots are zeroed by a small launch and
-// every range adds its sum with 32-bit atomic adds (tuning "ks_atomic"; same words: integer adds commute)
-// narrow: the tiled launch gives a thread 2 words of the row instead of 4 (more, lighter waves: kernels.hip
-// keyswitch_tile_kernel W; tuning "ks_narrow"); pipe: its strip reads run a pair of gates ahead of the subtractions
-// (keyswitch_tile_kernel PIPE; tuning "ks_pipe"; tiles of 16, 4 words per thread); branch: the rows in registers,
-// picked by scalar branches on the wave-uniform digit (keyswitch_branch_kernel; tuning "ks_branch"; not with atomic)
+// (partial sums in `partial[count][splits][ct_stride]`, then a reduce launch).  tile = 16, 24 or
+// 32: launches of at least 2*tile gates use a tiled kernel (one pass over the KSK rows of
+// a range serves `tile` gates); 0 = always one workgroup per (gate, range).  index: the tiled launch is the
+// index form (rows in pinned registers picked through the VGPR index mode: keyswitch_index_kernel), else the
+// LDS-strip form (tile 16 only: keyswitch_strip_kernel)
 void launch_keyswitch(hipStream_t s, const DevParams &p, const DevKey &key, const int32_t *u_buf,
                       const KsDesc *descs, int count, int32_t *pool, int splits, int32_t *partial, int tile,
-                      bool atomic = false, bool narrow = false, bool pipe = false, int branch = 0);
+                      bool index = true);
 void launch_not(hipStream_t s, const DevParams &p, const NotDesc *descs, int count, int32_t *pool);
 // res[c] = ip[c] * (poly whose image is img[c]) through the device NTT
 void launch_negacyclic(hipStream_t s, const DevParams &p, const uint32_t *tw, const int32_t *ip,

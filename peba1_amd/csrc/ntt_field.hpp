@@ -1,7 +1,7 @@
 // ntt_field.hpp -- the two NTT primes and their Montgomery constants, shared by
 // host (table generation) and device (kernels).
 //
-// Why two 27-bit primes: measured on gfx950 (profiles/r01_valu_rates.txt),
+// Why two 27-bit primes: measured on gfx950 (profiles/archive/r01_valu_rates.txt),
 // v_mul_lo/hi_u32, v_mad_u64_u32 and v_fma_f64 all issue at the same rate
 // (~4.5 cycles per wave64 instruction at >=2 waves/SIMD), half the rate of
 // v_add_u32.  A Montgomery product is then 3 multiplier ops, and with

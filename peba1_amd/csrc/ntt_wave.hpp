@@ -70,16 +70,21 @@ constexpr int DIGIT_TAB_BITS = 7, DIGIT_TAB = 1 << DIGIT_TAB_BITS;
 // so the two rows a digit indexes together are stored as ONE 8-byte entry: per group of four coefficients one
 // ds_read_b32 (row w1 by x2's digit) and two ds_read_b64 instead of five dword accesses -- the LDS array serves a
 // ds_read_b64 in the cycles of one ds_read_b32, and a data-dependent address pays its bank conflicts once, not twice
-// (SQ counters: profiles/r04_lds_conflict_attribution*.txt).  Layout of a table, in words:
+// (SQ counters: profiles/archive/r04_lds_conflict_attribution*.txt).  Layout of a table, in words:
 //   [0, DIGIT_TAB)                 w1 d
 //   [DIGIT_TAB, 3 DIGIT_TAB)       {w2 d, w3 d} per digit field
 //   [3 DIGIT_TAB, 5 DIGIT_TAB)     {w1 w2 d, (P - w1 w3) d} per digit field
-// BR_TAB_PAIRS=0 builds the round-3 layout (five rows of words) for A/B measurements.
-#ifndef BR_TAB_PAIRS
-#define BR_TAB_PAIRS 1
+// the lowest digit field must start at this bit or higher for the table index (8-byte entries) to be a plain shift + mask
+constexpr int DIGIT_TAB_MIN_SHIFT = 3;
+// How many of the first step's register groups (REGS / 4 of them: four at N = 1024) take their products from the table;
+// the rest multiply.  The table trades 11 multiplier-class instructions per group for LDS reads with data-dependent
+// addresses, i.e. bank conflicts: all-table against no-table measured 38.36 against 38.49 ms per 4,096 rotations with 2.64 G
+// against 1.63 G conflict cycles (profiles/archive/r04_lds_conflict_attribution.txt) -- a VALU / LDS balance whose middle points
+// round 6 swept once (tools/diag/r6_table_fraction.sh -> profiles/r06_ab_table_fraction.txt).
+// A measurement switch: the default is every group by table.
+#ifndef BR_TAB_GROUPS
+#define BR_TAB_GROUPS 99
 #endif
-// the lowest digit field must start at this bit or higher for the table index to be a plain shift + mask
-constexpr int DIGIT_TAB_MIN_SHIFT = BR_TAB_PAIRS ? 3 : 2;
 
 // signed Montgomery reduction: T*R^-1 mod P, |result| <= |T|/2^32 + P/2
 __device__ __forceinline__ int32_t mont_redc(int64_t T, uint32_t P, uint32_t pinv) {
@@ -199,14 +204,11 @@ struct WaveNtt {
     // Rows 8 words apart put the eight lanes of a b128 store group on eight different 16-byte slots and the four rows
     // of a gather on four different 8-bank windows; the pads keep the second gather (rows 4 apart) conflict-free too
     // (tools/lds_bank_model.py checks all of it against the bank rules of MI355X_MICROARCH.md).
-#ifndef BR_INV_LAYOUT_H
-#define BR_INV_LAYOUT_H 1
-#endif
     static constexpr int HROW = REGS < 8 ? REGS : 8;
     static constexpr int HPIECES = REGS / HROW;
     // piece arrays 16 words off a multiple of 32 where a gather spans two pieces (N = 2048: 16 columns per half wave)
     static constexpr int HPIECE = 64 * HROW + 4 * 16 + (HPIECES > 2 ? 16 : 0);
-    static constexpr int INV_WORDS = BR_INV_LAYOUT_H ? HPIECES * HPIECE : ROW_WORDS;
+    static constexpr int INV_WORDS = HPIECES * HPIECE;
     static constexpr int SCRATCH_WORDS = INV_WORDS > ROW_WORDS ? INV_WORDS : ROW_WORDS;   // a wave's transpose scratch
     static_assert(LOGN >= 9 && LOGN <= 11, "wave NTT is laid out for N = 512 (half of a split 1024-point transform), 1024 or 2048");
 
@@ -399,76 +401,18 @@ struct WaveNtt {
     }
     static constexpr int steps_in(int stages) { return (stages + 1) / 2; }
 
-    // ---- the first transpose (L0 -> L1) through the cross-lane VALU paths instead of LDS ------------------
-    // MEASUREMENT ONLY (negacyclic test kernel, "br_variant" 3): north_star names wavefront
-    // shuffle primitives, so the alternative to the LDS transposes was built once and timed.  L0 -> L1 swaps lane
-    // bit 2 + b with register bit b (b = 0..3, N = 1024): for every register pair (A, B) = (x[r], x[r | 1 << b])
-    // the lanes with the lane bit set exchange their A with the B of the partner lane.  Lane bit 5: one
-    // v_permlane32_swap per pair; bit 4: one v_permlane16_swap; bits 3, 2: two v_mov_b32_dpp (row_shr / row_shl by
-    // 8 or 4 under a bank mask) per pair -- 8 + 8 + 16 + 16 = 48 VALU instructions (+ copies) where the LDS form
-    // issues 16 ds_write_b32 and 4 ds_read_b128 and no VALU at all.
-    static __device__ __forceinline__ void transpose1_crosslane(int32_t (&x)[REGS]) {
-        static_assert(LOGN == 10, "cross-lane transpose written for N = 1024 (4 register bits, lane bits 5..2)");
-#pragma unroll
-        for (int r = 0; r < REGS; ++r)
-            if (!(r & 8)) {              // lane bit 5 <-> register bit 3
-                const auto v = __builtin_amdgcn_permlane32_swap((unsigned)x[r], (unsigned)x[r | 8], false, false);
-                x[r] = (int32_t)v[0]; x[r | 8] = (int32_t)v[1];
-            }
-#pragma unroll
-        for (int r = 0; r < REGS; ++r)
-            if (!(r & 4)) {              // lane bit 4 <-> register bit 2
-                const auto v = __builtin_amdgcn_permlane16_swap((unsigned)x[r], (unsigned)x[r | 4], false, false);
-                x[r] = (int32_t)v[0]; x[r | 4] = (int32_t)v[1];
-            }
-#pragma unroll
-        for (int r = 0; r < REGS; ++r)
-            if (!(r & 2)) {              // lane bit 3 <-> register bit 1: rows of 16, distance 8, banks {2,3} / {0,1}
-                const int a = x[r], b = x[r | 2];
-                x[r] = __builtin_amdgcn_update_dpp(a, b, 0x118 /* row_shr:8 */, 0xF, 0xC, false);
-                x[r | 2] = __builtin_amdgcn_update_dpp(b, a, 0x108 /* row_shl:8 */, 0xF, 0x3, false);
-            }
-#pragma unroll
-        for (int r = 0; r < REGS; ++r)
-            if (!(r & 1)) {              // lane bit 2 <-> register bit 0: distance 4, banks {1,3} / {0,2}
-                const int a = x[r], b = x[r | 1];
-                x[r] = __builtin_amdgcn_update_dpp(a, b, 0x114 /* row_shr:4 */, 0xF, 0xA, false);
-                x[r | 1] = __builtin_amdgcn_update_dpp(b, a, 0x104 /* row_shl:4 */, 0xF, 0x5, false);
-            }
-    }
-    // forward transform whose first transpose goes through the cross-lane paths (measurement only)
-    static __device__ __forceinline__ void forward_crosslane(int32_t (&x)[REGS], const PrimeCtx &c, uint32_t *scr, int lane) {
-        FwdTw0 t0;
-        t0.load(c, lane);
-        fwd_pass(x, c, t0);
-        FwdTw1 t1;
-        t1.load(c, lane);
-        transpose1_crosslane(x);
-        fwd_pass(x, c, t1);
-        FwdTw2 t2;
-        t2.load(c, lane);
-#pragma unroll
-        for (int r = 0; r < REGS; ++r) scr[t2_l1_addr(lane, r)] = (uint32_t)x[r];
-        wave_lds_fence();
-        read_row(x, scr, lane);
-        wave_lds_fence();
-        fwd_pass(x, c, t2);
-    }
-
     // forward NTT: x in L0 (natural order) -> L2; |x| <= 2^11 ends below 6.7P, |x| < P below 8.2P.
     // t0: the first pass's twiddles, loaded by the caller (FwdTw0 t0; t0.load(c, lane);)
-    // EARLY = false: a pass's twiddles are loaded after the transpose instead (fewer live registers).
-    template <bool EARLY = true, bool LDSTW = false>
+    template <bool LDSTW = false>
     static __device__ __forceinline__ void forward(int32_t (&x)[REGS], const PrimeCtx &c, uint32_t *scr, int lane,
                                                    const FwdTw0 &t0) {
         fwd_pass(x, c, t0);
-        forward_tail<EARLY, LDSTW>(x, c, scr, lane);
+        forward_tail<LDSTW>(x, c, scr, lane);
     }
-    template <bool EARLY = true>
     static __device__ __forceinline__ void forward(int32_t (&x)[REGS], const PrimeCtx &c, uint32_t *scr, int lane) {
         FwdTw0 t0;
         t0.load(c, lane);
-        forward<EARLY>(x, c, scr, lane, t0);
+        forward<false>(x, c, scr, lane, t0);
     }
 
     // Forward NTT of the gadget digit at bit position `shift`, `width` bits wide, of every D[r] (digit
@@ -477,40 +421,42 @@ struct WaveNtt {
     // reads, 3 shift+mask index computations and 8 additions instead of 4 bit-field extractions,
     // 11 multiplier-class instructions and 6 additions; magnitudes after the step are below
     // 1.5P + 2^6 instead of P, after the transform below 6.8P (N=1024) / 7.4P (N=2048).
-    template <bool EARLY, bool TABLE>
-    static __device__ __forceinline__ void forward_digits(int32_t (&x)[REGS], const uint32_t (&D)[REGS], int shift, int width,
-                                                          const PrimeCtx &c, uint32_t *scr, int lane) {
-        FwdTw0 t0;
-        t0.load(c, lane);
-        forward_digits<EARLY, TABLE>(x, D, shift, width, c, scr, lane, t0);
-    }
     // t0: the first pass's twiddles (lane-uniform and the same for every transform: a caller may load them once)
     // LDSTW: the per-lane twiddles of the second and third pass come from the workgroup's LDS copy (c.fw1, c.fw2)
     // instead of global memory.  They are the same for every row and step; from LDS they cost 13 ds_read_b128 per
     // transform where the global form issues 16 loads through the vector-memory pipe -- and, more to the point, they
     // leave the vector-memory counter to the key rows alone: a wait for twiddles no longer waits for the (older,
     // slower) key loads, whose latency then hides under the whole transform (round 3).
-    template <bool EARLY, bool TABLE, bool LDSTW = false>
+    template <bool TABLE, bool LDSTW = false>
     static __device__ __forceinline__ void forward_digits(int32_t (&x)[REGS], const uint32_t (&D)[REGS], int shift, int width,
                                                           const PrimeCtx &c, uint32_t *scr, int lane, const FwdTw0 &t0) {
         if constexpr (!TABLE) {
 #pragma unroll
             for (int r = 0; r < REGS; ++r) x[r] = __builtin_amdgcn_sbfe((int32_t)D[r], shift, width);
             fwd_pass(x, c, t0);
-            forward_tail<EARLY, LDSTW>(x, c, scr, lane);
+            forward_tail<LDSTW>(x, c, scr, lane);
         } else {
             static_assert(FwdTw0::PAIR && FwdTw0::CNT == 1, "the first step is a radix-4 step with one block");
             constexpr int RBIT = rbit_of(0), h = 1 << RBIT, l = h >> 1;
             const uint32_t mask4 = ((1u << width) - 1u) << 2;            // byte offset of a table word
             const int sh = shift - 2;
             const char *tab = reinterpret_cast<const char *>(c.dtab);
-#if BR_TAB_PAIRS
             const uint32_t mask8 = mask4 << 1;                           // byte offset of a pair
             const int sh8 = shift - 3;
             const char *tab1 = tab + DIGIT_TAB * 4, *tab3 = tab + 3 * DIGIT_TAB * 4;
 #pragma unroll
             for (int r = 0; r < REGS; ++r)
                 if (!(r & (h | l))) {
+                    // groups in register order: the first BR_TAB_GROUPS by table, the others by the radix-4 butterfly on
+                    // their extracted digits (|outputs| < P + 2^6: inside the table groups' 1.5P + 2^6)
+                    if ((r & (l - 1)) + ((r >> (RBIT + 1)) * l) >= BR_TAB_GROUPS) {
+                        x[r] = __builtin_amdgcn_sbfe((int32_t)D[r], shift, width);
+                        x[r | l] = __builtin_amdgcn_sbfe((int32_t)D[r | l], shift, width);
+                        x[r | h] = __builtin_amdgcn_sbfe((int32_t)D[r | h], shift, width);
+                        x[r | h | l] = __builtin_amdgcn_sbfe((int32_t)D[r | h | l], shift, width);
+                        ct_bfly4(x[r], x[r | l], x[r | h], x[r | h | l], t0.tw[0], t0.q[0], c);
+                        continue;
+                    }
                     const int32_t x0 = __builtin_amdgcn_sbfe((int32_t)D[r], shift, width);
                     const uint32_t i1 = (D[r | l] >> sh8) & mask8, i2 = (D[r | h] >> sh) & mask4, i3 = (D[r | h | l] >> sh8) & mask8;
                     const int32_t A = (int32_t)*reinterpret_cast<const uint32_t *>(tab + i2);
@@ -520,54 +466,37 @@ struct WaveNtt {
                     const int32_t u = x0 + A, v = x0 - A;
                     x[r] = u + S; x[r | l] = u - S; x[r | h] = v + T; x[r | h | l] = v - T;
                 }
-#else
-            auto entry = [&](int k, uint32_t off) { return (int32_t)*reinterpret_cast<const uint32_t *>(tab + k * (DIGIT_TAB * 4) + off); };
-#pragma unroll
-            for (int r = 0; r < REGS; ++r)
-                if (!(r & (h | l))) {
-                    const int32_t x0 = __builtin_amdgcn_sbfe((int32_t)D[r], shift, width);
-                    const uint32_t i1 = (D[r | l] >> sh) & mask4, i2 = (D[r | h] >> sh) & mask4, i3 = (D[r | h | l] >> sh) & mask4;
-                    const int32_t A = entry(0, i2);
-                    const int32_t S = entry(1, i1) + entry(2, i3);
-                    const int32_t T = entry(3, i1) + entry(4, i3);
-                    const int32_t u = x0 + A, v = x0 - A;
-                    x[r] = u + S; x[r | l] = u - S; x[r | h] = v + T; x[r | h | l] = v - T;
-                }
-#endif
-            forward_rest<EARLY, LDSTW>(x, c, scr, lane, t0);
+            forward_rest<LDSTW>(x, c, scr, lane, t0);
         }
     }
     // everything after the first radix-4 step of a forward transform (for callers that produce that
     // step's outputs themselves, from tables)
-    template <bool EARLY, bool LDSTW = false>
+    template <bool LDSTW = false>
     static __device__ __forceinline__ void forward_rest(int32_t (&x)[REGS], const PrimeCtx &c, uint32_t *scr, int lane,
                                                         const FwdTw0 &t0) {
         static_assert(FwdTw0::PAIR, "the first step is a radix-4 step");
         if constexpr (RB > 2) fwd_pass(x, c, t0.rest);               // the other steps of the first pass
-        forward_tail<EARLY, LDSTW>(x, c, scr, lane);
+        forward_tail<LDSTW>(x, c, scr, lane);
     }
-    // second and third pass of a forward transform, with the two transposes in front of them
-    template <bool EARLY, bool LDSTW>
+    // second and third pass of a forward transform, with the two transposes in front of them; a pass's twiddles are
+    // requested BEFORE the transpose in front of it (their latency overlaps the transpose)
+    template <bool LDSTW>
     static __device__ __forceinline__ void forward_tail(int32_t (&x)[REGS], const PrimeCtx &c, uint32_t *scr, int lane) {
         FwdTw1 t1;
-        auto get1 = [&] { if constexpr (LDSTW) t1.from_image(static_cast<const uint4 *>(c.fw1)); else t1.load(c, lane); };
-        if constexpr (EARLY) get1();
+        if constexpr (LDSTW) t1.from_image(static_cast<const uint4 *>(c.fw1)); else t1.load(c, lane);
 #pragma unroll
         for (int r = 0; r < REGS; ++r) scr[t1_l0_addr(lane, r)] = (uint32_t)x[r];
         wave_lds_fence();
         read_row(x, scr, lane);
         wave_lds_fence();
-        if constexpr (!EARLY) get1();
         fwd_pass(x, c, t1);
         FwdTw2 t2;
-        auto get2 = [&] { if constexpr (LDSTW) t2.from_image(static_cast<const uint4 *>(c.fw2)); else t2.load(c, lane); };
-        if constexpr (EARLY) get2();
+        if constexpr (LDSTW) t2.from_image(static_cast<const uint4 *>(c.fw2)); else t2.load(c, lane);
 #pragma unroll
         for (int r = 0; r < REGS; ++r) scr[t2_l1_addr(lane, r)] = (uint32_t)x[r];
         wave_lds_fence();
         read_row(x, scr, lane);
         wave_lds_fence();
-        if constexpr (!EARLY) get2();
         fwd_pass(x, c, t2);
     }
     // fills this prime's digit table for digits of `width` bits (threads tid, tid + nthreads, ... of
@@ -579,47 +508,41 @@ struct WaveNtt {
         for (int e = tid; e < 5 * fields; e += nthreads) {
             const int k = e >> width, f = e & (fields - 1);
             const int32_t d = f < fields / 2 ? f : f - fields;
-#if BR_TAB_PAIRS
             // k = 0: the word row; k = 1, 3 (w2, w3): halves of the pair x1's digit reads; k = 2, 4: of x3's
             const int pos = k == 0 ? f : (k & 1 ? DIGIT_TAB : 3 * DIGIT_TAB) + 2 * f + (k > 2 ? 1 : 0);
-#else
-            const int pos = k * DIGIT_TAB + f;
-#endif
             tab[pos] = (uint32_t)mont_mul(d, w[k], c.P, c.pinv);
         }
     }
 
     // inverse NTT (unscaled: the 1/N is folded into the key image):
     // x in L2, |x| < 4P -> L0 (natural order), |x| < P.  t2: the first pass's twiddles (InvTw2), as above
-    // LAYOUT_H: the transposes go through layout H (above; scr must hold INV_WORDS words) instead of layout R
-    template <bool EARLY = true, bool LAYOUT_H = (BR_INV_LAYOUT_H != 0)>
+    // LAYOUT_H (default): the transposes go through layout H (above; scr must hold INV_WORDS words); false: layout R
+    // (the 8-wave form's half transforms: with H its schedule came out 0.13 ms per rotation slower, profiles/archive/r04_ab_*.txt)
+    template <bool LAYOUT_H = true>
     static __device__ __forceinline__ void inverse(int32_t (&x)[REGS], const PrimeCtx &c, uint32_t *scr, int lane,
                                                    const InvTw2 &t2) {
         inv_pass<0>(x, c, t2);
         InvTw1 t1;
-        if constexpr (EARLY) t1.load(c, lane);
+        t1.load(c, lane);
         if constexpr (LAYOUT_H) write_row_h(x, scr, lane); else write_row(x, scr, lane);
         wave_lds_fence();
 #pragma unroll
         for (int r = 0; r < REGS; ++r) x[r] = (int32_t)scr[LAYOUT_H ? h_t2_addr(lane, r) : t2_l1_addr(lane, r)];
         wave_lds_fence();
-        if constexpr (!EARLY) t1.load(c, lane);
         inv_pass<steps_in(LC)>(x, c, t1);
         InvTw0 t0;
-        if constexpr (EARLY) t0.load(c, lane);
+        t0.load(c, lane);
         if constexpr (LAYOUT_H) write_row_h(x, scr, lane); else write_row(x, scr, lane);
         wave_lds_fence();
 #pragma unroll
         for (int r = 0; r < REGS; ++r) x[r] = (int32_t)scr[LAYOUT_H ? h_t1_addr(lane, r) : t1_l0_addr(lane, r)];
         wave_lds_fence();
-        if constexpr (!EARLY) t0.load(c, lane);
         inv_pass<steps_in(LC) + steps_in(RB)>(x, c, t0);
     }
-    template <bool EARLY = true>
     static __device__ __forceinline__ void inverse(int32_t (&x)[REGS], const PrimeCtx &c, uint32_t *scr, int lane) {
         InvTw2 t2;
         t2.load(c, lane);
-        inverse<EARLY>(x, c, scr, lane, t2);
+        inverse<true>(x, c, scr, lane, t2);
     }
 };
 

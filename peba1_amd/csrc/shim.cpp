@@ -971,24 +971,23 @@ int tfhe_hip_gate_batch(int gate, LweSample *result, const LweSample *a, const L
     return rc;
 }
 
+void tfhe_hip_test_set_alloc_cap(int64_t bytes) {
+    std::lock_guard<std::recursive_mutex> g(rec().mtx);
+    set_alloc_cap((long long)bytes);
+}
+
 int tfhe_hip_test_form_admissible(int form, int32_t N, int32_t l, int32_t Bgbit, int tables) {
     return br_form_admissible(form, N, l, Bgbit, tables) ? 1 : 0;
 }
 
 int tfhe_hip_set_tuning(const char *name, int64_t value) {
     std::lock_guard<std::recursive_mutex> g(rec().mtx);      // the launchers read the tunings under the same lock (flushes)
-    if (name && std::strcmp(name, "br4_max_rotations") == 0) { Engine::get().br4_max_rotations = (int)value; return 0; }
-    if (name && std::strcmp(name, "ks_target_blocks") == 0) { Engine::get().ks_target_blocks = (int)value; return 0; }
     if (name && std::strcmp(name, "ks_tile") == 0) {
         if (value != 0 && value != 16 && value != 24 && value != 32) { set_error("ks_tile must be 0, 16, 24 or 32"); return -1; }
         Engine::get().ks_tile = (int)value;
         return 0;
     }
-    if (name && std::strcmp(name, "ks_atomic") == 0) { Engine::get().ks_atomic = value != 0; return 0; }
-    if (name && std::strcmp(name, "ks_narrow") == 0) { Engine::get().ks_narrow = value != 0; return 0; }
-    if (name && std::strcmp(name, "ks_pipe") == 0) { Engine::get().ks_pipe = value != 0; return 0; }
-    if (name && std::strcmp(name, "ks_branch") == 0) { Engine::get().ks_branch = (int)value; return 0; }
-    if (name && std::strcmp(name, "br_fair") == 0) { Engine::get().br_fair = (int)value; return 0; }
+    if (name && std::strcmp(name, "ks_index") == 0) { Engine::get().ks_index = value != 0; return 0; }
     if (name && std::strcmp(name, "br_digit_table") == 0) { Engine::get().br_digit_table = (int)value; return 0; }
     if (name && std::strcmp(name, "br8_max_rotations") == 0) { Engine::get().br8_max_rotations = (int)value; return 0; }
     if (name && std::strcmp(name, "br_tail8") == 0) { Engine::get().br_tail8 = (int)value; return 0; }
@@ -1042,18 +1041,11 @@ int tfhe_hip_test_schedule(const int32_t *ops5, int32_t count, int32_t unit, int
 }
 
 
-double tfhe_hip_test_lane_probe(const TFheGateBootstrappingCloudKeySet *bk, int32_t lanes, int32_t levels, int32_t width) {
-    if (!bk || !bk->bk) { set_error("lane_probe: null keyset"); return -1.0; }
-    std::lock_guard<std::recursive_mutex> g(rec().mtx);
-    pool_of_key(bk);
-    return Engine::get().run_lane_probe(bk->bk->dev, lanes, levels, width);
-}
-
 int tfhe_hip_test_wg_times(const TFheGateBootstrappingCloudKeySet *bk, int32_t width, uint64_t *times4, double *launch_ms) {
     if (!bk || !bk->bk || !times4 || width <= 0) { set_error("wg_times: bad arguments"); return -1; }
     std::lock_guard<std::recursive_mutex> g(rec().mtx);
     pool_of_key(bk);
-    const double ms = Engine::get().run_lane_probe(bk->bk->dev, 1, 1, width, reinterpret_cast<unsigned long long *>(times4));
+    const double ms = Engine::get().run_wg_times(bk->bk->dev, width, reinterpret_cast<unsigned long long *>(times4));
     if (launch_ms) *launch_ms = ms;
     if (ms < 0) { set_error("wg_times: the launched kernel form wrote no stamps"); return -1; }
     return 0;

@@ -77,6 +77,9 @@ def load():
         D.peba1_dist_transport.argtypes = [V]
         D.peba1_dist_counters.restype = None
         D.peba1_dist_counters.argtypes = [V, C.POINTER(C.c_uint64)]
+        D.peba1_dist_status_channel.argtypes = [V]
+        D.peba1_dist_sequence.restype = None
+        D.peba1_dist_sequence.argtypes = [V, C.POINTER(C.c_uint64)]
         D.peba1_dist_inject_failure.restype = None
         D.peba1_dist_inject_failure.argtypes = [V, I]
         _dlib = D
@@ -139,15 +142,19 @@ class Comm:
         self._keep = None
         self.transport = device
         if device == "cuda":
-            ident = [None]
-            if self.rank == 0:
-                buf = C.create_string_buffer(128)
-                # (a failure here must still reach the broadcast below, or the other ranks wait in it for ever)
-                ident[0] = buf.raw if D.peba1_dist_unique_id(buf) == 0 else ("error", D.peba1_dist_last_error().decode())
-            dist.broadcast_object_list(ident, src=0)
-            if not isinstance(ident[0], bytes):
-                raise RuntimeError("cannot create the communicator: rank 0 has no RCCL unique id: " + str(ident[0]))
-            self.ptr = D.peba1_dist_init_rccl(ident[0], self.world, self.rank)
+            # Agree BEFORE ncclCommInitRank: no deadline covers that call, so a rank that cannot take part (RCCL
+            # does not load there, a symbol is missing, no unique id) must be known to every rank before any rank enters it.
+            # Every rank probes locally -- peba1_dist_unique_id opens RCCL, resolves every symbol the transport uses and
+            # makes an id, all without talking to anyone -- and the torch group (any backend) collects the verdicts.
+            buf = C.create_string_buffer(128)
+            ready = D.peba1_dist_unique_id(buf) == 0
+            mine = (ready, buf.raw if ready and self.rank == 0 else None, None if ready else D.peba1_dist_last_error().decode())
+            verdicts = [None] * self.world
+            dist.all_gather_object(verdicts, mine)
+            bad = [f"rank {r}: {v[2]}" for r, v in enumerate(verdicts) if not v[0]]
+            if bad:                                     # the same exception on every rank, and nobody is inside RCCL
+                raise RuntimeError("cannot create the communicator: " + "; ".join(bad))
+            self.ptr = D.peba1_dist_init_rccl(verdicts[0][1], self.world, self.rank)
         else:
             stage = (lambda t: t.cuda()) if device == "torch-cuda" else (lambda t: t)
 
@@ -185,6 +192,11 @@ class Comm:
         if not self.ptr:
             raise RuntimeError("cannot create the communicator: " + D.peba1_dist_last_error().decode())
 
+    def abandon(self):
+        """Forget the communicator WITHOUT destroying it: after a failed trial it may hold a collective that never completes,
+        and ncclCommDestroy / the stream wait in front of it would then hang too.  Leaks it on purpose."""
+        self.ptr = None
+
     def close(self):
         if self.ptr:
             load().peba1_dist_destroy(self.ptr)
@@ -194,8 +206,13 @@ class Comm:
         """What this communicator has done so far (peba1_dist_counters)."""
         out = (C.c_uint64 * 4)()
         load().peba1_dist_counters(self.ptr, out)
+        seq = (C.c_uint64 * 2)()
+        load().peba1_dist_sequence(self.ptr, seq)
+        channel = {0: "in front of the payload (host transport)", 1: "data communicator, provider's stream",
+                   2: "own communicator (ncclCommSplit), own stream"}[load().peba1_dist_status_channel(self.ptr)]
         return {"status_word_exchanges": int(out[0]), "gathers": int(out[1]), "broadcasts": int(out[2]),
-                "payload_bytes_sent": int(out[3]), "transport": "rccl" if load().peba1_dist_transport(self.ptr) else "host"}
+                "payload_bytes_sent": int(out[3]), "transport": "rccl" if load().peba1_dist_transport(self.ptr) else "host",
+                "status_channel": channel, "collectives_issued": int(seq[0]), "issue_order_hash": f"{int(seq[1]):016x}"}
 
     def set_timeout(self, seconds):
         """Bound of every host wait behind a collective (peba1_dist_set_timeout; default PEBA1_DIST_TIMEOUT_S or 600 s)."""

@@ -92,7 +92,6 @@ SIGNATURES = {
     "export_gate_bootstrapping_ciphertext_toFile": (None, [C.c_void_p, LS, PS]),
     "import_gate_bootstrapping_ciphertext_fromFile": (None, [C.c_void_p, LS, PS]),
     "tfhe_hip_test_wg_times": (C.c_int, [CK, C.c_int32, C.POINTER(C.c_uint64), C.POINTER(C.c_double)]),
-    "tfhe_hip_test_lane_probe": (C.c_double, [CK, C.c_int32, C.c_int32, C.c_int32]),
     "tfhe_hip_last_error": (C.c_char_p, []),
     "tfhe_hip_clear_error": (None, []),
     "tfhe_hip_set_device": (C.c_int, [C.c_int]),
@@ -129,6 +128,7 @@ SIGNATURES = {
     "tfhe_hip_gate_batch": (C.c_int, [C.c_int, LS, LS, LS, C.c_int32, CK]),
     "tfhe_hip_set_tuning": (C.c_int, [C.c_char_p, C.c_int64]),
     "tfhe_hip_test_form_admissible": (C.c_int, [C.c_int, C.c_int32, C.c_int32, C.c_int32, C.c_int]),
+    "tfhe_hip_test_set_alloc_cap": (None, [C.c_int64]),
     "tfhe_hip_get_stats": (None, [C.POINTER(Stats)]),
     "tfhe_hip_reset_stats": (None, []),
     "tfhe_hip_set_kernel_timing": (None, [C.c_int]),

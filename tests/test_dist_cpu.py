@@ -235,11 +235,14 @@ def test_bench_launcher_parent_reports_failed_ranks_and_never_loads_the_gpu_libr
     # the parent's own modules: import bench and run the launcher's argument handling in-process, then look at what is loaded
     code = ("import sys, os; sys.argv = ['bench.py', '--gpus', '2']; sys.path.insert(0, %r)\n"
             "import bench, subprocess\n"
+            "from benchkit.launch import self_launch\n"
             "class P:\n"
             "    stdout = iter(())\n"
+            "    pid = 0\n"
             "    def wait(self): return 7\n"
+            "    def poll(self): return 7\n"
             "subprocess.Popen = lambda *a, **k: P()\n"
-            "rc = bench.self_launch(2)\n"
+            "rc = self_launch(2)\n"
             "maps = open('/proc/self/maps').read()\n"
             "assert rc == 7, rc\n"
             "assert 'libtfhe-hip' not in maps and 'libamdhip64' not in maps and 'torch' not in sys.modules, 'the launcher touched the GPU stack'\n"

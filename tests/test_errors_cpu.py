@@ -157,19 +157,21 @@ def test_default_randomness_is_not_a_constant(L):
 
 def test_kernel_form_admissibility_predicate():
     """every blind-rotate kernel form has an explicit admissible (l, Bgbit) range derived from its own
-    lazy-arithmetic bounds (peba1_amd/csrc/br_forms.hpp).  Built-in sets: everything except the 4-wave form at
-    N = 2048 with l = 3 (both sums reduced per row: 4.4P into an inverse that takes < 4P) -- the split form is the
-    default there.  Custom gadgets: l = 4 stays inside the wide, split, 8-wave and 2-wave forms, not the lean one;
-    N = 2048 / l = 6 / Bgbit = 4 only inside the split form without its eleven-table first step; l = 8 at N = 2048
-    inside none."""
+    lazy-arithmetic bounds (peba1_amd/csrc/br_forms.hpp).  Built-in sets: every form of the set's ring (N = 2048 has
+    the split form only).  Custom gadgets: l = 4 / Bg = 2^8 stays inside all four forms at N = 1024; N = 2048 / l = 6 /
+    Bgbit = 4 only inside the split form without its eleven-table first step; l = 8 at N = 2048 inside none;
+    N = 1024 / l = 8 / Bg = 2^4 only inside the split and 2-wave forms; l = 9 / Bg = 2^3 only inside the 2-wave form
+    (why that form stays in the library)."""
     from peba1_amd import lib
     ok = lib.load().tfhe_hip_test_form_admissible
-    WIDE4, LEAN4, SPLIT, WAVE8, WAVE2 = range(5)
+    WIDE4, SPLIT, WAVE8, WAVE2 = range(4)
     for N, l, B in ((1024, 3, 7), (1024, 2, 10)):
-        assert all(ok(f, N, l, B, t) for f in range(5) for t in range(3))
-    assert [ok(f, 2048, 3, 6, 1) for f in range(5)] == [0, 0, 1, 0, 0]
-    assert [ok(f, 1024, 4, 8, 1) for f in range(5)] == [1, 0, 1, 1, 1]
+        assert all(ok(f, N, l, B, t) for f in range(4) for t in range(3))
+    assert [ok(f, 2048, 3, 6, 1) for f in range(4)] == [0, 1, 0, 0]
+    assert [ok(f, 1024, 4, 8, 1) for f in range(4)] == [1, 1, 1, 1]
     assert [ok(SPLIT, 2048, 6, 4, t) for t in range(3)] == [1, 0, 1]
-    assert not any(ok(f, 2048, 8, 4, t) for f in range(5) for t in range(3))
-    assert not ok(WIDE4, 1024, 8, 4, 0) and ok(WAVE2, 1024, 8, 4, 0)
+    assert not any(ok(f, 2048, 8, 4, t) for f in range(4) for t in range(3))
+    assert not ok(WIDE4, 1024, 8, 4, 0) and ok(WAVE2, 1024, 8, 4, 0) and ok(SPLIT, 1024, 8, 4, 0)
+    assert [ok(f, 1024, 9, 3, 0) for f in range(4)] == [0, 0, 0, 1]
+    assert not ok(4, 1024, 3, 7, 0)                                             # no fifth form
     assert not ok(WIDE4, 4096, 3, 7, 0) and not ok(WIDE4, 1024, 5, 7, 0)          # ring size / l * Bgbit > 32

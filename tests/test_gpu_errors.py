@@ -175,6 +175,76 @@ def test_pool_exhaustion_is_reported_not_fatal():
     assert "POOL-OK" in out.stdout
 
 
+OOM_WORKER = r'''
+import sys
+sys.path.insert(0, %r)
+import numpy as np
+from peba1_amd import api, lib
+L = lib.load()
+pp = api.ParameterSet(128)
+ks = api.SecretKeySet(pp, 7, device=True)
+L.tfhe_hip_set_encrypt_seed(5)
+G = 5000
+rng = np.random.default_rng(1)
+xa, xb = rng.integers(0, 2, G), rng.integers(0, 2, G)
+a = api.CiphertextArray(pp, G).encrypt(xa, ks)
+b = api.CiphertextArray(pp, G).encrypt(xb, ks)
+r = api.CiphertextArray(pp, G)
+api.set_deferred(True)
+for i in range(4):                                             # a first, small flush: pool and small scratch exist
+    L.bootsAND(r.at(i), a.at(i), b.at(i), ks.cloud)
+assert api.flush() >= 0
+# (1) the scratch of a flush: a 5,000-wide level needs ~0.6 GB of key-switch partial sums; with 64 MiB of headroom the
+# flush is refused, says why, and the gates stay recorded
+L.tfhe_hip_test_set_alloc_cap(64 << 20)                        # less than what is already held: nothing more may be allocated
+for i in range(G):
+    L.bootsAND(r.at(i), a.at(i), b.at(i), ks.cloud)
+L.tfhe_hip_clear_error()
+assert api.flush() == -1
+msg = L.tfhe_hip_last_error().decode()
+assert "out of device memory" in msg and "scratch" in msg, msg
+assert api.flush() == -1                                       # still pending, still refused
+L.tfhe_hip_test_set_alloc_cap(0)
+L.tfhe_hip_clear_error()
+assert api.flush() >= 1 and L.tfhe_hip_last_error().decode() == ""
+assert (r.decrypt(ks) == (xa & xb)).all()
+# (2) the slot pool's growth (it starts at 65,536 slots): the gate that needs slot 65,537 is refused and has no effect;
+# with the cap lifted the same call works and every gate recorded before it still evaluates
+L.tfhe_hip_test_set_alloc_cap(1 << 20)
+big = api.CiphertextArray(pp, 70000)
+refused = None
+for i in range(70000):
+    L.tfhe_hip_clear_error()
+    L.bootsXOR(big.at(i), a.at(i %% G), b.at((i + i // G) %% G), ks.cloud)       # a pair of operands never repeats: no gate is shared
+    e = L.tfhe_hip_last_error().decode()
+    if e:
+        refused = (i, e)
+        break
+assert refused is not None and "out of device memory" in refused[1] and "slot pool" in refused[1], refused
+assert 40000 < refused[0] < 65536, refused
+L.tfhe_hip_test_set_alloc_cap(0)
+L.tfhe_hip_clear_error()
+for i in range(refused[0], refused[0] + 2000):
+    L.bootsXOR(big.at(i), a.at(i %% G), b.at((i + i // G) %% G), ks.cloud)
+assert L.tfhe_hip_last_error().decode() == ""
+n = refused[0] + 2000
+got = big.decrypt(ks)[:n]
+want = np.array([xa[i %% G] ^ xb[(i + i // G) %% G] for i in range(n)])
+assert (got == want).all()
+print("OOM-OK", refused[0])
+'''
+
+
+def test_device_memory_exhaustion_is_recoverable():
+    """VERDICT r5 item 8: hipErrorOutOfMemory while sizing a flush's scratch or growing the slot pool (here: an artificial
+    cap, tfhe_hip_test_set_alloc_cap) does not abort the host: the flush returns -1 / the gate call has no effect,
+    tfhe_hip_last_error() names what could not be allocated, the recorded gates stay recorded and evaluate once memory
+    is there."""
+    out = subprocess.run([sys.executable, "-c", OOM_WORKER % ROOT], capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-3000:]
+    assert "OOM-OK" in out.stdout
+
+
 def test_pool_size_is_bounded_by_the_gate_key_fields():
     """VERDICT r1 item 7: TFHE_HIP_POOL_SLOTS beyond what the pending-gate keys can hold (2^29) is
     clamped and reported instead of letting two gates share a key."""

@@ -350,33 +350,6 @@ def test_edge_cases_empty_ragged_and_wide(p128_keys, oracle):
         assert (got[i] == oks.gate("ORNY", wa[i], wb[i])).all(), i
 
 
-def test_priority_swapping_does_not_change_results(p128_keys, oracle):
-    """Issue priority is pure scheduling: the kernel's own progress priority (the default, br_fair = 0) and the time
-    slices of rounds 1-4 on top of it (br_fair > 0: co-resident blind-rotate workgroups swap issue priority) give the
-    same words on a launch wide enough to put two workgroups on every CU."""
-    from peba1_amd import api, lib
-    pp, ks, oks = p128_keys
-    L = lib.load()
-    G = 700
-    rng = np.random.default_rng(18)
-    L.tfhe_hip_set_encrypt_seed(1818)
-    a = api.CiphertextArray(pp, G).encrypt(rng.integers(0, 2, G), ks)
-    b = api.CiphertextArray(pp, G).encrypt(rng.integers(0, 2, G), ks)
-    out = []
-    try:
-        for fair in (0, 18, 12):
-            api.set_tuning("br_fair", fair)
-            res = api.CiphertextArray(pp, G)
-            api.gate_batch("XNOR", res, a, b, ks)
-            out.append(res.words())
-    finally:
-        api.set_tuning("br_fair", 0)
-    assert (out[0] == out[1]).all() and (out[0] == out[2]).all()
-    wa, wb = a.words(), b.words()
-    for i in (0, 255, 256, 699):
-        assert (out[0][i] == oks.gate("XNOR", wa[i], wb[i])).all(), i
-
-
 def test_asynchronous_flush_pipelines_circuits_with_the_same_results(p128_keys):
     """tfhe_hip_flush_async: the launches of one recording are enqueued and the caller goes on recording the next --
     here a chain of three multipliers, each reading the one before (so a flush in flight feeds the next recording),

@@ -393,32 +393,38 @@ def test_sharded_match_in_two_processes_reproduces_the_oracle_digest(tmp_path):
     assert out.returncode == 0 and "TWO-PROCESS-OK" in out.stdout, out.stdout[-1500:] + out.stderr[-3000:]
 
 
-def _check_rehearsal_line(out, transport="gloo"):
+def _check_rehearsal_line(out, transport="gloo", world=2):
     import json
     assert out.returncode == 0, out.stdout[-1500:] + out.stderr[-3000:]
     lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
     j = json.loads(lines[-1])
-    assert j["n_gpus"] == 2 and j["scaling"] == "strong" and j["config"]["mode"] == "sharded"
+    assert j["n_gpus"] == world and j["scaling"] == "strong" and j["config"]["mode"] == "sharded"
     assert j["value"] > 0 and j["roofline"]["frac"] > 0
     # all ranks' rotations are counted: 8 slots of the reference's loop, one adder on rank 0, the comparator
     rotations = j["value"] * j["ms_per_step"] / 1e3
-    assert 8 * 1683 - 1 <= rotations <= 8 * 1683 + 1000, rotations
+    assert 8 * 1683 - 1 <= rotations <= 8 * 1683 + 1000 + 200 * world, rotations
     # ... and the same line carries the weak-scaling leg: every rank's own 8 independent matches through
     # peba1_identify, the match bits gathered to rank 0 and checked there (one 0 among 16: the genuine template)
     w = j["weak_scaling"]
-    assert w["n_gpus"] == 2 and w["matches_per_gpu"] == 8 and w["scaling"] == "weak"
-    per_match = w["gates_per_s_all_ranks"] * w["seconds"] / 16
+    assert w["n_gpus"] == world and w["matches_per_gpu"] == 8 and w["scaling"] == "weak"
+    per_match = w["gates_per_s_all_ranks"] * w["seconds"] / (8 * world)
     assert 8 * 1683 <= per_match <= 8 * 1683 + 400, per_match
     # the same match once more with SURVEY 8(e)'s combine on rank 0 (ripple-adder tree + bit-serial comparator)
     r = j["reference_order_combine"]
-    assert r["match_ms"] > 0 and 8 * 1683 <= r["blind_rotates_all_ranks"] <= 8 * 1683 + 1000
+    assert r["match_ms"] > 0 and 8 * 1683 <= r["blind_rotates_all_ranks"] <= 8 * 1683 + 1000 + 500 * world
     # who took part: two ranks, each naming the device libtfhe-hip ran on; on the one GPU of a test box
     # both name the same bus id and the line says so
     d = j["dist"]
-    assert d["world"] == 2 and len(d["devices"]) == 2 and all(d["devices"]) and d["library_transport"] == "host" and transport in d["transport"]
+    assert d["world"] == world and len(d["devices"]) == world and all(d["devices"]) and d["library_transport"] == "host" and transport in d["transport"]
     assert d["distinct_devices"] == 1 and d["one_gpu_per_rank"] is False
-    assert d["status_word_collectives"] >= 3 and d["data_collectives"]["gathers"] >= 3       # 1 step + reference leg + match bits
-    assert [e["rank"] for e in d["ranks"]] == [0, 1] and d["ranks"][0]["pid"] != d["ranks"][1]["pid"]
+    # exactly the collectives the run is made of (--steps 1 --warmup 0): the timed step's gather of the partial sums, the
+    # weak leg's broadcast of the probe and gather of the match bits, the reference-order leg's gather; over the host
+    # transport a status word rides in front of every payload
+    assert d["data_collectives"] == {"gathers": 3, "broadcasts": 1} and d["status_word_collectives"] == 4
+    # ... issued in the same order on every rank (peba1_dist_sequence: count + rolling hash of kind / size / root)
+    assert d["collectives_issued_rank0"] == 4 and d["same_issue_order_on_every_rank"] is True
+    assert len({e["collectives"]["issue_order_hash"] for e in d["ranks"]}) == 1
+    assert [e["rank"] for e in d["ranks"]] == list(range(world)) and len({e["pid"] for e in d["ranks"]}) == world
     return j
 
 
@@ -434,18 +440,51 @@ def test_bench_fallback_transport_moves_the_same_ciphertexts():
 
 
 def test_bench_launches_its_own_ranks_when_called_without_a_launcher():
-    """`python bench.py --gpus 2` with no WORLD_SIZE in the environment -- how the driver calls it at
-    N = 1 -- must produce the N = 2 line by itself: the parent starts one fresh process per rank (it never touches the GPU),
-    relays rank 0's JSON line as its own last stdout line and exits 0.  What the ranks then run is what the driver's
-    `torch.distributed.run ... bench.py --gpus N` runs at N > 1 -- mode auto = sharded: slots partitioned over the ranks,
-    one gather, rank 0 combines, barrier + max-over-ranks timing, one JSON line from rank 0 -- rehearsed with two
-    processes on one GPU (--backend gloo), 8 slots.  A rehearsal of the code path, not a measurement."""
+    """`python bench.py --gpus 4` with no WORLD_SIZE in the environment -- how the driver
+    calls it at N = 1 -- must produce the N = 4 line by itself: the parent starts one fresh process per rank (it never
+    touches the GPU), relays rank 0's JSON line as its own last stdout line and exits 0.  What the ranks then run is what
+    the driver's `torch.distributed.run ... bench.py --gpus N` runs at N > 1 -- mode auto = sharded: slots partitioned over
+    the ranks, one gather, rank 0 combines, barrier + max-over-ranks timing, one JSON line from rank 0 -- rehearsed with
+    FOUR processes on one GPU (--backend gloo), 8 slots: world 4, the exact collective counts, the same issue order on
+    every rank.  A rehearsal of the code path, not a measurement."""
     import subprocess
     import sys
     env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
     env["PEBA1_ROOT"] = ROOT
-    out = subprocess.run([sys.executable, "bench.py", "--gpus", "2", "--backend", "gloo", "--steps", "1", "--warmup", "0",
+    out = subprocess.run([sys.executable, "bench.py", "--gpus", "4", "--backend", "gloo", "--steps", "1", "--warmup", "0",
                           "--slots", "8", "--no-cpu-baseline"], env=env, capture_output=True, text=True, timeout=400, cwd=ROOT)
-    j = _check_rehearsal_line(out)
+    j = _check_rehearsal_line(out, world=4)
     assert out.stdout.rstrip().splitlines()[-1].startswith("{")           # the line is the LAST thing on stdout
     assert j["dist"]["torch_backend"] == "gloo"
+
+
+@pytest.mark.parametrize("hang", [False, True])
+def test_bench_tries_its_own_communicator_in_a_child_process_first(hang):
+    """before a rank makes libpeba1-dist's own RCCL communicator, the same communicator and one one-sample gather
+    are tried in a child process per rank; only if every rank's child reports success does the rank itself enter
+    ncclCommInitRank.  World 1 over RCCL on the one GPU (`--force-dist`).  hang = False: the child succeeds, the library's
+    own communicator carries the exchange and its status words travel on a communicator of their own (ncclCommSplit).
+    hang = True: the child never comes back (test hook), is killed at its budget, and the run still produces its line over
+    the fallback transport, saying why."""
+    import json
+    import subprocess
+    import sys
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env.update(MASTER_PORT="29671", PEBA1_BENCH_TRIAL_BUDGET_S="12" if hang else "150")
+    if hang:
+        env["PEBA1_BENCH_TRIAL_HANG"] = "1"
+    out = subprocess.run([sys.executable, "bench.py", "--mode", "sharded", "--force-dist", "--steps", "1", "--warmup", "0", "--slots", "8",
+                          "--no-cpu-baseline"], env=env, capture_output=True, text=True, timeout=400, cwd=ROOT)
+    assert out.returncode == 0, out.stdout[-1500:] + out.stderr[-3000:]
+    j = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][-1])
+    d = j["dist"]
+    assert d["world"] == 1 and d["backend"] == "rccl" and d["rccl_version"] > 0 and d["same_issue_order_on_every_rank"] is True
+    if hang:
+        assert "torch.distributed device tensors" in d["transport"] and d["library_transport"] == "host"
+        assert "did not finish within 12 s" in d["transport_fallback_reason"]
+        assert "falling back to torch's" in out.stderr
+    else:
+        assert d["transport"].startswith("rccl: libpeba1-dist's own communicator") and d["library_transport"] == "rccl"
+        assert d["transport_fallback_reason"] is None
+        assert d["status_channel"] == "own communicator (ncclCommSplit), own stream"
+        assert d["data_collectives"] == {"gathers": 3, "broadcasts": 1} and d["status_word_collectives"] == 4

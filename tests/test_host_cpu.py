@@ -296,7 +296,7 @@ def kernels_isa(tmp_path_factory):
 
 
 def test_counted_lds_waits_see_no_scalar_memory_load(kernels_isa):
-    """The pipelined key switch waits with s_waitcnt lgkmcnt(12 / 8 / 4): "all but the last N" -- sound only while everything
+    """The LDS-strip key switch (keyswitch_strip_kernel) waits with s_waitcnt lgkmcnt(12 / 8 / 4): "all but the last N" -- sound only while everything
     counted by lgkmcnt in that loop completes in order, i.e. is an LDS operation.  Scalar memory loads share the counter and
     return out of order: one inside the loop would let a wait pass before its rows have arrived.  The loop is compiler
     output, so the invariant is checked on the ISA of every build: no s_load / s_buffer_load in a basic block that holds a
@@ -305,7 +305,7 @@ def test_counted_lds_waits_see_no_scalar_memory_load(kernels_isa):
     kernel, block, checked = None, [], 0
     def flush():
         nonlocal checked
-        if kernel and "keyswitch_tile_kernel" in kernel and any(re.search(r"lgkmcnt\((4|8|12)\)", i) for i in block):
+        if kernel and "keyswitch_strip_kernel" in kernel and any(re.search(r"lgkmcnt\((4|8|12)\)", i) for i in block):
             bad = [i for i in block if i.startswith(("s_load", "s_buffer_load", "s_sendmsg", "s_memtime", "s_memrealtime"))]
             assert not bad, (kernel, bad[:3])
             checked += 1
@@ -321,7 +321,7 @@ def test_counted_lds_waits_see_no_scalar_memory_load(kernels_isa):
         if t and not t.startswith((";", ".", "//")):
             block.append(t)
     flush()
-    assert checked >= 6            # three row widths x (plain, in place) of the pipelined form
+    assert checked >= 3            # three row widths of the LDS-strip form
 
 
 def test_index_keyswitch_statements_are_current_and_fit_their_registers(kernels_isa):
@@ -373,7 +373,7 @@ def test_isa_mix_summary_is_what_the_built_kernels_give(kernels_isa, tmp_path):
     """profiles/isa_mix.json (the static VALU instruction mix of one blind-rotate step, which bench.py prices into
     `roofline.valu_issue`) is what tools/isa_mix.py finds in the assembly of THIS build, under the hash of everything the
     kernels are built from; and the step of the headline kernel is the one the SQ counters measured (1,719 VALU
-    instructions per wave and step, profiles/r04_set_profile_P128.json: the static count of the feasible path must be
+    instructions per wave and step, profiles/archive/r04_set_profile_P128.json: the static count of the feasible path must be
     within a few instructions of any such measurement, whichever round it is from)."""
     import importlib.util
     import json
@@ -388,7 +388,7 @@ def test_isa_mix_summary_is_what_the_built_kernels_give(kernels_isa, tmp_path):
     for needle, (report, _what, _roles) in mix.KERNELS.items():
         now = mix.analyse(lines, needle, 2 if report.endswith("false>") else 3)
         assert json.loads(json.dumps(now)) == committed["kernels"][report], report
-    head = committed["kernels"]["blind_rotate4_kernel<10,0,true>"]["roles"]
+    head = committed["kernels"]["blind_rotate4_kernel<10,true>"]["roles"]
     assert len(head) == 1 and len(head[0]["variants"]) == 1          # q = 0 and q = 1 run the same counts
     v = head[0]["variants"][0]
     assert v["barriers"] == 3 and v["mul"] + v["three_operand"] + v["two_operand"] == v["valu"]
@@ -397,11 +397,17 @@ def test_isa_mix_summary_is_what_the_built_kernels_give(kernels_isa, tmp_path):
     assert a["valu"] - b["valu"] == pytest.approx(380, abs=40)      # wave A transforms one gadget row more than wave B at l = 3
     # the hash covers the generated key-switch statements, the form table and the flags
     assert {"ks_index_asm.inc", "kernels.hpp", "br_forms.hpp", "build.sh"} <= set(KERNEL_FILES)
-    import bench
-    assert bench.kernel_source_hash() == kernels_sha16()
-    blk = bench.valu_issue_block({"P128": {"ms_blind_rotate": 36.77, "shader_clock_ghz": 2.369}}, None)
+    from benchkit import roofline
+    assert roofline.kernel_source_hash() == kernels_sha16()
+    blk = roofline.valu_issue_block({"P128": {"ms_blind_rotate": 36.77, "shader_clock_ghz": 2.369}}, None)
     assert blk["kernels_sha16"] == kernels_sha16() and 0.8 < blk["frac"] < 1.0          # round-4 launch time: ~0.88
     assert blk["model_cycles_per_simd_step"] == pytest.approx(2 * (v["mul"] * 5.4 + v["three_operand"] * 5.2 + v["two_operand"] * 3.0))
+    # the same mix at the chip's best issue rates (8 waves per SIMD): a ceiling that does not concede the kernel's occupancy
+    assert blk["chip_peak_cycles_per_simd_step"] == pytest.approx(2 * (v["mul"] * 4.63 + v["three_operand"] * 4.41 + v["two_operand"] * 2.86))
+    assert blk["frac_vs_chip_peak"] < blk["frac"]
+    # N > 1: the 8-wave kernel dominates and its own launches of the timed steps are the measured side
+    nar = roofline.valu_issue_block(None, None, {"ms": 2.75 * 300, "launches": 300, "shader_clock_ghz": 2.37})
+    assert nar["kernel"] == "blind_rotate8_kernel<10,true>" and 0.7 < nar["frac"] < 0.9 and nar["frac_vs_chip_peak"] < nar["frac"]
 
 
 def test_kernel_id_hashes_every_file_the_kernels_are_built_from():

@@ -1,11 +1,11 @@
 #!/bin/bash
-# Round 5 A/B on ONE box, variants interleaved (tools/diag/build_variants.sh builds the variant libraries first):
-#   gpurun --timeout 1200 -- 'bash tools/diag/r5_ab.sh <tag> "default pair" [sizes P128] [p80 p2048]'
+# A/B on ONE box, variants interleaved (tools/diag/build_variants.sh builds the variant libraries first):
+#   gpurun --timeout 1200 -- 'bash tools/diag/ab.sh <tag> "default pair" [sizes P128] [p80 p2048]'
 # PARITY_VARS="a b" limits the parity runs to those variants (priority-only variants compute the same integers by construction).
 # Per variant first a short parity run THROUGH that library (a measurement build that computes wrong words is not timed),
 # each under its own timeout; then the launch times of independent gates, three rounds, variants alternating.
 set -o pipefail
-TAG=${1:-r05ab}; VARS=${2:-"default"}; SIZES=${3:-"1 256 512 4096 4096"}; SETS=${4:-""}
+TAG=${1:-ab}; VARS=${2:-"default"}; SIZES=${3:-"1 256 512 4096 4096"}; SETS=${4:-""}
 OUT=gpurun_out/$TAG; mkdir -p $OUT
 export TMPDIR=/tmp
 AB=$PWD/tools/diag/_ab

@@ -39,9 +39,9 @@ THREE = ("v_add3_u32", "v_bfe_i32", "v_bfe_u32", "v_lshl_add_u32", "v_lshl_add_u
 # one workgroup per CU, a SIMD holds wave A = (q, u, rows 0..l-2) and wave B = (q, u, last row) of one rotation; split
 # form at N = 2048: one workgroup per CU, a SIMD holds the two half-transform waves (q, u, h) of one rotation.
 KERNELS = {
-    "blind_rotate4_kernelILi10ELi0ELb1E": ("blind_rotate4_kernel<10,0,true>", "4-wave form, digit tables (P128: the headline)",
+    "blind_rotate4_kernelILi10ELb1E": ("blind_rotate4_kernel<10,true>", "4-wave form, digit tables (P128: the headline)",
                                            [("wave", lambda l: l, 2)]),
-    "blind_rotate4_kernelILi10ELi0ELb0E": ("blind_rotate4_kernel<10,0,false>", "4-wave form, no digit table (P80)",
+    "blind_rotate4_kernelILi10ELb0E": ("blind_rotate4_kernel<10,false>", "4-wave form, no digit table (P80)",
                                            [("wave", lambda l: l, 2)]),
     "blind_rotate8_kernelILi10ELb1E": ("blind_rotate8_kernel<10,true>", "8-wave latency form (narrow launches)",
                                        [("A", lambda l: l - 1, 1), ("B", lambda l: 1, 1)]),

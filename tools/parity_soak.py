@@ -61,35 +61,25 @@ for pname, make, cnt in (("P128", lambda: api.ParameterSet(128), count), ("P80",
             api.set_tuning(k, v)
     if not ks_only:
         print(f"{pname}: oracle {t_cpu:.1f} s on {threads} threads ({cnt / t_cpu:.0f} rotations/s)", flush=True)
-    # key switch of the same number of uniformly random extracted samples: tiled (tiles of 16 and 32), per-gate,
-    # and both again accumulating in place
+    # key switch of the same number of uniformly random extracted samples: index form (tiles of 16, 24, 32), LDS-strip
+    # form, per-gate form
     u = rng.integers(-2**31, 2**31, (cnt, pp.k * pp.N + 1), dtype=np.int64).astype(np.int32)
     t0 = time.time()
     with ThreadPoolExecutor(threads) as ex:
         want_ks = np.stack(list(ex.map(oks.keyswitch, u)))
     t_cpu = time.time() - t0
     try:
-        # (tile, words-per-thread switch, pipelined strip reads, register form: 0 = LDS strips, 1 = scalar branches, 2 = index mode)
-        for tile, narrow, pipe, branch in ((16, 0, 0, 2), (24, 0, 0, 2), (32, 0, 0, 2), (16, 0, 0, 1), (32, 0, 0, 1),
-                                           (16, 0, 1, 0), (16, 0, 0, 0), (16, 1, 0, 0), (32, 1, 0, 0), (32, 0, 0, 0), (0, 0, 0, 0)):
-            for atomic in ((0,) if branch else (0, 1)):
-                api.set_tuning("ks_tile", tile)
-                api.set_tuning("ks_narrow", narrow)
-                api.set_tuning("ks_pipe", pipe)
-                api.set_tuning("ks_branch", branch)
-                api.set_tuning("ks_atomic", atomic)
-                got = api.kernel_keyswitch(ks, u)
-                bad = int((got != want_ks).any(axis=1).sum())
-                print(f"{pname}: {cnt} random key switches, tile {tile}, {2 if narrow else 4} words per thread, pipe {pipe}, register form {branch}, "
-                      f"in place {atomic}: {bad} differ from the oracle", flush=True)
-                assert bad == 0, (pname, tile, narrow, branch, atomic)
-                total_ks += cnt
+        for tile, index in ((16, 1), (24, 1), (32, 1), (16, 0), (0, 1)):
+            api.set_tuning("ks_tile", tile)
+            api.set_tuning("ks_index", index)
+            got = api.kernel_keyswitch(ks, u)
+            bad = int((got != want_ks).any(axis=1).sum())
+            print(f"{pname}: {cnt} random key switches, tile {tile}, {'index' if index else 'LDS-strip'} form: {bad} differ from the oracle", flush=True)
+            assert bad == 0, (pname, tile, index)
+            total_ks += cnt
     finally:
         api.set_tuning("ks_tile", 16)
-        api.set_tuning("ks_narrow", 0)
-        api.set_tuning("ks_pipe", 1)
-        api.set_tuning("ks_branch", 2)
-        api.set_tuning("ks_atomic", 0)
+        api.set_tuning("ks_index", 1)
     print(f"{pname}: oracle key switches {t_cpu:.1f} s on {threads} threads", flush=True)
     ks.close()
 print(f"OK: {total} rotation results and {total_ks} key-switch results equal the oracle's, word for word")
