@@ -31,8 +31,14 @@ rotations (a MUX is two) of ALL ranks per second of the slowest rank.
     python bench.py --gpus N ...            starts its own N ranks (a child `torch.distributed.run`; the parent never
                                             touches the GPU) and relays rank 0's line
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...      the same, launched by hand
-The N > 1 line carries `dist` (who took part: RCCL version, every rank's PCI bus id, the collectives run, the transport)
-and `roofline.valu_issue` (the roofline that binds, from profiles/isa_mix.json and profiles/valu_issue_costs.json).
+Every line carries `roofline.valu_issue` (the roofline that binds, from profiles/isa_mix.json and
+profiles/valu_issue_costs.json: `frac` at the kernel's own occupancy, `frac_vs_chip_peak` at the chip's best issue rates; at
+N > 1 for the 8-wave kernel that dominates there); the N > 1 line also `dist` (who took part: RCCL version, every rank's PCI
+bus id, the collectives run and their issue order, the transport and why).
+
+This file: argument parsing, the timed region, the CPU baseline, the JSON line.  benchkit/: the roofline models and committed
+counter summaries (roofline.py), the launcher, the transport negotiation and the evidence (launch.py), the untimed extra
+workloads of the single-GPU line (extras.py) -- nothing in there runs inside the timed region.
 """
 import argparse
 import ctypes

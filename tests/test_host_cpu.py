@@ -163,6 +163,65 @@ def test_product_key_derivation_equals_oracle(oracle, oks, golden):
     ks.close()
 
 
+def test_key_material_has_the_tgsw_and_key_switch_semantics_independently(oracle, oks, golden):
+    """the product's key derivation and the oracle's are one specification written twice by one hand, so
+    their equality (above) is self-consistency.  This is the independent statement: from the DEFINITION of the objects
+    (SURVEY Appendix A), in numpy, sharing no code or loop structure with either -- every bootstrapping-key row is a TLWE
+    sample whose phase is noise plus the gadget term (row (bloc, j) of TGSW(s_i): s_i / Bg^(j+1) on the body for bloc = k, and
+    on mask component bloc otherwise, where it shows in the phase as -(s_i / Bg^(j+1)) * S_bloc(X)); every key-switch row
+    (i, j, v) is an LWE sample of v * S_i / base^(j+1).  A wrong gadget position, sign, digit order or KSK message would
+    pass the equality test and fail here.  Run on the product's keys and on the oracle's."""
+    from peba1_amd import api
+    pp = api.ParameterSet(128)
+    ks = api.SecretKeySet(pp, golden["key_seed"], device=False)
+    n, N, k, l, Bgbit, t, bb = pp.n, pp.N, pp.k, pp.l, pp.Bgbit, pp.ks_t, pp.ks_basebit
+    kpl, base = (k + 1) * l, 1 << bb
+    try:
+        for who, lwe, tlwe, bk, ksk in (("product", ks.lwe_key(), ks.tlwe_key(), ks.bk(), ks.ksk()),
+                                        ("oracle", oks.lwe_key(), oks.tlwe_key(), oks.bk(), oks.ksk())):
+            s = np.asarray(lwe, dtype=np.int64)
+            S = np.asarray(tlwe, dtype=np.int64).reshape(k, N)
+            assert set(np.unique(s)) <= {0, 1} and set(np.unique(S)) <= {0, 1} and 0.4 < s.mean() < 0.6 and 0.4 < S.mean() < 0.6
+
+            def negacyclic(a, b):                       # a * b mod (X^N + 1), exact in int64 (|a| < 2^32, b binary)
+                full = np.convolve(a, b)
+                return full[:N] - np.concatenate([full[N:], [0]])
+
+            def centred(x):                             # Torus32 difference as a signed integer
+                return ((x + (1 << 31)) % (1 << 32)) - (1 << 31)
+
+            rows = np.asarray(bk, dtype=np.int64).reshape(n, kpl, k + 1, N) % (1 << 32)
+            worst = 0
+            for i in range(0, n, 9):                    # 70 of the 630 TGSW samples, all 6 rows of each
+                for row in range(kpl):
+                    bloc, j = divmod(row, l)
+                    phase = rows[i, row, k].copy()
+                    for u in range(k):
+                        phase -= negacyclic(rows[i, row, u], S[u])
+                    g = int(s[i]) << (32 - (j + 1) * Bgbit)
+                    if bloc == k:
+                        phase[0] -= g                   # the message sits on the body
+                    else:
+                        phase += g * S[bloc]            # ... or on mask component bloc: -g * S_bloc(X) in the phase
+                    worst = max(worst, int(np.abs(centred(phase)).max()))
+            sigma = pp.bk_stdev * 2.0 ** 32 if hasattr(pp, "bk_stdev") else 2.0 ** 7
+            assert worst < 8 * sigma, (who, "bootstrapping-key rows are not TGSW(s_i) under the TLWE key", worst, sigma)
+
+            K = np.asarray(ksk, dtype=np.int64).reshape(k * N, t, base, n + 1) % (1 << 32)
+            assert not K[:, :, 0, :].any()              # digit 0 subtracts nothing
+            Sf = S.reshape(-1)
+            idx = np.arange(0, k * N, 37)
+            ph = K[idx][:, :, 1:, n] - (K[idx][:, :, 1:, :n] * s).sum(axis=-1)          # [i][j][v-1]
+            jj = np.arange(t).reshape(1, t, 1)
+            vv = np.arange(1, base).reshape(1, 1, base - 1)
+            want = (Sf[idx].reshape(-1, 1, 1) * vv) << (32 - (jj + 1) * bb)
+            err = np.abs(centred(ph - want))
+            assert err.max() < 8 * 2.0 ** 17, (who, "key-switch rows are not LWE(v * S_i / base^(j+1))", int(err.max()))
+            assert err.std() > 2.0 ** 14                # ... with real noise of about 2^-15 on them
+    finally:
+        ks.close()
+
+
 def test_product_parameter_sets(oracle):
     from peba1_amd import api
     p80 = api.ParameterSet(80)

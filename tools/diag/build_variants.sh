@@ -1,6 +1,6 @@
 #!/bin/bash
 # Builds libtfhe-hip variants that differ in compile-time switches of the kernels, for A/B runs on one box:
-#   tools/diag/build_variants.sh name1="-DBR_TAB_PAIRS=0" name2="-DBR_INV_LAYOUT_H=0" ...
+#   tools/diag/build_variants.sh tg2="-DBR_TAB_GROUPS=2" stamps="-DTFHE_HIP_STAMPS" ...
 # -> tools/diag/_ab/libtfhe-hip-<name>.so (git-ignored; travels to the GPU box).  Select with PEBA1_TFHE_HIP_LIB.
 # Host objects come from the default build (run peba1_amd/csrc/build.sh first).
 set -euo pipefail

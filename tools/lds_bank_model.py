@@ -20,7 +20,7 @@ N = 1024, per transform:
 
 No single padded layout makes all four classes conflict-free within the LDS the default form has left (search:
 tools/diag/lds_layout_search.py); the digit tables are a different matter (data-dependent addresses: ~2.7 extra
-cycles per access whatever the layout) and were cut by reading two rows per access (ntt_wave.hpp BR_TAB_PAIRS).
+cycles per access whatever the layout) and were cut by reading two rows per access (the 8-byte table entries of ntt_wave.hpp).
 
 usage: lds_bank_model.py            (asserts the properties the kernels rely on; exit code 0 = all hold)"""
 import sys

@@ -24,8 +24,8 @@ def kernel_source_hash():
     from peba1_amd.kernel_id import kernels_sha16
     return kernels_sha16()
 
-WIDE_STREAM = ("blind_rotate_kernel", "blind_rotate4_kernel", "blind_rotate8_kernel", "keyswitch_kernel", "keyswitch_tile_kernel",
-               "keyswitch_branch_kernel", "keyswitch_index_kernel")
+WIDE_STREAM = ("blind_rotate2_kernel", "blind_rotate4_kernel", "blind_rotate8_kernel", "blind_rotate_split_kernel", "keyswitch_kernel",
+               "keyswitch_strip_kernel", "keyswitch_index_kernel")
 
 
 def short(name):
@@ -58,7 +58,7 @@ def main():
         f = f_raw * (2.0 if k in WIDE_STREAM else 1.0)
         out["kernels"][k] = {"launches": n, "fetch_bytes_raw": f_raw, "fetch_bytes_corrected": f, "write_bytes": w,
                              "hbm_bytes_per_launch": (f + w) / max(1, n)}
-    br = [out["kernels"][k] for k in ("blind_rotate_kernel", "blind_rotate4_kernel") if k in out["kernels"]]
+    br = [out["kernels"][k] for k in ("blind_rotate4_kernel",) if k in out["kernels"]]
     n = sum(b["launches"] for b in br)
     out["blind_rotate_launches"] = n
     out["hbm_bytes_per_launch"] = sum(b["fetch_bytes_corrected"] + b["write_bytes"] for b in br) / max(1, n)
