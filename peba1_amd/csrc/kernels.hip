@@ -797,8 +797,8 @@ __global__ __launch_bounds__(512, 2) void blind_rotate8_kernel(
 // the recombination and the accumulator update need one exchange, three workgroup barriers per step
 // as in the 4-wave form.
 // What it buys: at N = 2048 a wave holds 16 coefficients per lane instead of 32, both row sums stay in
-// 64 bits and two waves per SIMD fit (the 4-wave form runs lean there); at N = 1024, 8 coefficients
-// per lane and four waves per SIMD.  What it costs: stage 0 is outside the radix-4 pairing (digits:
+// 64 bits and two waves per SIMD fit (a 4-wave form fitted N = 2048 only with both sums reduced per row and was 38 %
+// slower: removed in round 6); at N = 1024, 8 coefficients per lane and four waves per SIMD.  What it costs: stage 0 is outside the radix-4 pairing (digits:
 // one table read and one addition per coefficient and gadget row), D is computed by both halves,
 // 8 waves meet at each barrier.  Same integers as the other forms.
 // ---------------------------------------------------------------------------
