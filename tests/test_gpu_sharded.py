@@ -400,6 +400,11 @@ def _check_rehearsal_line(out, transport="gloo", world=2):
     j = json.loads(lines[-1])
     assert j["n_gpus"] == world and j["scaling"] == "strong" and j["config"]["mode"] == "sharded"
     assert j["value"] > 0 and j["roofline"]["frac"] > 0
+    # a rank's share of 8 slots is narrow levels only: the 8-wave kernel dominates, and the binding roofline in the line is
+    # THAT kernel's, measured on its launches of the timed step
+    vi = j["roofline"]["valu_issue"]
+    assert j["roofline"]["kernel"] == "blind_rotate8_kernel" and vi["kernel"] == "blind_rotate8_kernel<10,true>"
+    assert vi["measured_cycles_per_simd_step"] > vi["chip_peak_cycles_per_simd_step"] > 0 and 0 < vi["frac_vs_chip_peak"] < vi["frac"] < 1
     # all ranks' rotations are counted: 8 slots of the reference's loop, one adder on rank 0, the comparator
     rotations = j["value"] * j["ms_per_step"] / 1e3
     assert 8 * 1683 - 1 <= rotations <= 8 * 1683 + 1000 + 200 * world, rotations
