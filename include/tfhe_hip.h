@@ -217,7 +217,7 @@ void tfhe_hip_set_kernel_timing(int on);
  * admissible form (peba1_amd/csrc/br_forms.hpp).  Returns 1 or 0. ---- */
 int tfhe_hip_test_form_admissible(int form, int32_t N, int32_t l, int32_t Bgbit, int tables);
 
-/* ---- test entry: device allocations of the ciphertext slot pool and of the per-flush scratch that would bring their total
+/* ---- test entry: device allocations of key images, the ciphertext slot pool and the per-flush scratch that would bring their total
  * above `bytes` fail as if the card were full (0 = no cap).  Running out of device memory there is RECOVERABLE: the call
  * that needed the memory has no effect (recorded gates stay recorded, tfhe_hip_flush returns -1), tfhe_hip_last_error()
  * says what could not be allocated, and the caller may free ciphertext arrays and carry on. ---- */

@@ -39,7 +39,8 @@ void hip_check(hipError_t e, const char *what) {
     if (e != hipSuccess) fatal(std::string(what) + ": " + hipGetErrorString(e));
 }
 
-// Device memory whose exhaustion is RECOVERABLE: the slot pool's growth and the per-flush scratch.
+// Device memory whose exhaustion is RECOVERABLE: the slot pool's growth, the per-flush scratch and
+// the device image of a key (a server holds one per enrolled client's key set).
 // A library living inside a matching server must not abort() because one request recorded more than the card holds:
 // hipErrorOutOfMemory becomes an ApiError -- the call that needed the memory has no effect (the gates recorded so far
 // stay recorded; a flush returns -1), tfhe_hip_last_error() says what could not be allocated, and the caller may free
@@ -54,8 +55,8 @@ static void *recoverable_alloc(size_t bytes, const char *what) {
     if (e == hipErrorOutOfMemory) {
         (void)hipGetLastError();                 // the sticky error of the failed call must not fail the next launch check
         api_fail(std::string("out of device memory: ") + what + " needs " + std::to_string(bytes >> 20) + " MiB more (" +
-                 std::to_string(g_alloc_total >> 20) + " MiB held by the slot pool and the flush scratch); the call had no "
-                 "effect -- free ciphertext arrays, flush less at a time, or lower TFHE_HIP_POOL_SLOTS");
+                 std::to_string(g_alloc_total >> 20) + " MiB held by key images, the slot pool and the flush scratch); the call "
+                 "had no effect -- free ciphertext arrays or key sets, flush less at a time, or lower TFHE_HIP_POOL_SLOTS");
     }
     hip_check(e, what);
     g_alloc_total += (long long)bytes;
@@ -399,29 +400,42 @@ DeviceKeyImage *Engine::upload_key(const TfheHipCloudKey &ck) {
         for (int t = 0; t < 3; ++t) img->form_ok[f][t] = br_form_admissible(f, p.N, p.l, p.Bgbit, t);
     uint32_t scale[2];
     const std::vector<uint32_t> tw = make_twiddles(p.N, scale);
-    hip_check(hipMalloc(reinterpret_cast<void **>(&img->tw), tw.size() * 4), "hipMalloc(tw)");
+    const size_t bk_words = p.bk_words();
+    const int base = 1 << p.ks_basebit, stride = p.ct_stride();
+    const size_t rows = (size_t)p.k * p.N * p.ks_t;
+    int32_t *raw = nullptr;
+    try {
+        // every buffer first (a card without room for them fails here, recoverably: the keyset is not made and
+        // tfhe_hip_last_error() says what was needed), then the uploads and the transform
+        img->tw_bytes = tw.size() * 4;
+        img->tw = static_cast<uint32_t *>(recoverable_alloc(img->tw_bytes, "the twiddle tables of a key"));
+        img->bk_img_bytes = bk_words * 2 * 4;
+        img->bk_img = static_cast<uint32_t *>(recoverable_alloc(img->bk_img_bytes, "the bootstrapping-key image"));
+        img->ksk_bytes = (rows * (base - 1) + 1) * (size_t)stride * 4;
+        img->ksk = static_cast<int32_t *>(recoverable_alloc(img->ksk_bytes, "the key-switching key"));
+        raw = static_cast<int32_t *>(recoverable_alloc(bk_words * 4, "the staging copy of the bootstrapping key"));
+    } catch (const ApiError &) {
+        recoverable_free(img->tw, img->tw_bytes);
+        recoverable_free(img->bk_img, img->bk_img_bytes);
+        recoverable_free(img->ksk, img->ksk_bytes);
+        delete img;
+        throw;
+    }
     hip_check(hipMemcpy(img->tw, tw.data(), tw.size() * 4, hipMemcpyHostToDevice), "upload twiddles");
 
     // BK: upload raw, transform on device
-    const size_t bk_words = p.bk_words();
-    int32_t *raw = nullptr;
-    hip_check(hipMalloc(reinterpret_cast<void **>(&raw), bk_words * 4), "hipMalloc(raw bk)");
     hip_check(hipMemcpy(raw, ck.bk.data(), bk_words * 4, hipMemcpyHostToDevice), "upload bk");
-    hip_check(hipMalloc(reinterpret_cast<void **>(&img->bk_img), bk_words * 2 * 4), "hipMalloc(bk image)");
     launch_bk_transform(stream_, img->dp, raw, img->bk_img, img->tw, p.n * p.kpl(), p.k + 1, scale);
     hip_check(hipGetLastError(), "bk_transform launch");
     sync_stream("bk_transform");
-    (void)hipFree(raw);
+    recoverable_free(raw, bk_words * 4);
 
     // KSK: drop the all-zero digit-0 rows, pad rows to ct_stride
-    const int base = 1 << p.ks_basebit, stride = p.ct_stride();
-    const size_t rows = (size_t)p.k * p.N * p.ks_t;
     std::vector<int32_t> compact((rows * (base - 1) + 1) * stride, 0);   // + one row of zeros (digit 0)
     for (size_t r = 0; r < rows; ++r)
         for (int v = 1; v < base; ++v)
             std::memcpy(&compact[(r * (base - 1) + (v - 1)) * stride], &ck.ksk[(r * base + v) * (size_t)(p.n + 1)],
                         (size_t)(p.n + 1) * 4);
-    hip_check(hipMalloc(reinterpret_cast<void **>(&img->ksk), compact.size() * 4), "hipMalloc(ksk)");
     hip_check(hipMemcpy(img->ksk, compact.data(), compact.size() * 4, hipMemcpyHostToDevice), "upload ksk");
 
     img->key.bk_img = img->bk_img;
@@ -435,9 +449,9 @@ void Engine::free_key(DeviceKeyImage *img) {
     ENGINE_DEVICE_SCOPE();
     if (!img) return;
     if (inited_) sync_stream("sync before key free");
-    if (img->bk_img) (void)hipFree(img->bk_img);
-    if (img->ksk) (void)hipFree(img->ksk);
-    if (img->tw) (void)hipFree(img->tw);
+    recoverable_free(img->bk_img, img->bk_img_bytes);
+    recoverable_free(img->ksk, img->ksk_bytes);
+    recoverable_free(img->tw, img->tw_bytes);
     delete img;
 }
 

@@ -23,6 +23,7 @@ struct DeviceKeyImage {
     uint32_t *bk_img = nullptr;
     int32_t *ksk = nullptr;
     uint32_t *tw = nullptr;
+    size_t bk_img_bytes = 0, ksk_bytes = 0, tw_bytes = 0;        // what the three hold (recoverable_alloc's accounting)
 };
 
 namespace tfhe_hip {

@@ -182,6 +182,15 @@ import numpy as np
 from peba1_amd import api, lib
 L = lib.load()
 pp = api.ParameterSet(128)
+# (0) the device image of a key (118 MiB at P128): with no room for it the keyset is not made, the reason is reported, and the
+# same call works once there is room
+L.tfhe_hip_test_set_alloc_cap(1 << 20)
+try:
+    api.SecretKeySet(pp, 7, device=True)
+    raise SystemExit("a key image was uploaded past the cap")
+except RuntimeError as e:
+    assert "out of device memory" in str(e) and "key" in str(e), str(e)
+L.tfhe_hip_test_set_alloc_cap(0)
 ks = api.SecretKeySet(pp, 7, device=True)
 L.tfhe_hip_set_encrypt_seed(5)
 G = 5000
@@ -236,8 +245,8 @@ print("OOM-OK", refused[0])
 
 
 def test_device_memory_exhaustion_is_recoverable():
-    """hipErrorOutOfMemory while sizing a flush's scratch or growing the slot pool (here: an artificial
-    cap, tfhe_hip_test_set_alloc_cap) does not abort the host: the flush returns -1 / the gate call has no effect,
+    """hipErrorOutOfMemory while uploading a key image, sizing a flush's scratch or growing the slot pool
+    (here: an artificial cap, tfhe_hip_test_set_alloc_cap) does not abort the host: the keyset is not made / the flush returns -1 / the gate call has no effect,
     tfhe_hip_last_error() names what could not be allocated, the recorded gates stay recorded and evaluate once memory
     is there."""
     out = subprocess.run([sys.executable, "-c", OOM_WORKER % ROOT], capture_output=True, text=True, timeout=600)
