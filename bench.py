@@ -472,7 +472,7 @@ def main():
                          "launches": int(dn), "avg_launch_ms": dms / max(1, dn), "rotations_per_launch": drot / max(1, dn),
                          # shader clock of the timed blind-rotate launches: cycles / 100 MHz reference ticks of every 61st workgroup
                          # of every launch (the same launch is ~15 % slower at the ~2.0 GHz of a cold or power-limited
-                         # chip than at ~2.37 GHz; DESIGN.md section 5) -- explains run-to-run and box-to-box differences
+                         # chip than at ~2.37 GHz; DESIGN.md section 7) -- explains run-to-run and box-to-box differences
                          "shader_clock_ghz": 0.1 * st["clk_shader_cycles"] / st["clk_ref_ticks"] if st["clk_ref_ticks"] else None,
                          # `value` per GHz of that clock: what compares runs on different boxes (round 5 saw 2.22-2.34 GHz: 103-110k
                          # gates/s for the same code, 46.6-46.8k per GHz; the driver's round-4 line: 44.6k per GHz)

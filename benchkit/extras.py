@@ -157,6 +157,31 @@ def extras(api, circuits, identify, lib, pd, pp, ks, probe, tmpl, bound, base, p
     assert int(rbh.decrypt(ks)[0]) == (1 if bin(ta ^ tb).count("1") > 40 else 0)
     out["hamming128_match"] = {"match_ms": t * 1e3, "blind_rotates": int(s["blind_rotates"]),
                                "levels": int(s["levels"]), "gates_per_s": s["blind_rotates"] / t}
+    # ... and the same circuit as a 1-to-N identification: ONE probe against 64 enrolled 128-bit templates recorded before one
+    # flush -- a lone match is 37 dependent levels of ~50 gates (latency-bound); 64 of them fill the same 37 levels
+    M = 64
+    enrolled = [rnd.getrandbits(128) for _ in range(M)]
+    enrolled[17] = ta ^ (1 << 5) ^ (1 << 77)                     # one template two bits from the probe: the only match bit 0
+    T = []
+    for v in enrolled:
+        e = circuits.encrypt_number(pp, v, 128, ks); e.set_words(e.words())
+        T.append(e)
+    api.reset_stats()
+    t = time.perf_counter()
+    outs = []
+    for e in T:
+        r_m = api.CiphertextArray(pp, w)
+        circuits.hamming_match(r_m, A, e, 128, hb, ks)
+        outs.append(r_m)
+    api.flush()
+    t = time.perf_counter() - t
+    s = api.stats()
+    got = [int(r_m.decrypt(ks)[0]) for r_m in outs]
+    assert got == [1 if bin(ta ^ v).count("1") > 40 else 0 for v in enrolled] and got.count(0) == 1 and got[17] == 0
+    out["hamming128_identify_64"] = {"matches": M, "seconds": t, "ms_per_match": t * 1e3 / M, "blind_rotates": int(s["blind_rotates"]),
+                                     "levels": int(s["levels"]), "gates_per_s": s["blind_rotates"] / t,
+                                     "checked": "all 64 decrypted match bits == plaintext rule (distance > 40); the near template is the only 0"}
+    del T, outs
     out["independent_gates_4096"] = independent_gates(api, lib, 4096)
     out["independent_gates_sweep"] = independent_gates_sweep(api, lib)
     # the same 128-slot match through the optimised DAG (peba1_function_f_fast; not the reference's
