@@ -384,6 +384,57 @@ def test_function_g_and_hamming_ciphertexts_match_oracle_digests(p128_keys):
         api.set_deferred(False)
 
 
+def test_arithmetic_building_blocks_ciphertexts_match_oracle_digests(p128_keys):
+    """VERDICT r5 "missing 5": the reference's arithmetic helpers one by one at ciphertext level -- ADDN, TwoSComplement, ABS
+    (both signs), SUBN, Multiply and the three shift helpers (/root/reference/src/Math.cpp:54-250; ABS and the shifts are not on
+    the protocol's path, so no whole-circuit digest covers them) -- on the known-answer operands of SURVEY 8(c): SHA-256 of each
+    result's ciphertext words == the oracle's (tests/golden/arith_helpers_digest.json, make_function_f_digest.py --arith),
+    the decrypted values the plaintext ones, the executed blind rotations the oracle's count."""
+    import hashlib
+    import json
+    from peba1_amd import api, circuits, lib
+    pp, ks, _ = p128_keys
+    L, Lc = lib.load(), circuits.load()
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    with open(os.path.join(root, "tests", "golden", "arith_helpers_digest.json")) as f:
+        g = json.load(f)
+    assert g["key_seed"] == 0x5EBA2
+    bits = g["bits"]
+    L.tfhe_hip_set_encrypt_seed(g["encrypt_seed"])
+    E = {k: circuits.encrypt_number(pp, v, bits, ks) for k, v in g["operands"].items()}      # dict order = encryption order
+    carry = api.CiphertextArray(pp, 1)
+    calls = {
+        "add_nbit(122, 204)": lambda r: Lc.peba1_add_nbit(r.ptr, E["a"].ptr, E["b"].ptr, carry.ptr, bits, ks.cloud),
+        "twos_complement(5)": lambda r: Lc.peba1_twos_complement(r.ptr, E["c"].ptr, bits, ks.cloud),
+        "abs(-100)": lambda r: Lc.peba1_abs(r.ptr, E["neg"].ptr, bits, ks.cloud),
+        "abs(37)": lambda r: Lc.peba1_abs(r.ptr, E["pos"].ptr, bits, ks.cloud),
+        "sub_nbit(122, 204)": lambda r: Lc.peba1_sub_nbit(r.ptr, E["a"].ptr, E["b"].ptr, bits, ks.cloud),
+        "multiply(122, 204)": lambda r: Lc.peba1_multiply(r.ptr, E["a"].ptr, E["b"].ptr, bits, ks.cloud),
+        "shift_left(0x35, 3)": lambda r: Lc.peba1_shift_left(r.ptr, E["s"].ptr, bits, 3, ks.cloud),
+        "shift_right(0x35, 2)": lambda r: Lc.peba1_shift_right(r.ptr, E["s"].ptr, bits, 2, ks.cloud),
+        "shift_left_inplace(0x35, 1)": lambda r: Lc.peba1_shift_left_inplace(r.ptr, bits, 1, ks.cloud),
+    }
+    assert [c["name"] for c in g["cases"]] == list(calls)
+    api.set_deferred(True)
+    api.set_tuning("reuse_gates", 0)          # the oracle's count is of every recorded gate
+    api.set_tuning("eliminate_dead", 0)
+    try:
+        for c in g["cases"]:
+            res = E["s"] if c["name"].startswith("shift_left_inplace") else api.CiphertextArray(pp, c["samples"])
+            api.reset_stats()
+            calls[c["name"]](res)
+            words = res.words()                                                        # runs the pending gates
+            assert hashlib.sha256(words.tobytes()).hexdigest() == c["sha256"], c["name"]
+            assert circuits.decrypt_number(res, ks) == c["value"], c["name"]
+            assert api.stats()["blind_rotates"] == c["blind_rotates"], c["name"]
+            if "carry" in c:
+                assert int(carry.decrypt(ks)[0]) == c["carry"]
+    finally:
+        api.set_tuning("reuse_gates", 1)
+        api.set_tuning("eliminate_dead", 1)
+        api.set_deferred(False)
+
+
 def test_gate_reuse_is_transparent(p128_keys):
     """reuse_gates: a 3-slot Function_f with and without sharing of identical pending gates --
     fewer blind rotations, the same 24 output ciphertexts."""

@@ -222,6 +222,26 @@ def test_key_material_has_the_tgsw_and_key_switch_semantics_independently(oracle
         ks.close()
 
 
+def test_arith_helper_fixture_is_what_the_oracle_produces(oracle):
+    """tests/golden/arith_helpers_digest.json (the GPU test test_arithmetic_building_blocks_... compares with it) spot-checked
+    against the oracle here: three of its nine cases re-evaluated through oracle/liboracle_boots.so (TwoSComplement: 64 gates,
+    ABS of a positive operand: 64, a shift helper: none) give the committed values, gate counts and SHA-256."""
+    import importlib.util
+    import json
+    spec = importlib.util.spec_from_file_location("make_digest", os.path.join(ROOT, "tests", "golden", "make_function_f_digest.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    names = {"twos_complement(5)", "abs(37)", "shift_right(0x35, 2)"}
+    got = mod.arith_helpers(only=names, write=False, threads=min(7, os.cpu_count() or 1))
+    with open(os.path.join(ROOT, "tests", "golden", "arith_helpers_digest.json")) as f:
+        want = json.load(f)
+    assert got["operands"] == want["operands"] and got["encrypt_seed"] == want["encrypt_seed"]
+    committed = {c["name"]: c for c in want["cases"]}
+    assert {c["name"] for c in got["cases"]} == names
+    for c in got["cases"]:
+        assert c == committed[c["name"]], c["name"]
+
+
 def test_product_parameter_sets(oracle):
     from peba1_amd import api
     p80 = api.ParameterSet(80)
