@@ -225,19 +225,25 @@ def test_key_material_has_the_tgsw_and_key_switch_semantics_independently(oracle
 def test_arith_helper_fixture_is_what_the_oracle_produces(oracle):
     """tests/golden/arith_helpers_digest.json (the GPU test test_arithmetic_building_blocks_... compares with it) spot-checked
     against the oracle here: three of its nine cases re-evaluated through oracle/liboracle_boots.so (TwoSComplement: 64 gates,
-    ABS of a positive operand: 64, a shift helper: none) give the committed values, gate counts and SHA-256."""
-    import importlib.util
+    ABS of a positive operand: 64, a shift helper: none) give the committed values, gate counts and SHA-256.  In a process
+    of its own: the oracle's gate provider and the product's export the same boots* names, and this process has loaded the
+    product's."""
     import json
-    spec = importlib.util.spec_from_file_location("make_digest", os.path.join(ROOT, "tests", "golden", "make_function_f_digest.py"))
-    mod = importlib.util.module_from_spec(spec)
-    spec.loader.exec_module(mod)
-    names = {"twos_complement(5)", "abs(37)", "shift_right(0x35, 2)"}
-    got = mod.arith_helpers(only=names, write=False, threads=min(7, os.cpu_count() or 1))
+    import subprocess
+    import sys
+    code = ("import importlib.util, json, os, sys\n"
+            "spec = importlib.util.spec_from_file_location('make_digest', os.path.join(%r, 'tests', 'golden', 'make_function_f_digest.py'))\n"
+            "mod = importlib.util.module_from_spec(spec); spec.loader.exec_module(mod)\n"
+            "got = mod.arith_helpers(only={'twos_complement(5)', 'abs(37)', 'shift_right(0x35, 2)'}, write=False, threads=min(7, os.cpu_count() or 1))\n"
+            "print('RESULT', json.dumps(got))\n" % ROOT)
+    run = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=600, cwd=ROOT)
+    assert run.returncode == 0, run.stdout[-1000:] + run.stderr[-2000:]
+    got = json.loads([l for l in run.stdout.splitlines() if l.startswith("RESULT ")][-1][7:])
     with open(os.path.join(ROOT, "tests", "golden", "arith_helpers_digest.json")) as f:
         want = json.load(f)
     assert got["operands"] == want["operands"] and got["encrypt_seed"] == want["encrypt_seed"]
     committed = {c["name"]: c for c in want["cases"]}
-    assert {c["name"] for c in got["cases"]} == names
+    assert {c["name"] for c in got["cases"]} == {"twos_complement(5)", "abs(37)", "shift_right(0x35, 2)"}
     for c in got["cases"]:
         assert c == committed[c["name"]], c["name"]
 
