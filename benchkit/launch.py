@@ -12,22 +12,20 @@ def self_launch(n):
     """The parent of `python bench.py --gpus N` (N > 1, no WORLD_SIZE in the environment): starts
     `python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py <same arguments>` as a CHILD process
     (subprocess; no exec, and this process never initialises the GPU) in a session of its own, rendezvous on the loopback
-    address at a free port, relays the children's output (rank 0's JSON line last, on stdout) and returns the launcher's
-    exit code -- non-zero if any rank failed.  If THIS process is told to stop (SIGTERM, SIGINT: a driver's time limit),
+    address at a port the launcher picks (`--standalone --local-addr 127.0.0.1`), relays the children's output (rank 0's JSON
+    line last, on stdout) and returns the launcher's exit code -- non-zero if any rank failed.  If THIS process is told to stop (SIGTERM, SIGINT: a driver's time limit),
     the launcher and every rank are stopped with it -- SIGTERM to the process group, SIGKILL after a grace period -- so that
     no rank stays behind holding a GPU of a shared box."""
     import signal
-    import socket
     import subprocess
     import time
-    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as sock:     # (bind-close-reuse is racy in principle; the
-        sock.bind(("127.0.0.1", 0))                                     # rendezvous fails loudly if the port was taken)
-        port = sock.getsockname()[1]
-    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    env = dict(os.environ)
     env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")          # dmabuf IPC: what RCCL needs on this driver
     env.setdefault("OMP_NUM_THREADS", "1")
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}",
-           "--master-addr", "127.0.0.1", "--master-port", str(port), BENCH] + sys.argv[1:]
+    # --standalone: the launcher picks a free rendezvous port itself and hands MASTER_ADDR / MASTER_PORT to the ranks (no
+    # probe-then-reuse race, ADVICE r5); --local-addr 127.0.0.1: the container's hostname may not resolve
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--standalone", "--local-addr", "127.0.0.1", "--nnodes=1",
+           f"--nproc-per-node={n}", BENCH] + sys.argv[1:]
     proc = subprocess.Popen(cmd, env=env, cwd=ROOT, stdout=subprocess.PIPE, text=True, bufsize=1, start_new_session=True)
 
     def stop_ranks(grace=10.0):
