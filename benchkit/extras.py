@@ -81,6 +81,24 @@ def extras(api, circuits, identify, lib, pd, pp, ks, probe, tmpl, bound, base, p
     assert (rbd.words() == last.words()).all()
     out["match_library_defaults"] = {"match_ms": t * 1e3, "blind_rotates": int(s["blind_rotates"]),
                                      "gates_shared": int(s["reused_gates"]), "gates_dropped_as_dead": int(s["dead_gates"])}
+    # ... and with the OPT-IN constant folding on top ("fold_constants": a gate with a public constant operand -- a trivial
+    # sample -- is answered without a bootstrap).  Same gate SEQUENCE from the caller, same decrypted match bit; the ciphertext
+    # words are the folded circuit's (its own oracle digest, tests/golden/function_f_128_folded_digest.json), not TFHE's --
+    # which is why it is off unless asked for and why the headline never uses it
+    api.set_tuning("fold_constants", 1)
+    api.reset_stats()
+    t = time.perf_counter()
+    rbc = api.CiphertextArray(pp, 3 * bitsize)
+    circuits.function_f(rbc, probe, tmpl, bound, bitsize, ks)
+    api.flush()
+    t = time.perf_counter() - t
+    s = api.stats()
+    api.set_tuning("fold_constants", 0)
+    assert int(rbc.decrypt(ks)[0]) == int(last.decrypt(ks)[0])
+    out["match_constant_folding_opt_in"] = {"match_ms": t * 1e3, "blind_rotates": int(s["blind_rotates"]), "gates_folded": int(s["folded_gates"]),
+                                            "gates_shared": int(s["reused_gates"]), "gates_dropped_as_dead": int(s["dead_gates"]),
+                                            "levels": int(s["levels"]),
+                                            "note": "opt-in: same calls, same decrypted match bit, NOT TFHE's ciphertext words"}
     api.set_tuning("eliminate_dead", 0)
     api.set_tuning("reuse_gates", 0)
     # BASELINE configs[3] shape, small: one probe against 4 templates in one flush

@@ -147,7 +147,7 @@ void tfhe_hip_set_diag_label(const char *label);
 int tfhe_hip_gate_batch(int gate, LweSample *result, const LweSample *a, const LweSample *b,
                         int32_t count, const TFheGateBootstrappingCloudKeySet *bk);
 
-/* ---- tuning (results never depend on these; ten names) ----
+/* ---- tuning (ten names that results never depend on, and the opt-in "fold_constants") ----
  * "br_variant": which form of the blind-rotate kernel runs wide launches (env TFHE_HIP_BR_VARIANT): -1 (default) =
  * the fastest measured for the ring size (N = 1024: 4 waves per rotation; N = 2048: split), 0 = 4 waves (N = 1024),
  * 2 = split (8 waves, every transform as two half-size ones), 4 = 2 waves (N = 1024; the form with the widest admissible
@@ -172,6 +172,12 @@ int tfhe_hip_gate_batch(int gate, LweSample *result, const LweSample *a, const L
  * observable changes; 0 = evaluate every recorded gate.
  * "balance_levels": 1 (default) = slack-aware level filling at flush, 0 = plain ASAP
  * levels.
+ * "fold_constants": 0 (default) / 1 (env TFHE_HIP_FOLD_CONSTANTS) = OPT-IN constant folding at record time: a gate one of
+ * whose operands is a trivial sample (bootsCONSTANT, a fresh sample, a copy of either: a PUBLIC constant) is not
+ * bootstrapped -- its result is the constant, the other operand or its negation; a MUX with a constant data operand becomes
+ * a two-input gate.  The reference's match circuit loses 62 % of its bootstraps that way.  Decrypted results are the same;
+ * the ciphertext WORDS are not TFHE's (which bootstraps every gate), which is why it is off unless asked for -- the only
+ * tuning results depend on.  The oracle folds by the same rule (orc_boots_set_fold): folded circuits have digests too.
  * "sync_deadline_ms": see "bounded host waits" above.
  * (Environment only: TFHE_HIP_KS_BLOCKS / TFHE_HIP_KS_MAX_SPLITS / TFHE_HIP_KS_SPLIT_TIES, how key switches are cut into
  * coefficient ranges -- engine.hpp.)
@@ -205,6 +211,9 @@ typedef struct TfheHipStats {
     /* recorded gates (and NOTs) dropped at a flush because nothing could ever observe their result: no sample
      * handle held it and no live gate read it ("eliminate_dead") */
     uint64_t dead_gates;
+    /* gates answered WITHOUT a bootstrap because an operand was a public constant (a trivial sample): "fold_constants",
+     * opt-in; a MUX turned into a two-input gate counts once */
+    uint64_t folded_gates;
 } TfheHipStats;
 void tfhe_hip_get_stats(TfheHipStats *out);
 void tfhe_hip_reset_stats(void);

@@ -245,11 +245,45 @@ static const Torus32 *value_words(const LweSample *s) {     /* recording mode: t
     return g_nodes[node_of(s)].w;
 }
 
+/* Constant folding (recording mode only; orc_boots_set_fold(1)): the rule the product's recorder applies under its opt-in
+ * tuning "fold_constants" (peba1_amd/csrc/shim.cpp), restated -- a gate with a public constant operand (THE zero / one
+ * node: bootsCONSTANT, a fresh sample, copies of them) is not bootstrapped: its result is a constant, the other operand or
+ * its negation; a MUX with a constant data operand is a two-input gate.  TFHE itself bootstraps every gate: a folded
+ * circuit's ciphertexts are NOT TFHE's, only its decryptions -- which is why both sides keep it off unless asked. */
+static int g_fold = 0;
+static long long g_folded = 0;
+void orc_boots_set_fold(int on) { g_fold = on != 0; }
+long long orc_boots_folded(void) { return g_folded; }
+static int const_of(int32_t node) { return node >= 0 && node == g_const_node[0] ? 0 : node >= 0 && node == g_const_node[1] ? 1 : -1; }
+static const unsigned char GATE_TT[ORC_NGATES2][4] = {      /* [gate][2 a + b], enum OrcGate order */
+    {1, 1, 1, 0}, {0, 1, 1, 1}, {0, 0, 0, 1}, {1, 0, 0, 0}, {0, 1, 1, 0}, {1, 0, 0, 1},
+    {0, 1, 0, 0}, {0, 0, 1, 0}, {1, 1, 0, 1}, {1, 0, 1, 1},
+};
+static int32_t not_node(int32_t ia) {
+    if (g_fold && const_of(ia) >= 0) return const_node(1 - const_of(ia));
+    return node_gate(ORC_NOT, ia, -1, -1);
+}
+static int32_t gate2_node(int g, int32_t ia, int32_t ib) {
+    if (g_fold) {
+        const int ka = const_of(ia), kb = const_of(ib);
+        if (ka >= 0 || kb >= 0) {
+            const unsigned char *tt = GATE_TT[g];
+            const int f0 = ka >= 0 ? tt[2 * ka + (kb >= 0 ? kb : 0)] : tt[kb];
+            const int f1 = ka >= 0 ? tt[2 * ka + (kb >= 0 ? kb : 1)] : tt[2 + kb];
+            ++g_folded;
+            if (f0 == f1) return const_node(f0);
+            if (f0 == 0) return ka >= 0 ? ib : ia;
+            return not_node(ka >= 0 ? ib : ia);
+        }
+    }
+    ++g_gates;
+    return node_gate(g, ia, ib, -1);
+}
+
 static void gate2(int g, LweSample *r, const LweSample *a, const LweSample *b) {
     if (g_rec_threads > 0) {
         const int32_t ia = node_of(a), ib = node_of(b);
-        r->slot = node_gate(g, ia, ib, -1);
-        ++g_gates;
+        r->slot = gate2_node(g, ia, ib);
         return;
     }
     const size_t nw = (size_t)g_ks->p.n + 1;
@@ -274,6 +308,18 @@ void bootsMUX(LweSample *r, const LweSample *a, const LweSample *b, const LweSam
     (void)k;
     if (g_rec_threads > 0) {
         const int32_t ia = node_of(a), ib = node_of(b), ic = node_of(c);
+        if (g_fold) {
+            const int ka = const_of(ia), kb = const_of(ib), kc = const_of(ic);
+            if (ka >= 0 || kb >= 0 || kc >= 0 || ib == ic) {
+                ++g_folded;
+                if (ka >= 0) r->slot = ka ? ib : ic;
+                else if (ib == ic) r->slot = ib;
+                else if (kb >= 0 && kc >= 0) r->slot = kb == 1 ? ia : not_node(ia);
+                else if (kc >= 0) r->slot = gate2_node(kc == 0 ? ORC_AND : ORC_ORNY, ia, ib);
+                else r->slot = gate2_node(kb == 0 ? ORC_ANDNY : ORC_OR, ia, ic);
+                return;
+            }
+        }
         r->slot = node_gate(ORC_MUX, ia, ib, ic);
         g_gates += 2;
         return;
@@ -288,7 +334,7 @@ void bootsMUX(LweSample *r, const LweSample *a, const LweSample *b, const LweSam
 }
 void bootsNOT(LweSample *r, const LweSample *a, const TFheGateBootstrappingCloudKeySet *k) {
     (void)k;
-    if (g_rec_threads > 0) { r->slot = node_gate(ORC_NOT, node_of(a), -1, -1); return; }
+    if (g_rec_threads > 0) { r->slot = not_node(node_of(a)); return; }
     for (int32_t i = 0; i < g_ks->p.n; ++i) r->a[i] = (Torus32)(0u - (uint32_t)a->a[i]);
     r->b = (Torus32)(0u - (uint32_t)a->b);
 }

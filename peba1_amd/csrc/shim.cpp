@@ -86,6 +86,12 @@ const GateLin GATE_LIN[10] = {
     {-1, -1, 1}, {-1, 1, -1}, {1, -1, 1}, {1, 1, -1},
 };
 
+// truth tables of the two-input gates, index [gate code][2 a + b] (enum TfheHipGate; GATE_LIN's signs say the same)
+const uint8_t GATE_TT[10][4] = {
+    {1, 1, 1, 0}, {0, 1, 1, 1}, {0, 0, 0, 1}, {1, 0, 0, 0}, {0, 1, 1, 0}, {1, 0, 0, 1},
+    {0, 1, 0, 0}, {0, 0, 1, 0}, {1, 1, 0, 1}, {1, 0, 1, 1},
+};
+
 struct Recorder {
     std::recursive_mutex mtx;
     // Default: deferred.  The reference (and any caller that stays inside the tfhe C API) never
@@ -117,6 +123,15 @@ struct Recorder {
     // ripple adders compute a carry out of their last bit and drop it (Math.cpp:60-64 into a freed temporary): 5 of the
     // 7 gates of that bit, ~55 gates per slot of the match.
     bool eliminate_dead = true;
+    // Constant folding at record time (round 6; OPT-IN: tuning "fold_constants", env TFHE_HIP_FOLD_CONSTANTS).  A trivial
+    // sample -- bootsCONSTANT, a fresh sample, a copy of either -- is a PUBLIC constant, and a gate with such an operand
+    // needs no bootstrap to be evaluated: its result is a constant, the other operand, or its negation (linear); a MUX with
+    // a constant data operand is a two-input gate.  The reference's circuits are full of them (zero-padded partial products,
+    // adders fed with constant zeros: 62 % of the 215,544 gates of a 128-slot Function_f).  Decrypted results are the
+    // same; the CIPHERTEXTS are not what TFHE produces (it bootstraps every gate whatever its operands), which is why this is
+    // off by default -- the drop-in's contract is TFHE's words.  The oracle's provider folds by the same rule
+    // (oracle/boots_oracle.c orc_boots_set_fold), so folded circuits have oracle digests of their own.
+    bool fold_constants = false;
     // operations of a flush that was launched without waiting (tfhe_hip_flush_async): their pending references are
     // released when the flush is known to be complete (finish_flight_locked)
     std::vector<PendingOp> flight_ops;
@@ -134,6 +149,7 @@ Recorder &rec() {
     static Recorder r;
     static bool init = [] {
         if (const char *e = std::getenv("TFHE_HIP_DEFERRED")) r.deferred = std::atoi(e) != 0;
+        if (const char *e = std::getenv("TFHE_HIP_FOLD_CONSTANTS")) r.fold_constants = std::atoi(e) != 0;   // opt-in (Recorder)
         return true;
     }();
     (void)init;
@@ -233,6 +249,15 @@ void record_gate2(int code, LweSample *result, const LweSample *ca, const LweSam
         record_gate2_locked(code, result, ca, cb, bk);
     });
 }
+// 0 / 1 if `slot` is one of the pool's shared trivial samples (a public constant), else -1
+int const_bit(const SlotPool *pool, int32_t slot) { return slot == pool->const_slot[0] ? 0 : slot == pool->const_slot[1] ? 1 : -1; }
+void point_at(LweSample *result, SlotPool *pool, int32_t slot) {        // result becomes (a handle of) `slot`: a COPY
+    pool->retain(slot);
+    repoint(result, pool, slot);
+    finish_op(result);
+}
+void not_locked(LweSample *result, const LweSample *ca, const TFheGateBootstrappingCloudKeySet *bk);
+
 void record_gate2_locked(int code, LweSample *result, const LweSample *ca, const LweSample *cb,
                          const TFheGateBootstrappingCloudKeySet *bk) {
     Recorder &r = rec();
@@ -240,6 +265,19 @@ void record_gate2_locked(int code, LweSample *result, const LweSample *ca, const
     SlotPool *pool = r.pool;
     bind_pool(result, pool);                  // refuse a foreign / mismatched result before anything changes
     const int32_t sa = ensure_slot(ca, pool), sb = ensure_slot(cb, pool);
+    if (r.fold_constants) {
+        const int ka = const_bit(pool, sa), kb = const_bit(pool, sb);
+        if (ka >= 0 || kb >= 0) {
+            // the gate as a function of its non-constant operand x: f(0), f(1)
+            const uint8_t *tt = GATE_TT[code];
+            const int f0 = ka >= 0 ? tt[2 * ka + (kb >= 0 ? kb : 0)] : tt[kb];
+            const int f1 = ka >= 0 ? tt[2 * ka + (kb >= 0 ? kb : 1)] : tt[2 + kb];
+            ++Engine::get().stats.folded_gates;
+            if (f0 == f1) return point_at(result, pool, pool->const_slot[f0]);          // a constant
+            if (f0 == 0) return point_at(result, pool, ka >= 0 ? sb : sa);                // x itself
+            return not_locked(result, ka >= 0 ? cb : ca, bk);                             // NOT x: linear, no bootstrap
+        }
+    }
     uint64_t key = 0;
     if (r.reuse_gates) {
         const bool symmetric = GATE_LIN[code].sa == GATE_LIN[code].sb;   // t = c0 + s (A + B)
@@ -617,19 +655,22 @@ void bootsCOPY(LweSample *result, const LweSample *ca, const TFheGateBootstrappi
     });
 }
 
-static void not_locked(LweSample *result, const LweSample *ca, const TFheGateBootstrappingCloudKeySet *bk);
 void bootsNOT(LweSample *result, const LweSample *ca, const TFheGateBootstrappingCloudKeySet *bk) {
     guarded([&] {
         std::lock_guard<std::recursive_mutex> g(rec().mtx);
         not_locked(result, ca, bk);
     });
 }
-static void not_locked(LweSample *result, const LweSample *ca, const TFheGateBootstrappingCloudKeySet *bk) {
+}  // extern "C"
+namespace {
+void not_locked(LweSample *result, const LweSample *ca, const TFheGateBootstrappingCloudKeySet *bk) {
     Recorder &r = rec();
     begin_op(bk);
     SlotPool *pool = r.pool;
     bind_pool(result, pool);
     const int32_t sa = ensure_slot(ca, pool);
+    if (r.fold_constants && const_bit(pool, sa) >= 0)             // NOT of a public constant is the other constant
+        return point_at(result, pool, pool->const_slot[1 - const_bit(pool, sa)]);
     {   // NOT of a still-pending NOT: -(-x) = x exactly, so alias the original operand; two NOTs
         // of one level would otherwise sit in the same launch and race
         auto it = r.not_origin.find(sa);
@@ -662,6 +703,8 @@ static void not_locked(LweSample *result, const LweSample *ca, const TFheGateBoo
     repoint(result, pool, dst);
     finish_op(result);
 }
+}  // namespace
+extern "C" {
 
 void bootsNAND(LweSample *r_, const LweSample *a, const LweSample *b, const TFheGateBootstrappingCloudKeySet *bk) { record_gate2(TFHE_HIP_NAND, r_, a, b, bk); }
 void bootsOR(LweSample *r_, const LweSample *a, const LweSample *b, const TFheGateBootstrappingCloudKeySet *bk) { record_gate2(TFHE_HIP_OR, r_, a, b, bk); }
@@ -690,6 +733,21 @@ static void mux_locked(LweSample *result, const LweSample *a, const LweSample *b
     SlotPool *pool = r.pool;
     bind_pool(result, pool);
     const int32_t sa = ensure_slot(a, pool), sb = ensure_slot(b, pool), sc = ensure_slot(c, pool);
+    if (r.fold_constants) {
+        const int ka = const_bit(pool, sa), kb = const_bit(pool, sb), kc = const_bit(pool, sc);
+        if (ka >= 0 || kb >= 0 || kc >= 0 || sb == sc) {
+            ++Engine::get().stats.folded_gates;
+            if (ka >= 0) return point_at(result, pool, ka ? sb : sc);                     // a constant selector picks an operand
+            if (sb == sc) return point_at(result, pool, sb);                                // both data operands the same sample
+            if (kb >= 0 && kc >= 0) {                                                       // (kb != kc here)  MUX(a, 1, 0) = a, MUX(a, 0, 1) = NOT a
+                if (kb == 1) return point_at(result, pool, sa);
+                return not_locked(result, a, bk);
+            }
+            // one constant data operand: a two-input gate, one blind rotation instead of two
+            if (kc >= 0) return record_gate2_locked(kc == 0 ? TFHE_HIP_AND : TFHE_HIP_ORNY, result, a, b, bk);   // a & b | !a | b
+            return record_gate2_locked(kb == 0 ? TFHE_HIP_ANDNY : TFHE_HIP_OR, result, a, c, bk);               // !a & c | a | c
+        }
+    }
     if (r.reuse_gates) {
         auto it = r.pending_mux.find({sa, sb, sc});
         if (it != r.pending_mux.end()) {
@@ -994,6 +1052,7 @@ int tfhe_hip_set_tuning(const char *name, int64_t value) {
     if (name && std::strcmp(name, "br_variant") == 0) { Engine::get().br_variant = (int)value; return 0; }
     if (name && std::strcmp(name, "reuse_gates") == 0) { rec().reuse_gates = value != 0; return 0; }
     if (name && std::strcmp(name, "eliminate_dead") == 0) { rec().eliminate_dead = value != 0; return 0; }
+    if (name && std::strcmp(name, "fold_constants") == 0) { rec().fold_constants = value != 0; return 0; }
     if (name && std::strcmp(name, "balance_levels") == 0) { rec().balance_levels = value != 0; return 0; }
     if (name && std::strcmp(name, "sync_deadline_ms") == 0) { Engine::get().sync_deadline_ms = value > 0 ? (long long)value : 0; return 0; }
     set_error(std::string("tfhe_hip_set_tuning: unknown name ") + (name ? name : "(null)"));

@@ -53,7 +53,8 @@ class Stats(C.Structure):
                 ("ms_blind_rotate", C.c_double), ("ms_keyswitch", C.c_double), ("ms_flush_wall", C.c_double),
                 ("ms_blind_rotate_busy", C.c_double), ("reused_gates", C.c_uint64),
                 ("br8_launches", C.c_uint64), ("br8_rotations", C.c_uint64), ("ms_blind_rotate8", C.c_double),
-                ("clk_shader_cycles", C.c_uint64), ("clk_ref_ticks", C.c_uint64), ("dead_gates", C.c_uint64)]
+                ("clk_shader_cycles", C.c_uint64), ("clk_ref_ticks", C.c_uint64), ("dead_gates", C.c_uint64),
+                ("folded_gates", C.c_uint64)]
 
 
 PS = C.POINTER(ParameterSet)

@@ -339,6 +339,121 @@ def test_function_f_128_slots_ciphertexts_match_oracle_digest(p128_keys):
         api.set_deferred(False)
 
 
+@pytest.mark.parametrize("fixture", ["function_f_2_folded_digest.json", "function_f_128_folded_digest.json"])
+def test_constant_folding_reproduces_the_oracles_folded_digest(p128_keys, fixture):
+    """Round 6, opt-in tuning "fold_constants": a gate with a public constant operand (a trivial sample: bootsCONSTANT, a fresh
+    sample, a copy of either) is answered without a bootstrap -- the constant, the other operand, or its negation; a MUX with a
+    constant data operand becomes a two-input gate.  The reference's own Function_f (/root/reference/src/Math.cpp:379-387,
+    unchanged gate sequence) then bootstraps 38 % of its gates: 82,499 of 215,544 at 128 slots.  The folded circuit's
+    ciphertexts are NOT TFHE's words (TFHE bootstraps every gate) -- so the oracle's provider folds by the same rule
+    (oracle/boots_oracle.c orc_boots_set_fold) and THIS test compares with its digest, word for word; the match bits are the
+    unfolded run's.  Default off: every other test in the suite runs with TFHE's words."""
+    import hashlib
+    import json
+    from types import SimpleNamespace
+    from peba1_amd import api, circuits, lib
+    pp, ks, _ = p128_keys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    path = os.path.join(root, "tests", "golden", fixture)
+    if not os.path.exists(path):
+        pytest.fail(f"{fixture} is missing: tests/golden/make_function_f_digest.py --slots128 --fold [--nslots N]")
+    with open(path) as f:
+        g = json.load(f)
+    assert g["key_seed"] == 0x5EBA2 and g["constant_folding"] is True
+    L = lib.load()
+    L.tfhe_hip_set_encrypt_seed(g["encrypt_seed"])
+    template = [(37 * i + 11) % 255 for i in range(g["nslots"])]
+    probe = [t + 1 for t in template]
+    T, S = [], []
+    for t, s in zip(template, probe):                    # encryption order is part of the fixture
+        T.append(circuits.encrypt_number(pp, t, g["bits"], ks))
+        S.append(circuits.encrypt_number(pp, s, g["bits"], ks))
+    bounds = [circuits.encrypt_number(pp, b, 3 * g["bits"], ks) for b in g["bounds"]]
+    api.set_deferred(True)
+    api.set_tuning("fold_constants", 1)
+    api.set_tuning("reuse_gates", 0)                     # so that the executed rotations are the oracle's recorded count exactly
+    api.set_tuning("eliminate_dead", 0)
+    try:
+        for run, bound in zip(g["runs"], bounds):
+            rb = api.CiphertextArray(pp, 3 * g["bits"])
+            api.reset_stats()
+            circuits.function_f(rb, SimpleNamespace(slots=S), SimpleNamespace(slots=T), bound, g["bits"], ks)
+            words = rb.words()                           # runs the pending gates
+            st = api.stats()
+            assert st["blind_rotates"] == run["blind_rotates_recorded"] and st["folded_gates"] > st["blind_rotates"]
+            assert hashlib.sha256(words[0].tobytes()).hexdigest() == run["result_b0_sha256"], run["bound"]
+            assert hashlib.sha256(words.tobytes()).hexdigest() == run["result_b_sha256"], run["bound"]
+            assert rb.decrypt(ks)[0] == run["match_bit"] == (1 if g["distance"] > run["bound"] else 0)
+        # ... and with the library's defaults on top (gate sharing, dead-gate elimination): the same words from fewer rotations
+        api.set_tuning("reuse_gates", 1)
+        api.set_tuning("eliminate_dead", 1)
+        rb = api.CiphertextArray(pp, 3 * g["bits"])
+        api.reset_stats()
+        circuits.function_f(rb, SimpleNamespace(slots=S), SimpleNamespace(slots=T), bounds[0], g["bits"], ks)
+        assert hashlib.sha256(rb.words()[0].tobytes()).hexdigest() == g["runs"][0]["result_b0_sha256"]
+        assert api.stats()["blind_rotates"] < g["runs"][0]["blind_rotates_recorded"]
+    finally:
+        api.set_tuning("fold_constants", 0)
+        api.set_tuning("reuse_gates", 1)
+        api.set_tuning("eliminate_dead", 1)
+        api.set_deferred(False)
+
+
+def test_constant_folding_truth_tables(p128_keys):
+    """Every two-input gate with a constant on either side, NOT of a constant, and every MUX with constants among its operands,
+    folded ("fold_constants" 1) against the same call bootstrapped (default): the same decrypted bit for every value of the
+    non-constant operands -- and no blind rotation where the rule says none is needed."""
+    import itertools
+    from peba1_amd import api, lib
+    pp, ks, _ = p128_keys
+    L = lib.load()
+    gates = ["NAND", "OR", "AND", "NOR", "XOR", "XNOR", "ANDNY", "ANDYN", "ORNY", "ORYN"]
+    fn = {g: getattr(L, "boots" + g) for g in gates}
+    tt = {"NAND": lambda a, b: 1 - (a & b), "OR": lambda a, b: a | b, "AND": lambda a, b: a & b, "NOR": lambda a, b: 1 - (a | b),
+          "XOR": lambda a, b: a ^ b, "XNOR": lambda a, b: 1 - (a ^ b), "ANDNY": lambda a, b: (1 - a) & b, "ANDYN": lambda a, b: a & (1 - b),
+          "ORNY": lambda a, b: (1 - a) | b, "ORYN": lambda a, b: a | (1 - b)}
+    x = api.CiphertextArray(pp, 2).encrypt([0, 1], ks)               # the variable operand: an encrypted 0 and an encrypted 1
+    k = api.CiphertextArray(pp, 2)
+    L.bootsCONSTANT(k.at(0), 0, ks.cloud); L.bootsCONSTANT(k.at(1), 1, ks.cloud)
+    api.set_deferred(True)
+    api.set_tuning("fold_constants", 1)
+    try:
+        api.reset_stats()
+        cases = []
+        for g in gates:
+            for xv, kv, const_first in itertools.product((0, 1), (0, 1), (False, True)):
+                r = api.CiphertextArray(pp, 1)
+                if const_first:
+                    fn[g](r.at(0), k.at(kv), x.at(xv), ks.cloud); want = tt[g](kv, xv)
+                else:
+                    fn[g](r.at(0), x.at(xv), k.at(kv), ks.cloud); want = tt[g](xv, kv)
+                cases.append((g, xv, kv, const_first, r, want))
+        for kv in (0, 1):
+            r = api.CiphertextArray(pp, 1)
+            L.bootsNOT(r.at(0), k.at(kv), ks.cloud)
+            cases.append(("NOT", None, kv, True, r, 1 - kv))
+        # MUX(a, b, c) = a ? b : c with every operand a constant (0 / 1) or a variable (None)
+        mux_rot = 0
+        for sel, b_, c_ in itertools.product((0, 1, None), repeat=3):
+            if sel is None and b_ is None and c_ is None:
+                continue
+            for va, vb, vc in itertools.product((0, 1), repeat=3):
+                ops = [k.at(o) if o is not None else x.at(v) for o, v in ((sel, va), (b_, vb), (c_, vc))]
+                a_val, b_val, c_val = (o if o is not None else v for o, v in ((sel, va), (b_, vb), (c_, vc)))
+                r = api.CiphertextArray(pp, 1)
+                L.bootsMUX(r.at(0), ops[0], ops[1], ops[2], ks.cloud)
+                cases.append(("MUX", (sel, b_, c_), (va, vb, vc), None, r, b_val if a_val else c_val))
+        api.flush()
+        st = api.stats()
+        # two-input gates and NOTs with a constant operand never rotate; a MUX does only as a two-input gate on two variables
+        assert st["folded_gates"] == len(cases) - 2 and st["blind_rotates"] <= 4 * 8
+        for name, p1, p2, p3, r, want in cases:
+            assert int(r.decrypt(ks)[0]) == want, (name, p1, p2, p3)
+    finally:
+        api.set_tuning("fold_constants", 0)
+        api.set_deferred(False)
+
+
 def test_function_g_and_hamming_ciphertexts_match_oracle_digests(p128_keys):
     """the protocol's second function and the Hamming workload were checked at decrypt level only.
     peba1_function_g (Math.cpp:390-417, b = 1: selects r1; 2,874 blind rotations) and peba1_hamming_match on 16-bit words

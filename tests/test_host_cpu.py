@@ -248,6 +248,64 @@ def test_arith_helper_fixture_is_what_the_oracle_produces(oracle):
         assert c == committed[c["name"]], c["name"]
 
 
+def test_oracle_constant_folding_keeps_the_decryptions_and_drops_the_bootstraps(oracle):
+    """oracle/boots_oracle.c orc_boots_set_fold (the rule of the product's opt-in "fold_constants", restated): the reference's
+    8-bit multiplier (Math.cpp:214-250: zero-padded partial products into 23-bit ripple adders) on 122 x 204, recorded with
+    and without folding -- the same 23 decrypted bits (24,888), 1,296 bootstraps against fewer than half of that, and
+    DIFFERENT ciphertext words (folding is not TFHE's evaluation; that is why it is opt-in).  In a process of its own (the
+    oracle's gate provider and the product's export the same boots* names)."""
+    import json
+    import subprocess
+    import sys
+    code = r'''
+import ctypes as C, hashlib, json, os, sys
+import numpy as np
+sys.path.insert(0, %r)
+from oracle import pyoracle as O
+B = C.CDLL(os.path.join(%r, "oracle", "liboracle_boots.so"))
+V, I = C.c_void_p, C.c_int
+B.orc_keygen.restype = V; B.orc_keygen.argtypes = [C.POINTER(O.OrcParams), C.c_uint64]
+B.orc_boots_bind.argtypes = [V, C.c_uint64]
+B.orc_boots_params.restype = V; B.orc_boots_cloud.restype = V
+B.orc_boots_gate_count.restype = C.c_longlong; B.orc_boots_folded.restype = C.c_longlong
+B.new_gate_bootstrapping_ciphertext_array.restype = V; B.new_gate_bootstrapping_ciphertext_array.argtypes = [C.c_int32, V]
+B.bootsSymEncrypt.argtypes = [V, C.c_int32, V]; B.bootsSymDecrypt.argtypes = [V, V]
+B.orc_boots_export.argtypes = [V, C.c_int32, V]
+B.peba1_multiply.argtypes = [V, V, V, I, V]; B.peba1_multiply.restype = None
+p = O.params("P128")
+ks = B.orc_keygen(C.byref(p), 0x5EBA2)
+out = {}
+for fold in (0, 1):
+    B.orc_boots_bind(ks, 4242)
+    B.orc_boots_set_recording(min(7, os.cpu_count() or 1))
+    B.orc_boots_set_fold(fold)
+    params, cloud = B.orc_boots_params(), B.orc_boots_cloud()
+    def enc(v):
+        a = B.new_gate_bootstrapping_ciphertext_array(8, params)
+        for i in range(8):
+            B.bootsSymEncrypt(a + i * 24, (v >> i) & 1, None)
+        return a
+    ea, eb = enc(122), enc(204)
+    res = B.new_gate_bootstrapping_ciphertext_array(23, params)
+    before = B.orc_boots_gate_count()
+    B.peba1_multiply(res, ea, eb, 8, cloud)
+    w = np.zeros((23, p.n + 1), dtype=np.int32)
+    B.orc_boots_export(res, 23, w.ctypes.data_as(V))
+    out[fold] = {"value": sum(B.bootsSymDecrypt(res + i * 24, None) << i for i in range(23)),
+                 "gates": int(B.orc_boots_gate_count() - before), "folded": int(B.orc_boots_folded()),
+                 "sha": hashlib.sha256(w.tobytes()).hexdigest()}
+print("RESULT", json.dumps(out))
+''' % (ROOT, ROOT)
+    run = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=900, cwd=ROOT)
+    assert run.returncode == 0, run.stdout[-1000:] + run.stderr[-2000:]
+    out = json.loads([l for l in run.stdout.splitlines() if l.startswith("RESULT ")][-1][7:])
+    plain, folded = out["0"], out["1"]
+    assert plain["value"] == folded["value"] == 122 * 204
+    assert plain["gates"] == 1296 and plain["folded"] == 0
+    assert 0 < folded["gates"] < 1296 // 2 and folded["folded"] > 0
+    assert plain["sha"] != folded["sha"]
+
+
 def test_product_parameter_sets(oracle):
     from peba1_amd import api
     p80 = api.ParameterSet(80)
